@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark (BASELINE.json: "BPE merges/sec + pair-count
+GB/s vs HBM roofline").
+
+    python bench.py [--gpus N --steps K --warmup W]
+
+Workload (N=1): BASELINE.json configs[1] -- BasicTokenizer.train on 100 MB of
+synthetic UTF-8 (synth_text(100_000_000, seed=1)), vocab 4096 = 3840 merges, one
+MI355X.  A "step" is one complete train() over the stream: widen the resident
+bytes to ids, then 3840 x (pair statistics, arg-max with the reference's
+tie-break, merge).  The bytes are uploaded once, before the timed region (the
+PCIe-inclusive rate is noted in DESIGN.md, never reported as `value`).
+
+Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel class,
+timed with hipEvents on the library's own stream during the timed steps;
+`cpu_baseline` is the CPU oracle (a C port of the reference's loop, one thread)
+on the first iterations of the same stream, on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bytes", type=int, default=100_000_000, help="stream size per GPU")
+    ap.add_argument("--vocab", type=int, default=4096)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--mode", type=int, default=int(os.environ.get("BPE_MODE", "-1")),
+                    help="-1 library default | 0 recount | 1 delta")
+    ap.add_argument("--cpu-iters", type=int, default=4, help="oracle iterations for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch  # device sync + torch.distributed (RCCL) plumbing only
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import minbpe_amd
+    from minbpe_amd import Engine
+
+    num_merges = args.vocab - 256
+    # BasicTokenizer's single stream does not shard ("replicas only"):
+    # with N > 1 each rank trains its own stream (different seed), weak scaling.
+    data = minbpe_amd.synth_text(args.bytes, args.seed + rank)
+    eng = Engine(local_rank)
+    if args.mode >= 0:
+        eng.set_option("mode", args.mode)
+    eng.load_bytes(data)  # H2D once, outside the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train(num_merges)
+    eng.set_option("profile", 1)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = eng.train(num_merges)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = eng.prof_read()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    merges_total = num_merges * args.steps * world
+    value = merges_total / dt
+
+    # dominant kernel class by device time -> roofline
+    hot = max(("pair_count", "merge", "widen"), key=lambda k: prof[k]["ms"])
+    hp = prof[hot]
+    achieved = hp["alg_bytes"] / (hp["ms"] * 1e-3) / 1e9 if hp["ms"] > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": hot, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "launches": hp["launches"], "avg_launch_ms": round(hp["ms"] / max(hp["launches"], 1), 5),
+        "alg_bytes_per_launch": hp["alg_bytes"] // max(hp["launches"], 1),
+    }
+    # the two figures the metric names, over the whole timed region
+    pc, mg = prof["pair_count"], prof["merge"]
+    extra = {
+        "pair_count_GBps": round(pc["alg_bytes"] / (pc["ms"] * 1e-3) / 1e9, 1) if pc["ms"] else None,
+        "merge_GBps": round(mg["alg_bytes"] / (mg["ms"] * 1e-3) / 1e9, 1) if mg["ms"] else None,
+        "iter_GBps": round((pc["alg_bytes"] + mg["alg_bytes"]) /
+                           ((pc["ms"] + mg["ms"] + prof["argmax"]["ms"] + prof["table"]["ms"]) * 1e-3) / 1e9, 1),
+        "device_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+        "final_len": res["lens"][-1] if res["lens"] else len(data),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and args.cpu_iters > 0:
+        import oracle
+        t0 = time.perf_counter()
+        cp, _, _ = oracle.train(data, args.cpu_iters)
+        ct = time.perf_counter() - t0
+        assert cp == res["pairs"][:args.cpu_iters], "GPU merges differ from the CPU oracle"
+        cpu_baseline = {
+            "value": round(args.cpu_iters / ct, 4), "unit": "merges/s", "cores": 1, "kind": "port",
+            "sample": f"first {args.cpu_iters} iterations (get_stats+max+merge) of the same "
+                      f"{args.bytes}-byte stream, oracle/bpe_oracle.c, single thread",
+        }
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "BPE merges/sec", "value": round(value, 2), "unit": "merges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"BasicTokenizer.train, {args.bytes} B synthetic UTF-8 per GPU, "
+                                   f"vocab {args.vocab} ({num_merges} merges), bit-exact vs oracle",
+                       "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
+                       "parallelism": f"replicas x{world}" if world > 1 else "single"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, **extra,
+        }))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

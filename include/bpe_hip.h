@@ -1,0 +1,119 @@
+/*
+ * bpe_hip.h -- C-ABI of libbpe_hip.so, the MI355X (gfx950) BPE train/encode engine.
+ *
+ * This is the drop-in boundary for minbpe's hot path.  The reference
+ * (karpathy/minbpe) has no FFI of its own: its boundary is the Python surface
+ * minbpe/__init__.py:1-4.  Each entry point below names the reference code it
+ * replaces; minbpe_amd/ (Python, ctypes) mirrors the reference classes on top.
+ *
+ * Conventions
+ *   - every call returns BPE_OK (0) or a negative status; no C++ exception
+ *     crosses the ABI; bpe_last_error() gives a human-readable message.
+ *   - the caller owns every host buffer for the duration of the call; the
+ *     library owns all device memory, tied to the ctx, freed by bpe_destroy.
+ *   - a ctx is bound to one GPU and is not thread-safe.  One ctx per GPU.
+ *   - token ids are int32 (minbpe: Python ints; new id = 256 + i, basic.py:37).
+ *   - chunk_offsets: n_chunks START offsets into the byte/id stream, ascending,
+ *     chunk_offsets[0] == 0; NULL (n_chunks ignored) = one chunk.  Pairs never
+ *     span chunks (regex.py:44,60).
+ */
+#ifndef BPE_HIP_H
+#define BPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPE_OK 0
+#define BPE_E_HIP (-1)         /* a HIP runtime call failed (see bpe_last_error) */
+#define BPE_E_ARG (-2)         /* bad argument */
+#define BPE_E_EMPTY_STATS (-3) /* stats dict empty: minbpe raises ValueError from max() (basic.py:35, regex.py:56) */
+#define BPE_E_STATE (-4)       /* call out of order (e.g. train before load) */
+#define BPE_E_CAP (-5)         /* caller's output buffer too small */
+#define BPE_E_LIMIT (-6)       /* size beyond what this build supports */
+#define BPE_E_INTERNAL (-7)    /* device-side consistency check failed */
+
+typedef struct bpe_ctx bpe_ctx;
+
+/* ---- lifetime -------------------------------------------------------------- */
+int bpe_create(int device_id, bpe_ctx **out);
+void bpe_destroy(bpe_ctx *ctx);
+const char *bpe_last_error(bpe_ctx *ctx); /* ctx may be NULL: last create error */
+/* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's
+ * current stream, so collectives issued by the host order with our kernels). */
+int bpe_set_stream(bpe_ctx *ctx, void *hip_stream);
+/* Knobs: "mode" = 0 recount (get_stats every iteration, the literal reference
+ * loop) | 1 delta (pair table kept current by the merge pass).  "profile" =
+ * 1 records hipEvents around every hot kernel.  Unknown names -> BPE_E_ARG. */
+int bpe_set_option(bpe_ctx *ctx, const char *name, int64_t value);
+
+/* ---- input ----------------------------------------------------------------- */
+/* text.encode("utf-8") -> list(bytes)  (basic.py:25-26; per chunk regex.py:44).
+ * Uploads the bytes; they stay resident so bpe_train can be re-run. */
+int bpe_load_bytes(bpe_ctx *ctx, const uint8_t *bytes, uint64_t n,
+                   const uint64_t *chunk_offsets, uint64_t n_chunks);
+/* Arbitrary id lists, for the module-level get_stats()/merge() drop-ins
+ * (base.py:13-41 called on user lists). */
+int bpe_load_ids(bpe_ctx *ctx, const int32_t *ids, uint64_t n,
+                 const uint64_t *chunk_offsets, uint64_t n_chunks);
+
+/* ---- single-step hot functions (parity tests, module-level drop-ins) ------- */
+/* get_stats(ids) over all chunks into one table (base.py:13-22, regex.py:51-54).
+ * Also records each pair's first position (dict insertion order, F3). */
+int bpe_get_stats(bpe_ctx *ctx, uint64_t *n_pairs_out);
+/* Read back the table of the last bpe_get_stats, unordered; sort by first_pos
+ * to obtain the reference's dict order. */
+int bpe_read_stats(bpe_ctx *ctx, int32_t *a, int32_t *b, uint64_t *cnt,
+                   uint64_t *first_pos, uint64_t cap, uint64_t *n_out);
+/* max(stats, key=stats.get) with first-occurrence tie-break (basic.py:35) on
+ * the current ids: returns the pair and its count, BPE_E_EMPTY_STATS if none. */
+int bpe_argmax(bpe_ctx *ctx, int32_t *a, int32_t *b, uint64_t *count);
+/* merge(ids, pair, idx) on every chunk (base.py:25-41, regex.py:60). */
+int bpe_merge(bpe_ctx *ctx, int32_t a, int32_t b, int32_t idx, uint64_t *new_len);
+int bpe_len(bpe_ctx *ctx, uint64_t *n);
+/* Current ids, start flags stripped. */
+int bpe_read_ids(bpe_ctx *ctx, int32_t *out, uint64_t cap);
+/* Current chunk start offsets (positions in the current id stream). */
+int bpe_read_chunk_starts(bpe_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n_out);
+
+/* ---- the training loop ----------------------------------------------------- */
+/* BasicTokenizer.train / RegexTokenizer.train loop (basic.py:31-45,
+ * regex.py:49-66) on the loaded bytes, entirely on device.
+ *   pairs_out[2*i], pairs_out[2*i+1] : pair merged at iteration i (idx 256+i)
+ *   counts_out[i]                    : stats[pair] (the verbose print, F10)
+ *   len_out[i]                       : total ids after merge i
+ *   iter_ms_out                      : optional (NULL ok) per-iteration device ms
+ *   n_done                           : merges completed
+ * Returns BPE_E_EMPTY_STATS when the pair table empties before num_merges
+ * (n_done tells where); the Python layer raises ValueError like the reference. */
+int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
+              uint64_t *counts_out, double *iter_ms_out, uint64_t *len_out,
+              int32_t *n_done);
+
+/* ---- measurement ------------------------------------------------------------ */
+#define BPE_PROF_WIDEN 0
+#define BPE_PROF_PAIR_COUNT 1
+#define BPE_PROF_ARGMAX 2   /* rowmax + argmax + tie-break + finalize */
+#define BPE_PROF_MERGE 3    /* merge pass(es) */
+#define BPE_PROF_TABLE 4    /* delta apply / table clear */
+#define BPE_PROF_ENCODE 5
+#define BPE_PROF_NKINDS 6
+/* Accumulated since the last bpe_prof_reset: device ms (hipEvents on the ctx's
+ * stream), launches, algorithmic bytes (4 B per id read or written,
+ * tables and flags not counted). */
+int bpe_prof_reset(bpe_ctx *ctx);
+int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_bytes);
+
+/* ---- host utilities (no GPU needed) ------------------------------------------ */
+/* Deterministic synthetic UTF-8 text (SURVEY 8d synth_text): explicit
+ * splitmix64, integer tables only.  Writes exactly n bytes, valid UTF-8. */
+int bpe_synth_text(uint8_t *out, uint64_t n, uint64_t seed);
+/* Library version / build info string. */
+const char *bpe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPE_HIP_H */

@@ -1,0 +1,230 @@
+"""ctypes binding of libbpe_hip.so (include/bpe_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  If the shared
+library has not been built, importing this module raises ImportError with the
+build command; if no GPU is present, Engine() raises RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbpe_hip.so")
+
+BPE_OK = 0
+BPE_E_HIP = -1
+BPE_E_ARG = -2
+BPE_E_EMPTY_STATS = -3
+BPE_E_STATE = -4
+BPE_E_CAP = -5
+BPE_E_LIMIT = -6
+BPE_E_INTERNAL = -7
+
+PROF_KINDS = ("widen", "pair_count", "argmax", "merge", "table", "encode")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -m minbpe_amd.build` "
+        "(hipcc --offload-arch=gfx950). minbpe_amd has no CPU fallback.")
+
+_lib = C.CDLL(LIB_PATH)
+_p = C.c_void_p
+_u64 = C.c_uint64
+_i32 = C.c_int32
+
+_SIGS = {
+    "bpe_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "bpe_destroy": (None, [_p]),
+    "bpe_last_error": (C.c_char_p, [_p]),
+    "bpe_set_stream": (C.c_int, [_p, _p]),
+    "bpe_set_option": (C.c_int, [_p, C.c_char_p, C.c_int64]),
+    "bpe_load_bytes": (C.c_int, [_p, _p, _u64, _p, _u64]),
+    "bpe_load_ids": (C.c_int, [_p, _p, _u64, _p, _u64]),
+    "bpe_get_stats": (C.c_int, [_p, C.POINTER(_u64)]),
+    "bpe_read_stats": (C.c_int, [_p, _p, _p, _p, _p, _u64, C.POINTER(_u64)]),
+    "bpe_argmax": (C.c_int, [_p, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
+    "bpe_merge": (C.c_int, [_p, _i32, _i32, _i32, C.POINTER(_u64)]),
+    "bpe_len": (C.c_int, [_p, C.POINTER(_u64)]),
+    "bpe_read_ids": (C.c_int, [_p, _p, _u64]),
+    "bpe_read_chunk_starts": (C.c_int, [_p, _p, _u64, C.POINTER(_u64)]),
+    "bpe_train": (C.c_int, [_p, _i32, _p, _p, _p, _p, C.POINTER(_i32)]),
+    "bpe_prof_reset": (C.c_int, [_p]),
+    "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
+    "bpe_synth_text": (C.c_int, [_p, _u64, _u64]),
+    "bpe_version": (C.c_char_p, []),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(_lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def exported_symbols():
+    """Names bound above (tests check them against include/bpe_hip.h)."""
+    return sorted(_SIGS)
+
+
+def version():
+    return _lib.bpe_version().decode()
+
+
+def synth_text(n: int, seed: int) -> bytes:
+    """Deterministic synthetic UTF-8 text (host only, no GPU needed)."""
+    buf = np.empty(n, dtype=np.uint8)
+    rc = _lib.bpe_synth_text(buf.ctypes.data_as(_p), n, seed)
+    if rc != BPE_OK:
+        raise RuntimeError(f"bpe_synth_text failed: {rc}")
+    return buf.tobytes()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_p)
+
+
+class Engine:
+    """One ctx = one GPU.  Thin, typed wrapper; all compute is in the library."""
+
+    def __init__(self, device: int = 0):
+        h = _p()
+        rc = _lib.bpe_create(device, C.byref(h))
+        if rc != BPE_OK:
+            raise RuntimeError(
+                "minbpe_amd needs an AMD GPU (gfx950): "
+                + (_lib.bpe_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.bpe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- errors ------------------------------------------------------------
+    def _check(self, rc):
+        if rc == BPE_OK:
+            return
+        msg = (_lib.bpe_last_error(self._h) or b"").decode()
+        if rc == BPE_E_EMPTY_STATS:
+            # the reference's failure mode: max() over an empty dict (basic.py:35)
+            raise ValueError("max() arg is an empty sequence")
+        if rc == BPE_E_ARG:
+            raise ValueError(msg)
+        raise RuntimeError(f"libbpe_hip error {rc}: {msg}")
+
+    # -- options -------------------------------------------------------------
+    def set_option(self, name: str, value: int):
+        self._check(_lib.bpe_set_option(self._h, name.encode(), int(value)))
+
+    def set_stream(self, stream_handle: int):
+        self._check(_lib.bpe_set_stream(self._h, _p(stream_handle)))
+
+    # -- input -----------------------------------------------------------------
+    @staticmethod
+    def _offsets(offsets):
+        if offsets is None:
+            return None, 0
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return off, len(off)
+
+    def load_bytes(self, data, offsets=None):
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        off, n_off = self._offsets(offsets)
+        self._keep = (buf, off)
+        self._check(_lib.bpe_load_bytes(self._h, _ptr(buf) if len(buf) else None, len(buf),
+                                        _ptr(off), n_off))
+
+    def load_ids(self, ids, offsets=None):
+        arr = np.ascontiguousarray(ids, dtype=np.int32)
+        off, n_off = self._offsets(offsets)
+        self._check(_lib.bpe_load_ids(self._h, _ptr(arr) if len(arr) else None, len(arr),
+                                      _ptr(off), n_off))
+
+    # -- single steps ---------------------------------------------------------------
+    def get_stats(self):
+        """[( (a,b), count, first_pos )] in the reference's dict order."""
+        n = _u64(0)
+        self._check(_lib.bpe_get_stats(self._h, C.byref(n)))
+        cap = max(int(n.value), 1)
+        a = np.empty(cap, np.int32)
+        b = np.empty(cap, np.int32)
+        cnt = np.empty(cap, np.uint64)
+        first = np.empty(cap, np.uint64)
+        got = _u64(0)
+        self._check(_lib.bpe_read_stats(self._h, _ptr(a), _ptr(b), _ptr(cnt), _ptr(first), cap,
+                                        C.byref(got)))
+        k = int(got.value)
+        order = np.argsort(first[:k], kind="stable")
+        return [((int(a[i]), int(b[i])), int(cnt[i]), int(first[i])) for i in order]
+
+    def argmax(self):
+        a, b, cnt = _i32(0), _i32(0), _u64(0)
+        self._check(_lib.bpe_argmax(self._h, C.byref(a), C.byref(b), C.byref(cnt)))
+        return (a.value, b.value), cnt.value
+
+    def merge(self, pair, idx):
+        n = _u64(0)
+        self._check(_lib.bpe_merge(self._h, int(pair[0]), int(pair[1]), int(idx), C.byref(n)))
+        return n.value
+
+    def __len__(self):
+        n = _u64(0)
+        self._check(_lib.bpe_len(self._h, C.byref(n)))
+        return n.value
+
+    def read_ids(self):
+        n = len(self)
+        out = np.empty(max(n, 1), np.int32)
+        self._check(_lib.bpe_read_ids(self._h, _ptr(out), len(out)))
+        return out[:n]
+
+    def read_chunk_starts(self):
+        n = len(self)
+        out = np.empty(max(n, 1), np.uint64)
+        got = _u64(0)
+        self._check(_lib.bpe_read_chunk_starts(self._h, _ptr(out), len(out), C.byref(got)))
+        return out[:got.value]
+
+    # -- training ---------------------------------------------------------------------
+    def train(self, num_merges: int, want_iter_ms: bool = False):
+        """Returns dict(pairs, counts, lens, iter_ms, n_done); raises ValueError
+        like the reference when the pair table runs empty (basic.py:35)."""
+        nm = max(num_merges, 1)
+        pairs = np.zeros(2 * nm, np.int32)
+        counts = np.zeros(nm, np.uint64)
+        lens = np.zeros(nm, np.uint64)
+        ms = np.zeros(nm, np.float64) if want_iter_ms else None
+        done = _i32(0)
+        rc = _lib.bpe_train(self._h, num_merges, _ptr(pairs), _ptr(counts), _ptr(ms), _ptr(lens),
+                            C.byref(done))
+        d = done.value
+        self.last_train = dict(
+            pairs=[(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(d)],
+            counts=[int(x) for x in counts[:d]], lens=[int(x) for x in lens[:d]],
+            iter_ms=None if ms is None else ms[:d].copy(), n_done=d)
+        self._check(rc)
+        return self.last_train
+
+    # -- measurement ----------------------------------------------------------------
+    def prof_reset(self):
+        self._check(_lib.bpe_prof_reset(self._h))
+
+    def prof_read(self):
+        k = len(PROF_KINDS)
+        ms = np.zeros(k, np.float64)
+        launches = np.zeros(k, np.uint64)
+        nbytes = np.zeros(k, np.uint64)
+        self._check(_lib.bpe_prof_read(self._h, _ptr(ms), _ptr(launches), _ptr(nbytes)))
+        return {name: dict(ms=float(ms[i]), launches=int(launches[i]), alg_bytes=int(nbytes[i]))
+                for i, name in enumerate(PROF_KINDS)}

@@ -1,0 +1,713 @@
+// bpe_api.hip -- host side of the C-ABI declared in include/bpe_hip.h.
+//
+// One ctx per GPU.  All work of a ctx is queued on one HIP stream; the id
+// stream, the pair table and all scratch live in HBM for the lifetime of the
+// ctx.  The training loop is host-sequenced (the
+// reference's outer loop is inherently sequential, basic.py:31) but every
+// iteration runs on the device with no id data crossing PCIe.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "bpe_hip.h"
+#include "bpe_kernels.hip"
+
+using namespace bpe;
+
+namespace {
+thread_local std::string g_create_err;
+
+struct ProfEv {
+    int kind;
+    hipEvent_t e0, e1;
+    uint64_t bytes;
+};
+}  // namespace
+
+struct bpe_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // resident input (bpe_load_bytes)
+    uint8_t *d_bytes = nullptr;
+    uint64_t nbytes = 0, cap_bytes = 0;
+    uint64_t *d_offsets = nullptr;
+    uint64_t n_chunks = 0, cap_offsets = 0;
+    bool have_bytes = false;
+
+    // id stream
+    uint32_t *d_ids[2] = {nullptr, nullptr};
+    uint64_t cap_ids = 0;
+    int par = 0;
+    uint64_t n = 0;
+    bool have_ids = false;
+
+    // pair table
+    uint32_t *d_mat = nullptr, *d_first = nullptr, *d_rowmax = nullptr;
+    uint32_t vcap = 0;  // matrix dimension == row stride
+    uint32_t vcur = 0;  // ids in use: [0, vcur)
+    bool stats_valid = false;
+
+    DevState *d_st = nullptr;
+    uint64_t *d_tsum = nullptr, *d_tile_off = nullptr;
+    uint8_t *d_tile_sin = nullptr;
+    uint64_t cap_tiles = 0;
+    IterRec *h_rec = nullptr;  // pinned, device-visible
+    int rec_cap = 0;
+    unsigned long long *d_scratch = nullptr;  // 2 x u64 cursor/counter
+
+    int mode = 0;     // 0 recount | 1 delta
+    int profile = 0;  // hipEvents around hot kernels
+    int k1 = 1;       // 0 simple | 1 LDS-cached pair count
+
+    std::vector<ProfEv> prof_open;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[BPE_PROF_NKINDS] = {0};
+    uint64_t prof_launches[BPE_PROF_NKINDS] = {0};
+    uint64_t prof_bytes[BPE_PROF_NKINDS] = {0};
+};
+
+namespace {
+
+int fail(bpe_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail((c), BPE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define LAUNCHCHK(c, name)                                                                \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), BPE_E_HIP, "launch %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != BPE_OK) return rc_; \
+    } while (0)
+
+template <typename T>
+int dev_realloc(bpe_ctx *c, T *&p, size_t count) {
+    if (p) HIPCHK(c, hipFree(p));
+    p = nullptr;
+    if (count) HIPCHK(c, hipMalloc((void **)&p, count * sizeof(T)));
+    return BPE_OK;
+}
+
+inline uint64_t ntiles_of(uint64_t n) { return (n + TILE - 1) / TILE; }
+
+int ensure_ids(bpe_ctx *c, uint64_t n) {
+    // capacity padded so every tile load (and the +1 halo word) is in bounds
+    const uint64_t need = (ntiles_of(n) + 2) * TILE;
+    if (need > c->cap_ids) {
+        TRY(dev_realloc(c, c->d_ids[0], need));
+        TRY(dev_realloc(c, c->d_ids[1], need));
+        c->cap_ids = need;
+    }
+    const uint64_t nt = ntiles_of(n) + 1;
+    if (nt > c->cap_tiles) {
+        TRY(dev_realloc(c, c->d_tsum, nt));
+        TRY(dev_realloc(c, c->d_tile_off, nt));
+        TRY(dev_realloc(c, c->d_tile_sin, nt));
+        c->cap_tiles = nt;
+    }
+    return BPE_OK;
+}
+
+int ensure_table(bpe_ctx *c, uint32_t v) {
+    if (v > 65535) return fail(c, BPE_E_LIMIT, "vocab %u exceeds this build's 65535 limit", v);
+    if (v <= c->vcap) return BPE_OK;
+    uint32_t nv = std::max<uint32_t>(v, 256);
+    nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
+    TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
+    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv));
+    if (c->d_first) {
+        HIPCHK(c, hipFree(c->d_first));
+        c->d_first = nullptr;
+    }
+    c->vcap = nv;
+    c->stats_valid = false;
+    return BPE_OK;
+}
+
+int ensure_rec(bpe_ctx *c, int n) {
+    if (n <= c->rec_cap) return BPE_OK;
+    if (c->h_rec) HIPCHK(c, hipHostFree(c->h_rec));
+    c->h_rec = nullptr;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_rec, sizeof(IterRec) * (size_t)n, hipHostMallocMapped));
+    c->rec_cap = n;
+    return BPE_OK;
+}
+
+// ---- profiling --------------------------------------------------------------
+int prof_begin(bpe_ctx *c, int kind, uint64_t bytes) {
+    if (!c->profile) return BPE_OK;
+    ProfEv ev;
+    ev.kind = kind;
+    ev.bytes = bytes;
+    for (hipEvent_t *e : {&ev.e0, &ev.e1}) {
+        if (!c->ev_pool.empty()) {
+            *e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        } else {
+            HIPCHK(c, hipEventCreate(e));
+        }
+    }
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    c->prof_open.push_back(ev);
+    return BPE_OK;
+}
+int prof_end(bpe_ctx *c) {
+    if (!c->profile) return BPE_OK;
+    HIPCHK(c, hipEventRecord(c->prof_open.back().e1, c->stream));
+    return BPE_OK;
+}
+int prof_drain(bpe_ctx *c) {
+    if (c->prof_open.empty()) return BPE_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (ProfEv &ev : c->prof_open) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        c->prof_ms[ev.kind] += ms;
+        c->prof_launches[ev.kind] += 1;
+        c->prof_bytes[ev.kind] += ev.bytes;
+        c->ev_pool.push_back(ev.e0);
+        c->ev_pool.push_back(ev.e1);
+    }
+    c->prof_open.clear();
+    return BPE_OK;
+}
+
+// ---- launch helpers -----------------------------------------------------------
+inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap) {
+    uint64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// widen resident bytes into ids[0], mark chunk starts, reset state
+int start_from_bytes(bpe_ctx *c) {
+    const uint64_t n = c->nbytes;
+    TRY(ensure_ids(c, n));
+    TRY(prof_begin(c, BPE_PROF_WIDEN, 5 * n));
+    if (n) {
+        hipLaunchKernelGGL(k_widen, dim3(grid_for(n, 256 * 16, c->num_cus * 8)), dim3(256), 0,
+                           c->stream, c->d_bytes, c->d_ids[0], n);
+        LAUNCHCHK(c, "k_widen");
+        if (c->n_chunks) {
+            hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[0], c->d_offsets, c->n_chunks, n);
+            LAUNCHCHK(c, "k_mark_starts");
+        }
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
+    LAUNCHCHK(c, "k_init_state");
+    TRY(prof_end(c));
+    c->par = 0;
+    c->n = n;
+    c->vcur = 256;
+    c->have_ids = true;
+    c->stats_valid = false;
+    return BPE_OK;
+}
+
+int clear_table(bpe_ctx *c) {
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcur * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// K1 on the current stream into the (cleared) table
+int launch_pair_count(bpe_ctx *c, bool with_first) {
+    const uint64_t n = c->n;
+    TRY(prof_begin(c, BPE_PROF_PAIR_COUNT, 4 * n));
+    if (n >= 2) {
+        if (with_first) {
+            hipLaunchKernelGGL(k_pair_count_simple<true>, dim3(grid_for(n, 1024, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
+                               c->vcap, c->d_first);
+        } else if (c->k1 == 0) {
+            hipLaunchKernelGGL(k_pair_count_simple<false>, dim3(grid_for(n, 1024, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
+                               c->vcap, (uint32_t *)nullptr);
+        } else {
+            hipLaunchKernelGGL(k_pair_count_lds, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus * 2)),
+                               dim3(PC_THREADS), 0, c->stream, c->d_ids[c->par], c->d_st, c->par,
+                               c->d_mat, c->vcap);
+        }
+        LAUNCHCHK(c, "k_pair_count");
+    }
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// K2 + tie-break + finalize: decides st->a, st->b
+int launch_select(bpe_ctx *c, bool rowmax_all, int iter, IterRec *rec) {
+    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    if (rowmax_all) {
+        hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           c->vcur, c->d_rowmax);
+        LAUNCHCHK(c, "k_rowmax_all");
+    }
+    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
+                       c->vcur, c->d_st);
+    LAUNCHCHK(c, "k_argmax");
+    // growing windows: ties among frequent pairs resolve in the first one
+    const uint64_t n = c->n;
+    const uint64_t edges[4] = {0, 1ull << 20, 1ull << 24, n};
+    for (int s = 0; s < 3; s++) {
+        const uint64_t lo = edges[s], hi = std::min(edges[s + 1], n);
+        if (lo >= hi) break;
+        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(hi - lo, 256, c->num_cus * 8)), dim3(256), 0,
+                           c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat, c->vcap, lo, hi);
+        LAUNCHCHK(c, "k_tiebreak");
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st, rec,
+                       iter);
+    LAUNCHCHK(c, "k_finalize");
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// K3: three passes (summary, tile scan, rewrite); flips the ping-pong parity.
+int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
+    const uint64_t n = c->n;
+    const uint64_t nt = ntiles_of(n);
+    TRY(prof_begin(c, BPE_PROF_MERGE, 4 * n));  // + 4*new_len once known
+    if (nt) {
+        hipLaunchKernelGGL(k_merge_count, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                           c->d_ids[c->par], c->d_st, c->par, c->d_tsum);
+        LAUNCHCHK(c, "k_merge_count");
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tsum, nt, c->d_tile_off,
+                       c->d_tile_sin, c->d_st, c->par, rec, iter);
+    LAUNCHCHK(c, "k_tile_scan");
+    if (nt) {
+        hipLaunchKernelGGL(k_merge_scatter, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                           c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_tile_off,
+                           c->d_tile_sin, newid);
+        LAUNCHCHK(c, "k_merge_scatter");
+    }
+    TRY(prof_end(c));
+    c->par ^= 1;
+    c->stats_valid = false;
+    return BPE_OK;
+}
+
+int read_state(bpe_ctx *c, DevState *out) {
+    HIPCHK(c, hipMemcpyAsync(out, c->d_st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BPE_OK;
+}
+
+}  // namespace
+
+// ============================================================================
+extern "C" {
+
+const char *bpe_version(void) { return "minbpe_amd libbpe_hip 0.1 (gfx950)"; }
+
+const char *bpe_last_error(bpe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int bpe_create(int device_id, bpe_ctx **out) {
+    if (!out) return fail(nullptr, BPE_E_ARG, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, BPE_E_HIP, "no HIP device available: %s",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= ndev)
+        return fail(nullptr, BPE_E_ARG, "device %d out of range (%d devices)", device_id, ndev);
+    bpe_ctx *c = new bpe_ctx();
+    c->device = device_id;
+    auto bail = [&](const char *what, hipError_t er) {
+        int rc = fail(nullptr, BPE_E_HIP, "%s failed: %s", what, hipGetErrorString(er));
+        delete c;
+        return rc;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return bail("hipGetDeviceProperties", e);
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    c->own_stream = true;
+    if ((e = hipMalloc((void **)&c->d_st, sizeof(DevState))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&c->d_scratch, 4 * sizeof(unsigned long long))) != hipSuccess)
+        return bail("hipMalloc", e);
+    *out = c;
+    return BPE_OK;
+}
+
+void bpe_destroy(bpe_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (ProfEv &ev : c->prof_open) {
+        (void)hipEventDestroy(ev.e0);
+        (void)hipEventDestroy(ev.e1);
+    }
+    for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
+    void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
+                    c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bpe_set_stream(bpe_ctx *c, void *hip_stream) {
+    if (!c) return BPE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) HIPCHK(c, hipStreamDestroy(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return BPE_OK;
+}
+
+int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return BPE_E_ARG;
+    if (!strcmp(name, "mode")) {
+        if (value != 0 && value != 1) return fail(c, BPE_E_ARG, "mode must be 0 or 1");
+        c->mode = (int)value;
+    } else if (!strcmp(name, "profile")) {
+        c->profile = value != 0;
+    } else if (!strcmp(name, "k1")) {
+        c->k1 = (int)value;
+    } else {
+        return fail(c, BPE_E_ARG, "unknown option '%s'", name);
+    }
+    return BPE_OK;
+}
+
+int bpe_load_bytes(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                   uint64_t n_chunks) {
+    if (!c || (!bytes && n)) return fail(c, BPE_E_ARG, "bytes is NULL");
+    if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream of %llu bytes exceeds 2^32-1 per GPU",
+                                       (unsigned long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n + 16 > c->cap_bytes) {
+        TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
+        c->cap_bytes = n + 16;
+    }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, hipMemcpyHostToDevice, c->stream));
+    static const uint64_t zero = 0;
+    if (!chunk_offsets) {
+        chunk_offsets = &zero;
+        n_chunks = 1;
+    }
+    if (n_chunks > c->cap_offsets) {
+        TRY(dev_realloc(c, c->d_offsets, (size_t)n_chunks));
+        c->cap_offsets = n_chunks;
+    }
+    if (n_chunks)
+        HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free its buffers on return
+    c->nbytes = n;
+    c->n_chunks = n_chunks;
+    c->have_bytes = true;
+    TRY(ensure_table(c, 256));
+    TRY(start_from_bytes(c));
+    return BPE_OK;
+}
+
+int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chunk_offsets,
+                 uint64_t n_chunks) {
+    if (!c || (!ids && n)) return fail(c, BPE_E_ARG, "ids is NULL");
+    if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream too long");
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t mx = 255;
+    for (uint64_t i = 0; i < n; i++) {
+        if (ids[i] < 0) return fail(c, BPE_E_ARG, "negative token id at %llu", (unsigned long long)i);
+        mx = std::max(mx, ids[i]);
+    }
+    TRY(ensure_table(c, (uint32_t)mx + 1));
+    TRY(ensure_ids(c, n));
+    // stage through buffer 1, then mask into buffer 0
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_ids[1], ids, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_load_ids, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                           (const int32_t *)c->d_ids[1], c->d_ids[0], n);
+        LAUNCHCHK(c, "k_load_ids");
+    }
+    static const uint64_t zero = 0;
+    if (!chunk_offsets) {
+        chunk_offsets = &zero;
+        n_chunks = 1;
+    }
+    if (n_chunks > c->cap_offsets) {
+        TRY(dev_realloc(c, c->d_offsets, (size_t)n_chunks));
+        c->cap_offsets = n_chunks;
+    }
+    if (n && n_chunks) {
+        HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(n_chunks, 256, c->num_cus * 8)), dim3(256), 0,
+                           c->stream, c->d_ids[0], c->d_offsets, n_chunks, n);
+        LAUNCHCHK(c, "k_mark_starts");
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
+    LAUNCHCHK(c, "k_init_state");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_bytes = false;
+    c->par = 0;
+    c->n = n;
+    c->vcur = (uint32_t)mx + 1;
+    c->have_ids = true;
+    c->stats_valid = false;
+    return BPE_OK;
+}
+
+int bpe_get_stats(bpe_ctx *c, uint64_t *n_pairs_out) {
+    if (!c) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_first) TRY(dev_realloc(c, c->d_first, (size_t)c->vcap * c->vcap));
+    TRY(clear_table(c));
+    HIPCHK(c, hipMemsetAsync(c->d_first, 0xFF, (size_t)c->vcur * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(launch_pair_count(c, true));
+    HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_count_nonzero, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                       c->vcur, c->d_scratch);
+    LAUNCHCHK(c, "k_count_nonzero");
+    unsigned long long np = 0;
+    HIPCHK(c, hipMemcpyAsync(&np, c->d_scratch, sizeof np, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stats_valid = true;
+    if (n_pairs_out) *n_pairs_out = np;
+    return BPE_OK;
+}
+
+int bpe_read_stats(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *cnt, uint64_t *first_pos,
+                   uint64_t cap, uint64_t *n_out) {
+    if (!c) return BPE_E_ARG;
+    if (!c->stats_valid) return fail(c, BPE_E_STATE, "bpe_get_stats has not been run on the current ids");
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t *da = nullptr, *db = nullptr;
+    unsigned long long *dc = nullptr, *df = nullptr;
+    const size_t capn = cap ? cap : 1;
+    HIPCHK(c, hipMalloc((void **)&da, capn * 4));
+    HIPCHK(c, hipMalloc((void **)&db, capn * 4));
+    HIPCHK(c, hipMalloc((void **)&dc, capn * 8));
+    HIPCHK(c, hipMalloc((void **)&df, capn * 8));
+    HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_dump_stats, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->d_first,
+                       c->vcap, c->vcur, da, db, dc, df, (unsigned long long)cap, c->d_scratch);
+    LAUNCHCHK(c, "k_dump_stats");
+    unsigned long long np = 0;
+    HIPCHK(c, hipMemcpyAsync(&np, c->d_scratch, sizeof np, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = BPE_OK;
+    if (np > cap) {
+        rc = fail(c, BPE_E_CAP, "%llu pairs but cap is %llu", np, (unsigned long long)cap);
+    } else if (np) {
+        HIPCHK(c, hipMemcpy(a, da, np * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(b, db, np * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(cnt, dc, np * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(first_pos, df, np * 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dc);
+    (void)hipFree(df);
+    if (n_out) *n_out = np;
+    return rc;
+}
+
+int bpe_argmax(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *count) {
+    if (!c) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->d_st, 0, 0);  // clears status
+    TRY(clear_table(c));
+    TRY(launch_pair_count(c, false));
+    c->stats_valid = false;
+    TRY(launch_select(c, true, 0, nullptr));
+    DevState st;
+    TRY(read_state(c, &st));
+    if (st.status == ST_EMPTY) return fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence");
+    if (st.status != ST_OK) return fail(c, BPE_E_INTERNAL, "device status %u", st.status);
+    if (a) *a = st.a;
+    if (b) *b = st.b;
+    if (count) *count = st.count;
+    return BPE_OK;
+}
+
+int bpe_merge(bpe_ctx *c, int32_t a, int32_t b, int32_t idx, uint64_t *new_len) {
+    if (!c) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    if (a < 0 || b < 0 || idx < 0) return fail(c, BPE_E_ARG, "negative id");
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_table(c, (uint32_t)std::max(idx, std::max(a, b)) + 1));
+    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->d_st, a, b);
+    LAUNCHCHK(c, "k_set_pair");
+    TRY(launch_merge(c, (uint32_t)idx, 0, nullptr));
+    DevState st;
+    TRY(read_state(c, &st));
+    c->n = st.n[c->par];
+    c->vcur = std::max<uint32_t>(c->vcur, (uint32_t)idx + 1);
+    if (new_len) *new_len = c->n;
+    return BPE_OK;
+}
+
+int bpe_len(bpe_ctx *c, uint64_t *n) {
+    if (!c || !n) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    *n = c->n;
+    return BPE_OK;
+}
+
+int bpe_read_ids(bpe_ctx *c, int32_t *out, uint64_t cap) {
+    if (!c) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    if (cap < c->n) return fail(c, BPE_E_CAP, "need %llu entries", (unsigned long long)c->n);
+    if (!c->n) return BPE_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // strip flags into the idle ping-pong buffer, then copy out
+    int32_t *tmp = (int32_t *)c->d_ids[c->par ^ 1];
+    hipLaunchKernelGGL(k_strip_flags, dim3(grid_for(c->n, 256, c->num_cus * 8)), dim3(256), 0,
+                       c->stream, c->d_ids[c->par], tmp, c->n);
+    LAUNCHCHK(c, "k_strip_flags");
+    HIPCHK(c, hipMemcpyAsync(out, tmp, c->n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BPE_OK;
+}
+
+int bpe_read_chunk_starts(bpe_ctx *c, uint64_t *out, uint64_t cap, uint64_t *n_out) {
+    if (!c) return BPE_E_ARG;
+    if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    unsigned long long *d_out = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_out, (cap ? cap : 1) * 8));
+    HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long), c->stream));
+    if (c->n) {
+        hipLaunchKernelGGL(k_collect_starts, dim3(grid_for(c->n, 256, c->num_cus * 8)), dim3(256), 0,
+                           c->stream, c->d_ids[c->par], c->n, d_out, (unsigned long long)cap,
+                           c->d_scratch);
+        LAUNCHCHK(c, "k_collect_starts");
+    }
+    unsigned long long ns = 0;
+    HIPCHK(c, hipMemcpyAsync(&ns, c->d_scratch, sizeof ns, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = BPE_OK;
+    if (ns > cap) {
+        rc = fail(c, BPE_E_CAP, "%llu chunk starts but cap is %llu", ns, (unsigned long long)cap);
+    } else if (ns) {
+        HIPCHK(c, hipMemcpy(out, d_out, ns * 8, hipMemcpyDeviceToHost));
+        std::sort(out, out + ns);
+    }
+    (void)hipFree(d_out);
+    if (n_out) *n_out = ns;
+    return rc;
+}
+
+int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
+              double *iter_ms_out, uint64_t *len_out, int32_t *n_done) {
+    if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
+    if (n_done) *n_done = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_table(c, 256u + (uint32_t)num_merges));
+    TRY(ensure_rec(c, std::max(num_merges, 1)));
+    TRY(start_from_bytes(c));
+    std::vector<hipEvent_t> evs;
+    if (iter_ms_out) {
+        evs.resize((size_t)num_merges + 1);
+        for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
+        HIPCHK(c, hipEventRecord(evs[0], c->stream));
+    }
+    int done = 0, rc = BPE_OK;
+    for (int i = 0; i < num_merges; i++) {
+        c->vcur = 256u + (uint32_t)i;
+        TRY(clear_table(c));
+        TRY(launch_pair_count(c, false));
+        TRY(launch_select(c, true, i, c->h_rec));
+        TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec));
+        if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const IterRec &r = c->h_rec[i];
+        if (r.status == ST_EMPTY) {
+            rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", i);
+            c->par ^= 1;  // the merge kernels did nothing
+            break;
+        }
+        if (r.status != ST_OK) {
+            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d", r.status, i);
+            break;
+        }
+        if (pairs_out) {
+            pairs_out[2 * i] = r.a;
+            pairs_out[2 * i + 1] = r.b;
+        }
+        if (counts_out) counts_out[i] = r.count;
+        if (len_out) len_out[i] = r.new_len;
+        c->n = r.new_len;
+        if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * r.new_len;
+        done++;
+    }
+    c->vcur = 256u + (uint32_t)done;
+    if (iter_ms_out) {
+        for (int i = 0; i < done; i++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, evs[(size_t)i], evs[(size_t)i + 1]));
+            iter_ms_out[i] = ms;
+        }
+        for (auto &e : evs) (void)hipEventDestroy(e);
+    }
+    TRY(prof_drain(c));
+    if (n_done) *n_done = done;
+    return rc;
+}
+
+int bpe_prof_reset(bpe_ctx *c) {
+    if (!c) return BPE_E_ARG;
+    TRY(prof_drain(c));
+    for (int k = 0; k < BPE_PROF_NKINDS; k++) {
+        c->prof_ms[k] = 0;
+        c->prof_launches[k] = 0;
+        c->prof_bytes[k] = 0;
+    }
+    return BPE_OK;
+}
+
+int bpe_prof_read(bpe_ctx *c, double *ms, uint64_t *launches, uint64_t *alg_bytes) {
+    if (!c) return BPE_E_ARG;
+    TRY(prof_drain(c));
+    for (int k = 0; k < BPE_PROF_NKINDS; k++) {
+        if (ms) ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_launches[k];
+        if (alg_bytes) alg_bytes[k] = c->prof_bytes[k];
+    }
+    return BPE_OK;
+}
+
+}  // extern "C"

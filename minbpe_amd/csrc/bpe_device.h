@@ -1,0 +1,51 @@
+// bpe_device.h -- constants and device-visible structs shared by the kernels
+// (bpe_kernels.hip) and the host side of the C-ABI (bpe_api.hip).
+#pragma once
+#include <stdint.h>
+
+namespace bpe {
+
+// id-stream word format
+constexpr uint32_t FLAG = 0x80000000u;          // bit 31: token starts a chunk
+constexpr uint32_t IDMASK = 0x7FFFFFFFu;        // bits 0..30: token id
+constexpr uint32_t INVALID_WORD = 0xFFFFFFFFu;  // positions >= n inside a tile
+constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;     // LDS cache: free slot
+constexpr unsigned long long NOPOS = ~0ull;
+
+// merge tile geometry: 4 waves x MJ stripes x 64 lanes x 4 ids
+constexpr int MT = 256;
+constexpr int MJ = 4;
+constexpr int WAVE_SPAN = MJ * 256;
+constexpr int TILE = (MT / 64) * WAVE_SPAN;  // 4096 ids = 16 KiB
+
+// pair-count kernel: LDS cache of 2^PC_BITS {key,count} slots per workgroup
+constexpr int PC_BITS = 13;
+constexpr int PC_THREADS = 512;
+
+constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
+constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_argmax
+
+constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2;
+
+// one per ctx, in device memory
+struct DevState {
+    unsigned long long n[2];      // length of the id stream in ping-pong buffer 0/1
+    unsigned long long firstpos;  // tie-break: earliest position holding a tied pair
+    int32_t a, b;                 // pair being merged
+    uint32_t count;               // its count
+    uint32_t ntied;               // pairs tied at the max (TIE_CAP+1: too many to list)
+    uint32_t found;               // (a,b) decided
+    uint32_t status;              // ST_*
+    int32_t tied[2 * TIE_CAP];
+};
+
+// one per training iteration, written by the device into pinned host memory
+struct IterRec {
+    int32_t a, b;
+    uint32_t count;
+    uint32_t status;
+    unsigned long long new_len;
+    unsigned long long seq;  // iteration + 1 once every field above is final
+};
+
+}  // namespace bpe

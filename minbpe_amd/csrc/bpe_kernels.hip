@@ -1,0 +1,690 @@
+// bpe_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the BPE hot path.
+//
+// Written for 64-wide wavefronts, 256 CUs in 8 XCDs, 160 KiB LDS per CU and an
+// HBM3E-bound workload: every kernel here is integer / byte work whose roofline
+// is HBM bandwidth, so the rules that matter are coalesced 16 B-per-lane
+// accesses, LDS pre-aggregation of atomics, and keeping the id stream resident.
+// No MFMA anywhere.
+//
+// Data layout
+//   id stream : uint32 words, ping-pong buffers.  bits 0..30 = token id,
+//               bit 31 = "this token starts a chunk" (regex.py:44: pairs never
+//               span chunks).  A pair (p, p+1) exists iff word[p+1] has bit 31
+//               clear, so "next word == b" is a complete validity test.
+//   pair table: dense row-major uint32 matrix count[a][b], stride = vcap.
+//               288 GB of HBM makes the dense form affordable (vocab 32000 ->
+//               4.1 GB) and turns per-iteration table maintenance into four
+//               dense vectors (delta mode) -- see k_apply_delta.
+//   row maxima: rowmax[a] = max_b count[a][b]; argmax scans V values, not V^2.
+//
+// Reference semantics restated here:
+//   F1 get_stats counts every adjacent pair        -> k_pair_count_*
+//   F2 merge is greedy left-to-right               -> mbit() / run-parity scan
+//   F3 argmax ties go to the earliest first occurrence -> k_argmax + k_tiebreak
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bpe_device.h"
+
+namespace bpe {
+
+// ---------------------------------------------------------------------------
+// small wave / block helpers (wave = 64 lanes, hard-coded: gfx950 only)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// K0: list(text_bytes)  (basic.py:25-26, regex.py:44)
+// 16 B read -> 64 B written per lane; HBM-bound, 5 B of traffic per id.
+
+__global__ void __launch_bounds__(256)
+k_widen(const uint8_t *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint4 o;
+                o.x = w[k] & 0xffu;
+                o.y = (w[k] >> 8) & 0xffu;
+                o.z = (w[k] >> 16) & 0xffu;
+                o.w = w[k] >> 24;
+                *reinterpret_cast<uint4 *>(dst + i + 4 * k) = o;
+            }
+        } else {
+            for (uint64_t j = i; j < n; j++) dst[j] = src[j];
+        }
+    }
+}
+
+// int32 ids from the host (module-level get_stats/merge drop-ins): strip sign.
+__global__ void k_mark_starts(uint32_t *ids, const uint64_t *__restrict__ off, uint64_t n_chunks,
+                              uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
+        const uint64_t o = off[c];
+        if (o < n) atomicOr(&ids[o], FLAG);  // duplicate offsets (empty chunks) are idempotent
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: get_stats  (base.py:13-22; shared dict over chunks regex.py:51-54)
+//
+// k_pair_count_simple: one global atomic per position. Used when the first
+// position of every pair is wanted too (bpe_get_stats: dict insertion order).
+template <bool FIRST>
+__global__ void __launch_bounds__(256)
+k_pair_count_simple(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+                    uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ first) {
+    const uint64_t n = st->n[par];
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g * 4 < n; g += total) {
+        const uint64_t p = g * 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(ids + p);  // buffers are tile-padded
+        uint32_t x[5] = {v.x, v.y, v.z, v.w, ids[p + 4]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (p + k + 1 < n && !(x[k + 1] & FLAG)) {
+                const size_t idx = (size_t)(x[k] & IDMASK) * stride + x[k + 1];
+                atomicAdd(&mat[idx], 1u);
+                if (FIRST) atomicMin(&first[idx], (uint32_t)(p + k));
+            }
+        }
+    }
+}
+
+// k_pair_count_lds: the production histogram.  Each workgroup owns a contiguous
+// span of the stream and a direct-mapped LDS cache {key = table index, count}.
+// A position costs one ds_read + one ds_add on a hit; a cold key whose slot is
+// taken goes straight to an L2 atomic.  The cache is flushed once per workgroup
+// (one global atomic per resident key), which turns the Zipf-hot pairs -- the
+// ones that would serialise at a single L2 channel -- into ~#workgroups atomics.
+__device__ __forceinline__ void cache_add(uint32_t *keys, uint32_t *vals, uint32_t *__restrict__ g,
+                                          uint32_t idx, uint32_t v) {
+    const uint32_t h = (idx * 0x9E3779B1u) >> (32 - PC_BITS);
+    uint32_t k = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+    if (k == EMPTY_KEY) {
+        const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, idx);
+        k = (old == EMPTY_KEY) ? idx : old;
+    }
+    if (k == idx) {
+        atomicAdd(&vals[h], v);
+    } else {
+        atomicAdd(&g[idx], v);
+    }
+}
+
+__global__ void __launch_bounds__(PC_THREADS)
+k_pair_count_lds(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+                 uint32_t *__restrict__ mat, uint32_t stride) {
+    __shared__ uint32_t s_keys[1 << PC_BITS];
+    __shared__ uint32_t s_vals[1 << PC_BITS];
+    for (int i = threadIdx.x; i < (1 << PC_BITS); i += PC_THREADS) {
+        s_keys[i] = EMPTY_KEY;
+        s_vals[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t n = st->n[par];
+    // contiguous span per workgroup, rounded to whole 4-id groups per thread
+    const uint64_t groups = (n + 3) / 4;
+    const uint64_t per_wg = (groups + gridDim.x - 1) / gridDim.x;
+    const uint64_t g0 = per_wg * blockIdx.x;
+    const uint64_t g1 = min(g0 + per_wg, groups);
+    for (uint64_t g = g0 + threadIdx.x; g < g1; g += PC_THREADS) {
+        const uint64_t p = g * 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(ids + p);
+        const uint32_t x[5] = {v.x, v.y, v.z, v.w, ids[p + 4]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (p + k + 1 < n && !(x[k + 1] & FLAG))
+                cache_add(s_keys, s_vals, mat, (x[k] & IDMASK) * stride + x[k + 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (1 << PC_BITS); i += PC_THREADS) {
+        const uint32_t c = s_vals[i];
+        if (c) atomicAdd(&mat[s_keys[i]], c);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: pair = max(stats, key=stats.get)  (basic.py:35, regex.py:56)
+
+// one workgroup per row: rowmax[x] = max_y count[x][y]
+__global__ void __launch_bounds__(256)
+k_rowmax_all(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur,
+             uint32_t *__restrict__ rowmax) {
+    __shared__ uint32_t s_red[4];
+    const uint32_t x = blockIdx.x;
+    const uint32_t *row = mat + (size_t)x * stride;
+    uint32_t m = 0;
+    const uint32_t v4 = vcur & ~3u;
+    for (uint32_t y = threadIdx.x * 4; y < v4; y += 256 * 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + y);
+        m = max(max(m, q.x), max(max(q.y, q.z), q.w));
+    }
+    for (uint32_t y = v4 + threadIdx.x; y < vcur; y += 256) m = max(m, row[y]);
+    m = wave_max_u32(m);
+    if (lane_id() == 0) s_red[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+}
+
+// Single workgroup: global max over rowmax, then gather every pair that attains
+// it (the candidates of the reference's first-occurrence tie-break, F3).
+__global__ void __launch_bounds__(1024)
+k_argmax(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
+         uint32_t vcur, DevState *st) {
+    __shared__ uint32_t s_red[16];
+    __shared__ uint32_t s_M, s_nrows, s_nt;
+    __shared__ uint32_t s_rows[ARGMAX_ROWS];
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    if (st->status) return;
+    uint32_t m = 0;
+    for (uint32_t x = threadIdx.x; x < vcur; x += 1024) m = max(m, rowmax[x]);
+    m = wave_max_u32(m);
+    if (lane_id() == 0) s_red[wave_id()] = m;
+    if (threadIdx.x == 0) {
+        s_nrows = 0;
+        s_nt = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t M = 0;
+        for (int i = 0; i < 16; i++) M = max(M, s_red[i]);
+        s_M = M;
+    }
+    __syncthreads();
+    const uint32_t M = s_M;
+    if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
+        if (threadIdx.x == 0) {
+            st->status = ST_EMPTY;
+            st->count = 0;
+            st->found = 0;
+        }
+        return;
+    }
+    for (uint32_t x = threadIdx.x; x < vcur; x += 1024) {
+        if (rowmax[x] == M) {
+            const uint32_t s = atomicAdd(&s_nrows, 1u);
+            if (s < ARGMAX_ROWS) s_rows[s] = x;
+        }
+    }
+    __syncthreads();
+    const uint32_t nrows = s_nrows;
+    if (nrows <= ARGMAX_ROWS) {
+        for (uint32_t r = 0; r < nrows; r++) {
+            const uint32_t x = s_rows[r];
+            const uint32_t *row = mat + (size_t)x * stride;
+            for (uint32_t y = threadIdx.x; y < vcur; y += 1024) {
+                if (row[y] == M) {
+                    const uint32_t s = atomicAdd(&s_nt, 1u);
+                    if (s < TIE_CAP) {
+                        s_tied[2 * s] = (int32_t)x;
+                        s_tied[2 * s + 1] = (int32_t)y;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nt = (nrows > ARGMAX_ROWS) ? (TIE_CAP + 1) : min(s_nt, (uint32_t)TIE_CAP + 1);
+    if (threadIdx.x < 2 * min(nt, (uint32_t)TIE_CAP)) st->tied[threadIdx.x] = s_tied[threadIdx.x];
+    if (threadIdx.x == 0) {
+        st->count = M;
+        st->ntied = nt;
+        st->found = (nt == 1);
+        st->a = s_tied[0];
+        st->b = s_tied[1];
+        st->firstpos = NOPOS;
+    }
+}
+
+// Tie-break (F3): the winner among the pairs tied at the maximum is the one
+// whose first occurrence is earliest, i.e. the pair found at the FIRST position
+// of the stream that holds any tied pair.  Searched over growing windows; every
+// launch is a no-op unless a tie exists and earlier windows found nothing.
+__global__ void __launch_bounds__(256)
+k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
+           const uint32_t *__restrict__ mat, uint32_t stride, uint64_t lo, uint64_t hi) {
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ uint32_t s_go;
+    if (threadIdx.x == 0)
+        s_go = (st->status == 0 && st->found == 0 &&
+                __atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) == NOPOS);
+    __syncthreads();
+    if (!s_go) return;
+    const uint32_t nt = st->ntied;
+    const uint32_t M = st->count;
+    if (nt <= TIE_CAP && threadIdx.x < 2 * nt) s_tied[threadIdx.x] = st->tied[threadIdx.x];
+    __syncthreads();
+    const uint64_t n = st->n[par];
+    if (hi > n) hi = n;
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p + 1 < n && p < hi;
+         p += total) {
+        const uint32_t w1 = ids[p + 1];
+        if (w1 & FLAG) continue;
+        const uint32_t a = ids[p] & IDMASK;
+        bool hit = false;
+        if (nt <= TIE_CAP) {
+            for (uint32_t t = 0; t < nt; t++)
+                hit |= (s_tied[2 * t] == (int32_t)a) & (s_tied[2 * t + 1] == (int32_t)w1);
+        } else {
+            hit = mat[(size_t)a * stride + w1] == M;
+        }
+        if (hit) {
+            atomicMin(&st->firstpos, (unsigned long long)p);
+            break;  // later positions of this thread cannot be earlier
+        }
+    }
+}
+
+__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st, IterRec *rec, int iter) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->status == 0 && !st->found) {
+        const unsigned long long p = st->firstpos;
+        if (p == NOPOS) {
+            st->status = ST_INTERNAL;  // a tie was reported but no tied pair is in the stream
+        } else {
+            st->a = (int32_t)(ids[p] & IDMASK);
+            st->b = (int32_t)ids[p + 1];
+            st->found = 1;
+        }
+    }
+    if (rec) {
+        rec[iter].a = st->a;
+        rec[iter].b = st->b;
+        rec[iter].count = st->count;
+        rec[iter].status = st->status;
+    }
+}
+
+// host-chosen pair for the single-step bpe_merge()
+__global__ void k_set_pair(DevState *st, int32_t a, int32_t b) {
+    st->a = a;
+    st->b = b;
+    st->found = 1;
+    st->status = 0;
+    st->count = 0;
+}
+
+// ---------------------------------------------------------------------------
+// K3: merge  (base.py:25-41, applied to every chunk regex.py:60)
+//
+// Greedy left-to-right replacement.  r[p] = 1 iff (word[p], word[p+1]) is the
+// pair; a site starts at p iff m[p] = r[p] & !m[p-1].  With L_p = length of the
+// run of ones of r ending at p, m[p] = r[p] & (L_p odd) -- for a != b runs of r
+// have length 1 and m = r; for a == b this is exactly the reference's pairing
+// inside a run "aaaa..." (F2).  L_p comes from a max-scan of "index of the last
+// zero of r", so one code path serves both cases.  A run that reaches the tile
+// start takes the carry s = m[tile_start-1] of the previous tile.
+//
+// Tile = 4 waves; each wave owns MJ stripes of 256 consecutive ids, lane l holds
+// ids [4l, 4l+4) of each stripe: every global load is a full 1 KiB wave access.
+
+struct Tile {
+    uint32_t x[MJ][4];  // words
+    uint32_t rb[MJ];    // r bits of my 4 elements per stripe
+    int E[MJ];          // tile-relative index of the last zero of r before my group (-1: none)
+};
+
+__device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
+                                          uint64_t tile_base, uint32_t a, uint32_t b, int *s_wave) {
+    const int lane = lane_id(), wave = wave_id();
+    const uint64_t wbase = tile_base + (uint64_t)wave * WAVE_SPAN;
+    uint32_t nx[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const uint64_t p0 = wbase + j * 256 + lane * 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(ids + p0);
+        t.x[j][0] = (p0 + 0 < n) ? v.x : INVALID_WORD;
+        t.x[j][1] = (p0 + 1 < n) ? v.y : INVALID_WORD;
+        t.x[j][2] = (p0 + 2 < n) ? v.z : INVALID_WORD;
+        t.x[j][3] = (p0 + 3 < n) ? v.w : INVALID_WORD;
+    }
+    const uint64_t tailp = wbase + WAVE_SPAN;
+    const uint32_t tail = (tailp < n) ? ids[tailp] : INVALID_WORD;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const uint32_t nb = (uint32_t)__shfl((int)t.x[j][0], (lane + 1) & 63);
+        const uint32_t up = (j < MJ - 1) ? (uint32_t)__shfl((int)t.x[(j + 1) % MJ][0], 0) : tail;
+        nx[j] = (lane == 63) ? up : nb;
+    }
+    // r bits and the index of the last zero in each group
+    int lzg[MJ];
+    const int gb0 = wave * WAVE_SPAN + lane * 4;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        uint32_t rb = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t nxt = (k < 3) ? t.x[j][k + 1] : nx[j];
+            rb |= (uint32_t)(((t.x[j][k] & IDMASK) == a) & (nxt == b)) << k;
+        }
+        t.rb[j] = rb;
+        const uint32_t z = (~rb) & 0xFu;
+        lzg[j] = z ? (gb0 + j * 256 + (31 - __clz((int)z))) : -1;
+    }
+    // exclusive max-scan of lzg in (wave, stripe, lane) order
+    int carry = -1;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        int v = lzg[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v = max(v, o);
+        }
+        int ex = __shfl_up(v, 1);
+        if (lane == 0) ex = -1;
+        t.E[j] = max(carry, ex);
+        carry = max(carry, __shfl(v, 63));
+    }
+    if (lane == 0) s_wave[wave] = carry;
+    __syncthreads();
+    int win = -1;
+    for (int w = 0; w < wave; w++) win = max(win, s_wave[w]);
+#pragma unroll
+    for (int j = 0; j < MJ; j++) t.E[j] = max(t.E[j], win);
+}
+
+// m bit of tile-relative position q given lz = index of the last zero at or
+// before q's predecessor... see callers.  s = carry into the tile.
+__device__ __forceinline__ uint32_t parity_bit(int q, int lz, uint32_t s) {
+    return (uint32_t)((q - lz) & 1) ^ ((lz < 0) ? s : 0u);
+}
+
+// m bits (4) of my group in stripe j, and mprev = m of the element before it.
+__device__ __forceinline__ uint32_t group_mbits(const Tile &t, int j, uint32_t s, uint32_t &mprev) {
+    const int q0 = wave_id() * WAVE_SPAN + j * 256 + lane_id() * 4;
+    int lz = t.E[j];
+    // predecessor q0-1: r = 1 unless it is the last zero itself
+    mprev = (q0 == 0) ? s : ((lz == q0 - 1) ? 0u : parity_bit(q0 - 1, lz, s));
+    uint32_t mb = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((t.rb[j] >> k) & 1u) {
+            mb |= parity_bit(q0 + k, lz, s) << k;
+        } else {
+            lz = q0 + k;
+        }
+    }
+    return mb;
+}
+
+// pass 1: per-tile summary, as a function of the unknown carry s:
+//   M0      sites in the tile for s = 0
+//   Podd    length of the all-ones prefix of r is odd   (M1 = M0 - Podd)
+//   allones r is 1 on the whole tile                    (o1 = !o0, else o1 = o0)
+//   o0      m[last] for s = 0 (carry into the next tile)
+__global__ void __launch_bounds__(MT)
+k_merge_count(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+              uint64_t *__restrict__ tsum) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ uint32_t s_cnt[MT / 64];
+    __shared__ int s_fz[MT / 64];
+    __shared__ uint32_t s_o0;
+    if (st->status) return;
+    const uint64_t n = st->n[par];
+    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
+    if (tile_base >= n) return;
+    const int len = (int)min((uint64_t)TILE, n - tile_base);
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    if (threadIdx.x == 0) s_o0 = 0;
+    Tile t;
+    tile_load(t, ids, n, tile_base, a, b, s_wave);  // contains a __syncthreads
+    uint32_t cnt = 0;
+    int fz = 0x7fffffff;
+    const int gb0 = wave_id() * WAVE_SPAN + lane_id() * 4;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        uint32_t mprev;
+        const uint32_t mb = group_mbits(t, j, 0u, mprev);
+        cnt += __popc(mb);
+        const uint32_t z = (~t.rb[j]) & 0xFu;
+        if (z) fz = min(fz, gb0 + j * 256 + (__ffs((int)z) - 1));
+        const int q0 = gb0 + j * 256;
+        if (len - 1 >= q0 && len - 1 < q0 + 4) s_o0 = (mb >> (len - 1 - q0)) & 1u;
+    }
+    cnt = wave_sum_u32(cnt);
+    fz = wave_min_i32(fz);
+    if (lane_id() == 0) {
+        s_cnt[wave_id()] = cnt;
+        s_fz[wave_id()] = fz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t M0 = 0;
+        int F = 0x7fffffff;
+        for (int w = 0; w < MT / 64; w++) {
+            M0 += s_cnt[w];
+            F = min(F, s_fz[w]);
+        }
+        const int P = min(F, len);
+        const uint64_t podd = (uint64_t)(P & 1);
+        const uint64_t allones = (uint64_t)(F >= len);
+        tsum[blockIdx.x] = (uint64_t)M0 | (podd << 32) | (allones << 33) | ((uint64_t)s_o0 << 34);
+    }
+}
+
+// pass 2: one workgroup walks the tile summaries: carry s and output offset per tile.
+__global__ void __launch_bounds__(1024)
+k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__restrict__ tile_off,
+            uint8_t *__restrict__ tile_sin, DevState *st, int par, IterRec *rec, int iter) {
+    __shared__ unsigned long long s_kept[1024][2];
+    __shared__ uint8_t s_out[1024][2];
+    __shared__ unsigned long long s_off[1024];
+    __shared__ uint8_t s_sin[1024];
+    if (st->status) {
+        if (threadIdx.x == 0 && rec) rec[iter].new_len = st->n[par];
+        return;
+    }
+    const uint64_t n = st->n[par];
+    const uint64_t R = (ntiles + 1023) / 1024;
+    const uint64_t t0 = min((uint64_t)threadIdx.x * R, ntiles), t1 = min(t0 + R, ntiles);
+    unsigned long long kept[2] = {0, 0};
+    uint32_t sc[2] = {0, 1};
+    for (uint64_t t = t0; t < t1; t++) {
+        const uint64_t tb = t * TILE;
+        if (tb >= n) break;
+        const uint64_t w = tsum[t];
+        const uint32_t M0 = (uint32_t)w, podd = (w >> 32) & 1, allones = (w >> 33) & 1,
+                       o0 = (w >> 34) & 1;
+        const uint32_t len = (uint32_t)min((uint64_t)TILE, n - tb);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t s = sc[q];
+            const uint32_t Ms = M0 - (s & podd);
+            const uint32_t os = allones ? (o0 ^ s) : o0;
+            kept[q] += len - s - (Ms - os);
+            sc[q] = os;
+        }
+    }
+    s_kept[threadIdx.x][0] = kept[0];
+    s_kept[threadIdx.x][1] = kept[1];
+    s_out[threadIdx.x][0] = (uint8_t)sc[0];
+    s_out[threadIdx.x][1] = (uint8_t)sc[1];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        unsigned long long off = 0;
+        for (int i = 0; i < 1024; i++) {
+            s_sin[i] = (uint8_t)s;
+            s_off[i] = off;
+            off += s_kept[i][s];
+            s = s_out[i][s];
+        }
+        st->n[par ^ 1] = off;
+        if (rec) rec[iter].new_len = off;
+    }
+    __syncthreads();
+    uint32_t s = s_sin[threadIdx.x];
+    unsigned long long off = s_off[threadIdx.x];
+    for (uint64_t t = t0; t < t1; t++) {
+        const uint64_t tb = t * TILE;
+        if (tb >= n) break;
+        const uint64_t w = tsum[t];
+        const uint32_t M0 = (uint32_t)w, podd = (w >> 32) & 1, allones = (w >> 33) & 1,
+                       o0 = (w >> 34) & 1;
+        const uint32_t len = (uint32_t)min((uint64_t)TILE, n - tb);
+        tile_off[t] = off;
+        tile_sin[t] = (uint8_t)s;
+        const uint32_t Ms = M0 - (s & podd);
+        const uint32_t os = allones ? (o0 ^ s) : o0;
+        off += len - s - (Ms - os);
+        s = os;
+    }
+}
+
+// pass 3: rewrite.  kept[p] = !m[p-1]; a site start emits the new id (and keeps
+// the chunk-start flag of its first element).
+__global__ void __launch_bounds__(MT)
+k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                const DevState *__restrict__ st, int par, const uint64_t *__restrict__ tile_off,
+                const uint8_t *__restrict__ tile_sin, uint32_t newid) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ uint32_t s_wsum[MT / 64];
+    if (st->status) return;
+    const uint64_t n = st->n[par];
+    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
+    if (tile_base >= n) return;
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    const uint32_t s = tile_sin[blockIdx.x];
+    Tile t;
+    tile_load(t, in, n, tile_base, a, b, s_wave);
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t mb[MJ], kb[MJ], ex[MJ];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        uint32_t mprev;
+        mb[j] = group_mbits(t, j, s, mprev);
+        // kept bit k = !m[k-1], only for valid positions
+        uint32_t valid = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) valid |= (uint32_t)(t.x[j][k] != INVALID_WORD) << k;
+        kb[j] = (~((mb[j] << 1) | mprev)) & valid & 0xFu;
+        uint32_t v = __popc(kb[j]);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+            if (lane >= d) v += o;
+        }
+        ex[j] = carry + v - __popc(kb[j]);
+        carry += (uint32_t)__shfl((int)v, 63);
+    }
+    if (lane == 0) s_wsum[wave] = carry;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += s_wsum[w];
+    uint32_t *dst = out + tile_off[blockIdx.x] + wbase;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        uint32_t o = ex[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((kb[j] >> k) & 1u) {
+                const uint32_t w = t.x[j][k];
+                dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// table utilities for the single-step API
+
+__global__ void __launch_bounds__(256)
+k_count_nonzero(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur,
+                unsigned long long *out) {
+    const uint32_t x = blockIdx.x;
+    uint32_t c = 0;
+    for (uint32_t y = threadIdx.x; y < vcur; y += 256) c += mat[(size_t)x * stride + y] != 0;
+    c = wave_sum_u32(c);
+    if (lane_id() == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
+__global__ void __launch_bounds__(256)
+k_dump_stats(const uint32_t *__restrict__ mat, const uint32_t *__restrict__ first, uint32_t stride,
+             uint32_t vcur, int32_t *oa, int32_t *ob, unsigned long long *oc,
+             unsigned long long *of, unsigned long long cap, unsigned long long *cursor) {
+    const uint32_t x = blockIdx.x;
+    for (uint32_t y = threadIdx.x; y < vcur; y += 256) {
+        const uint32_t c = mat[(size_t)x * stride + y];
+        if (c) {
+            const unsigned long long s = atomicAdd(cursor, 1ull);
+            if (s < cap) {
+                oa[s] = (int32_t)x;
+                ob[s] = (int32_t)y;
+                oc[s] = c;
+                of[s] = first ? first[(size_t)x * stride + y] : 0;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_strip_flags(const uint32_t *__restrict__ in, int32_t *__restrict__ out, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (int32_t)(in[i] & IDMASK);
+}
+
+__global__ void __launch_bounds__(256)
+k_collect_starts(const uint32_t *__restrict__ in, uint64_t n, unsigned long long *out,
+                 unsigned long long cap, unsigned long long *cursor) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (in[i] & FLAG) {
+            const unsigned long long s = atomicAdd(cursor, 1ull);
+            if (s < cap) out[s] = i;
+        }
+    }
+}
+
+__global__ void k_load_ids(const int32_t *__restrict__ in, uint32_t *__restrict__ out, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = (uint32_t)in[i] & IDMASK;
+}
+
+__global__ void k_init_state(DevState *st, unsigned long long n) {
+    st->n[0] = n;
+    st->n[1] = 0;
+    st->firstpos = NOPOS;
+    st->a = st->b = 0;
+    st->count = 0;
+    st->ntied = 0;
+    st->found = 0;
+    st->status = 0;
+}
+
+}  // namespace bpe

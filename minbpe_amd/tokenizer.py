@@ -1,0 +1,369 @@
+"""Drop-in tokenizer classes backed by the MI355X engine (libbpe_hip.so).
+
+Same public surface as karpathy/minbpe (minbpe/__init__.py:1-4): `Tokenizer`,
+`BasicTokenizer`, `RegexTokenizer`, `GPT4Tokenizer`, plus the module-level
+`get_stats` / `merge` helpers of minbpe/base.py:13-41.  Signatures, results,
+exception types and the `.model` / `.vocab` file formats are the reference's;
+the implementation is not: all pair counting, arg-max selection, merging and
+encoding runs on the GPU through the C-ABI in include/bpe_hip.h.  Host Python
+only does what the reference leaves to the `regex` module and to O(vocab)
+bookkeeping ("out of scope as kernels").
+"""
+import os
+import unicodedata
+
+import numpy as np
+import regex as re
+
+from . import _native
+
+# the GPT split patterns are data (regex.py:18-19), reproduced verbatim because
+# chunking must be byte-identical to the reference's
+GPT2_SPLIT_PATTERN = r"""'(?:[sdmt]|ll|ve|re)| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
+GPT4_SPLIT_PATTERN = r"""'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"""
+
+_engines = {}
+
+
+def engine(device=None) -> "_native.Engine":
+    """Process-wide engine (one ctx) per GPU, created on first use."""
+    if device is None:
+        device = int(os.environ.get("MINBPE_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _engines:
+        _engines[device] = _native.Engine(device)
+    return _engines[device]
+
+
+# ---------------------------------------------------------------------------
+# module-level helpers (minbpe/base.py:13-41), device-backed
+
+def get_stats(ids, counts=None):
+    """Adjacent-pair counts of `ids` as a dict in first-occurrence order;
+    accumulates into `counts` when given (base.py:13-22)."""
+    counts = {} if counts is None else counts
+    if len(ids) < 2:
+        return counts
+    eng = engine()
+    eng.load_ids(ids)
+    for pair, c, _first in eng.get_stats():
+        counts[pair] = counts.get(pair, 0) + c
+    return counts
+
+
+def merge(ids, pair, idx):
+    """Replace every left-to-right non-overlapping occurrence of `pair` in `ids`
+    by `idx` (base.py:25-41)."""
+    if len(ids) == 0:
+        return []
+    eng = engine()
+    eng.load_ids(ids)
+    eng.merge(pair, idx)
+    return eng.read_ids().tolist()
+
+
+# ---------------------------------------------------------------------------
+# rendering helpers for the human-readable .vocab file (base.py:44-61)
+
+def replace_control_characters(s: str) -> str:
+    return "".join(ch if unicodedata.category(ch)[0] != "C" else f"\\u{ord(ch):04x}" for ch in s)
+
+
+def render_token(t: bytes) -> str:
+    return replace_control_characters(t.decode("utf-8", errors="replace"))
+
+
+def _concat_chunks(chunks):
+    """list[bytes] -> (data, start offsets) with empty chunks dropped."""
+    chunks = [c for c in chunks if c]
+    lens = np.fromiter((len(c) for c in chunks), dtype=np.uint64, count=len(chunks))
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    if len(chunks) > 1:
+        np.cumsum(lens[:-1], out=offs[1:])
+    return b"".join(chunks), offs
+
+
+class Tokenizer:
+    """Base class: state, vocab construction, save/load (base.py:66-165)."""
+
+    def __init__(self):
+        self.merges = {}          # (int, int) -> int, insertion-ordered by idx
+        self.pattern = ""
+        self.special_tokens = {}  # str -> int
+        self.vocab = self._build_vocab()
+
+    def train(self, text, vocab_size, verbose=False):
+        raise NotImplementedError
+
+    def encode(self, text):
+        raise NotImplementedError
+
+    def decode(self, ids):
+        raise NotImplementedError
+
+    def _build_vocab(self):
+        vocab = {i: bytes([i]) for i in range(256)}
+        for (left, right), idx in self.merges.items():
+            vocab[idx] = vocab[left] + vocab[right]
+        for tok, idx in self.special_tokens.items():
+            vocab[idx] = tok.encode("utf-8")
+        return vocab
+
+    # -- device training shared by Basic/Regex ------------------------------------
+    def _train_on_device(self, data: bytes, offsets, vocab_size: int, verbose: bool):
+        assert vocab_size >= 256
+        num_merges = vocab_size - 256
+        eng = engine()
+        eng.load_bytes(data, offsets)
+        failure = None
+        try:
+            res = eng.train(num_merges)
+        except ValueError as e:  # stats ran empty: same exception as max() in the reference
+            res, failure = eng.last_train, e
+        merges, vocab = {}, {i: bytes([i]) for i in range(256)}
+        for i, pair in enumerate(res["pairs"]):
+            idx = 256 + i
+            merges[pair] = idx
+            vocab[idx] = vocab[pair[0]] + vocab[pair[1]]
+            if verbose:
+                print(f"merge {i+1}/{num_merges}: {pair} -> {idx} ({vocab[idx]}) had "
+                      f"{res['counts'][i]} occurrences")
+        if failure is not None:
+            raise failure  # like the reference, merges/vocab are NOT updated
+        self.merges = merges
+        self.vocab = vocab
+
+    # -- device encoding of a batch of byte chunks ----------------------------------
+    def _encode_chunks(self, chunks):
+        """chunks: list[bytes] -> (ids ndarray, token start offset of each
+        non-empty chunk).  Applies the merges in ascending idx order, which is
+        what the reference's lowest-rank-first loop computes."""
+        data, offs = _concat_chunks(chunks)
+        if not data:
+            return np.empty(0, np.int32), np.empty(0, np.uint64)
+        eng = engine()
+        eng.load_bytes(data, offs)
+        for pair, idx in sorted(self.merges.items(), key=lambda kv: kv[1]):
+            eng.merge(pair, idx)
+        return eng.read_ids(), eng.read_chunk_starts()
+
+    # -- persistence (file formats of base.py:97-165, byte for byte) -----------------
+    def save(self, file_prefix):
+        lines = ["minbpe v1", f"{self.pattern}", f"{len(self.special_tokens)}"]
+        lines += [f"{tok} {idx}" for tok, idx in self.special_tokens.items()]
+        lines += [f"{a} {b}" for a, b in self.merges]
+        with open(file_prefix + ".model", "w") as f:
+            f.write("\n".join(lines) + "\n")
+        parents = {idx: pair for pair, idx in self.merges.items()}
+        with open(file_prefix + ".vocab", "w", encoding="utf-8") as f:
+            for idx, tok in self.vocab.items():
+                shown = render_token(tok)
+                if idx in parents:
+                    a, b = parents[idx]
+                    f.write(f"[{render_token(self.vocab[a])}][{render_token(self.vocab[b])}]"
+                            f" -> [{shown}] {idx}\n")
+                else:
+                    f.write(f"[{shown}] {idx}\n")
+
+    def load(self, model_file):
+        assert model_file.endswith(".model")
+        with open(model_file, "r", encoding="utf-8") as f:
+            assert f.readline().strip() == "minbpe v1"
+            self.pattern = f.readline().strip()
+            specials = {}
+            for _ in range(int(f.readline().strip())):
+                tok, idx = f.readline().strip().split()
+                specials[tok] = int(idx)
+            merges = {}
+            for idx, line in enumerate(f, start=256):
+                a, b = map(int, line.split())
+                merges[(a, b)] = idx
+        self.merges = merges
+        self.special_tokens = specials
+        self.vocab = self._build_vocab()
+
+
+class BasicTokenizer(Tokenizer):
+    """Byte-level BPE over the whole text as one chunk (basic.py:15-74)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def train(self, text, vocab_size, verbose=False):
+        self._train_on_device(text.encode("utf-8"), None, vocab_size, verbose)
+
+    def decode(self, ids):
+        return b"".join(self.vocab[i] for i in ids).decode("utf-8", errors="replace")
+
+    def encode(self, text):
+        ids, _ = self._encode_chunks([text.encode("utf-8")])
+        return ids.tolist()
+
+
+class RegexTokenizer(Tokenizer):
+    """BPE over regex-split chunks with optional special tokens (regex.py:22-164)."""
+
+    def __init__(self, pattern=None):
+        super().__init__()
+        self.pattern = GPT4_SPLIT_PATTERN if pattern is None else pattern
+        self.compiled_pattern = re.compile(self.pattern)
+        self.special_tokens = {}
+        self.inverse_special_tokens = {}
+
+    def _split(self, text):
+        return [piece.encode("utf-8") for piece in re.findall(self.compiled_pattern, text)]
+
+    def train(self, text, vocab_size, verbose=False):
+        data, offs = _concat_chunks(self._split(text))
+        self._train_on_device(data, offs, vocab_size, verbose)
+
+    def register_special_tokens(self, special_tokens):
+        self.special_tokens = special_tokens
+        self.inverse_special_tokens = {idx: tok for tok, idx in special_tokens.items()}
+
+    def decode(self, ids):
+        parts = []
+        for idx in ids:
+            if idx in self.vocab:
+                parts.append(self.vocab[idx])
+            elif idx in self.inverse_special_tokens:
+                parts.append(self.inverse_special_tokens[idx].encode("utf-8"))
+            else:
+                raise ValueError(f"invalid token id: {idx}")
+        return b"".join(parts).decode("utf-8", errors="replace")
+
+    def _prepare_chunk(self, chunk_bytes):
+        return chunk_bytes  # GPT4Tokenizer permutes bytes here
+
+    def _encode_chunk(self, text_bytes):
+        ids, _ = self._encode_chunks([self._prepare_chunk(text_bytes)])
+        return ids.tolist()
+
+    def encode_ordinary(self, text):
+        ids, _ = self._encode_chunks([self._prepare_chunk(c) for c in self._split(text)])
+        return ids.tolist()
+
+    def encode(self, text, allowed_special="none_raise"):
+        if allowed_special == "all":
+            special = self.special_tokens
+        elif allowed_special == "none":
+            special = {}
+        elif allowed_special == "none_raise":
+            special = {}
+            assert all(tok not in text for tok in self.special_tokens)
+        elif isinstance(allowed_special, set):
+            special = {k: v for k, v in self.special_tokens.items() if k in allowed_special}
+        else:
+            raise ValueError(f"allowed_special={allowed_special} not understood")
+        if not special:
+            return self.encode_ordinary(text)
+        splitter = "(" + "|".join(re.escape(k) for k in special) + ")"
+        parts = re.split(splitter, text)
+        # one device batch for all ordinary parts; specials spliced back in order
+        chunks, owner = [], []
+        for pi, part in enumerate(parts):
+            if part in special:
+                continue
+            for c in self._split(part):
+                c = self._prepare_chunk(c)
+                if c:
+                    chunks.append(c)
+                    owner.append(pi)
+        ids, starts = self._encode_chunks(chunks)
+        bounds = np.append(starts, len(ids)).astype(np.int64)
+        out, ci = [], 0
+        for pi, part in enumerate(parts):
+            if part in special:
+                out.append(special[part])
+                continue
+            first = ci
+            while ci < len(owner) and owner[ci] == pi:
+                ci += 1
+            if ci > first:
+                out.extend(ids[bounds[first]:bounds[ci]].tolist())
+        return out
+
+
+class GPT4Tokenizer(RegexTokenizer):
+    """cl100k_base through the same engine (gpt4.py:57-130).  Needs `tiktoken`
+    for the published ranks; without it construction raises ImportError."""
+
+    SPECIAL_TOKENS = {
+        '<|endoftext|>': 100257, '<|fim_prefix|>': 100258, '<|fim_middle|>': 100259,
+        '<|fim_suffix|>': 100260, '<|endofprompt|>': 100276,
+    }
+
+    def __init__(self):
+        super().__init__(pattern=GPT4_SPLIT_PATTERN)
+        try:
+            import tiktoken
+        except ImportError as e:
+            raise ImportError("GPT4Tokenizer needs the `tiktoken` package for cl100k_base ranks") from e
+        ranks = tiktoken.get_encoding("cl100k_base")._mergeable_ranks
+        self.merges = _recover_merges(ranks)
+        vocab = {i: bytes([i]) for i in range(256)}
+        for (a, b), idx in self.merges.items():
+            vocab[idx] = vocab[a] + vocab[b]
+        self.vocab = vocab
+        self.byte_shuffle = {i: ranks[bytes([i])] for i in range(256)}
+        self.inverse_byte_shuffle = {v: k for k, v in self.byte_shuffle.items()}
+        self._shuffle_lut = bytes(self.byte_shuffle[i] for i in range(256))
+        self._unshuffle_lut = bytes(self.inverse_byte_shuffle[i] for i in range(256))
+        self.register_special_tokens(self.SPECIAL_TOKENS)
+
+    def _prepare_chunk(self, chunk_bytes):
+        return chunk_bytes.translate(self._shuffle_lut)
+
+    def decode(self, ids):
+        raw = b"".join(self.vocab[i] for i in ids).translate(self._unshuffle_lut)
+        return raw.decode("utf-8", errors="replace")
+
+    def train(self, text, vocab_size, verbose=False):
+        raise NotImplementedError
+
+    def save(self, file_prefix):
+        raise NotImplementedError("GPT4Tokenizer cannot be saved.")
+
+    def load(self, model_file):
+        raise NotImplementedError("GPT4Tokenizer cannot be loaded.")
+
+    def save_vocab(self, vocab_file):
+        vocab = {i: bytes([self.inverse_byte_shuffle[i]]) for i in range(256)}
+        for (a, b), idx in self.merges.items():
+            vocab[idx] = vocab[a] + vocab[b]
+        parents = {idx: pair for pair, idx in self.merges.items()}
+        with open(vocab_file, "w", encoding="utf-8") as f:
+            for idx, tok in vocab.items():
+                if idx in parents:
+                    a, b = parents[idx]
+                    f.write(f"[{render_token(vocab[a])}][{render_token(vocab[b])}]"
+                            f" -> [{render_token(tok)}] {idx}\n")
+                else:
+                    f.write(f"[{render_token(tok)}] {idx}\n")
+
+
+def _split_by_ranks(ranks, token, max_rank):
+    """Re-run BPE on one token's bytes using only ranks below max_rank
+    (gpt4.py:11-26): the two parts left are the pair that was merged."""
+    parts = [bytes([b]) for b in token]
+    while True:
+        best = None
+        for i in range(len(parts) - 1):
+            r = ranks.get(parts[i] + parts[i + 1])
+            if r is not None and (best is None or r < best[0]):
+                best = (r, i)
+        if best is None or (max_rank is not None and best[0] >= max_rank):
+            return parts
+        i = best[1]
+        parts[i:i + 2] = [parts[i] + parts[i + 1]]
+
+
+def _recover_merges(ranks):
+    """mergeable_ranks (bytes -> rank) -> {(id, id): rank}  (gpt4.py:29-46)."""
+    merges = {}
+    for token, rank in ranks.items():
+        if len(token) == 1:
+            continue
+        pair = _split_by_ranks(ranks, token, rank)
+        assert len(pair) == 2
+        merges[(ranks[pair[0]], ranks[pair[1]])] = rank
+    return merges

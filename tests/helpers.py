@@ -1,0 +1,31 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+import regex as re
+
+from minbpe_amd.tokenizer import GPT4_SPLIT_PATTERN
+
+_PAT = re.compile(GPT4_SPLIT_PATTERN)
+
+
+def case_text(case, native):
+    if "text" in case:
+        return case["text"]
+    n, seed = case["synth"]
+    return native.synth_text(n, seed).decode("utf-8")
+
+
+def split_chunks(text, pattern=_PAT):
+    """(data, start offsets) the way RegexTokenizer.train chunks its input."""
+    chunks = [c.encode("utf-8") for c in re.findall(pattern, text)]
+    chunks = [c for c in chunks if c]
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    if len(chunks) > 1:
+        np.cumsum(np.fromiter((len(c) for c in chunks[:-1]), dtype=np.uint64), out=offs[1:])
+    return b"".join(chunks), offs
+
+
+def data_for(case, native):
+    text = case_text(case, native)
+    if case["kind"] == "basic":
+        return text.encode("utf-8"), None
+    return split_chunks(text)

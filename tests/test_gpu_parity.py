@@ -1,0 +1,220 @@
+"""GPU: the HIP path (through the C-ABI) against the CPU oracle and the golden
+vectors generated from the reference.  Integer work: every comparison is exact."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import case_text, data_for, split_chunks
+
+pytestmark = pytest.mark.gpu
+
+
+def starts_to_offsets(starts, n):
+    return None if starts is None else np.asarray(starts, dtype=np.uint64)
+
+
+# ---------------------------------------------------------------------------
+# single-step primitives
+
+def test_primitives_golden(golden, engine):
+    for prim in golden["primitives"]:
+        ids = prim["ids"]
+        engine.load_ids(ids)
+        st = engine.get_stats()
+        assert [[a, b, c] for (a, b), c, _ in st] == prim["stats"]
+        if prim["stats"]:
+            pair, cnt = engine.argmax()
+            assert list(pair) == prim["argmax"]
+            assert cnt == max(c for _, _, c in prim["stats"])
+            engine.merge(prim["argmax"], 1000)
+            assert engine.read_ids().tolist() == prim["merged"]
+            engine.load_ids(ids)
+            engine.merge(prim["merged_same"]["pair"], 1001)
+            assert engine.read_ids().tolist() == prim["merged_same"]["out"]
+        else:
+            with pytest.raises(ValueError):
+                engine.argmax()
+
+
+@pytest.mark.parametrize("k,n", [(2, 5000), (3, 70000), (40, 200000), (256, 1 << 20), (2, 4096),
+                                 (2, 4097), (2, 8191), (1, 10000), (5, 1), (5, 2), (5, 0)])
+def test_get_stats_argmax_merge_vs_oracle(engine, k, n):
+    rng = np.random.default_rng(n * 31 + k)
+    ids = rng.integers(0, k, size=n, dtype=np.int32)
+    # ragged chunks: boundaries at random places, including adjacent ones
+    nb = min(n, max(1, n // 7))
+    offs = np.unique(np.concatenate([[0], rng.integers(0, max(n, 1), size=nb)])).astype(np.uint64) if n else None
+    for offsets in (None, offs):
+        if offsets is None and n == 0:
+            continue
+        engine.load_ids(ids, offsets)
+        ref = oracle.get_stats(ids, offsets)
+        got = engine.get_stats()
+        assert got == ref
+        if not ref:
+            with pytest.raises(ValueError):
+                engine.argmax()
+            continue
+        best = max(ref, key=lambda e: e[1])  # first max in insertion order
+        pair, cnt = engine.argmax()
+        assert (pair, cnt) == (best[0], best[1])
+        for mp in (pair, (int(ids[0]), int(ids[0]))):
+            engine.load_ids(ids, offsets)
+            engine.merge(mp, 300)
+            off_full = oracle.oracle._offsets(n, offsets).copy()
+            buf = ids.copy()
+            lib = oracle.oracle._load()
+            nl = lib.orc_merge_chunks(buf.ctypes.data, off_full.ctypes.data, len(off_full) - 1,
+                                      int(mp[0]), int(mp[1]), 300)
+            assert len(engine) == nl
+            assert np.array_equal(engine.read_ids(), buf[:nl])
+            # chunk starts follow the tokens (drop empty chunks / duplicates)
+            exp_starts = np.unique(off_full[:-1][off_full[:-1] < nl]) if nl else np.empty(0)
+            if offsets is not None:
+                exp = sorted(set(int(off_full[c]) for c in range(len(off_full) - 1)
+                                 if off_full[c + 1] > off_full[c]))
+                assert engine.read_chunk_starts().tolist() == exp
+
+
+def test_long_runs_cross_tile_boundaries(engine):
+    # a == b merges with runs spanning many 4096-id tiles, odd/even lengths
+    for n in (4095, 4096, 4097, 12289, 100001):
+        ids = np.full(n, 7, np.int32)
+        engine.load_ids(ids)
+        engine.merge((7, 7), 300)
+        exp = oracle.merge(ids, (7, 7), 300)
+        assert np.array_equal(engine.read_ids(), exp)
+    rng = np.random.default_rng(5)
+    ids = np.where(rng.random(300000) < 0.97, 7, 8).astype(np.int32)
+    engine.load_ids(ids)
+    engine.merge((7, 7), 300)
+    assert np.array_equal(engine.read_ids(), oracle.merge(ids, (7, 7), 300))
+
+
+# ---------------------------------------------------------------------------
+# the training loop
+
+def test_train_golden_cases(golden, engine, native):
+    for case in golden["train"]:
+        data, offs = data_for(case, native)
+        nm = case["vocab_size"] - 256
+        engine.load_bytes(data, offs)
+        if case["raises_value_error"]:
+            with pytest.raises(ValueError, match="empty sequence"):
+                engine.train(nm)
+            continue
+        res = engine.train(nm)
+        assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
+
+
+@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300)])
+def test_train_tie_heavy_vs_oracle(engine, mode, k, n, nm):
+    rng = random.Random(k * 1000 + n)
+    data = bytes(97 + rng.randrange(k) for _ in range(n))
+    engine.set_option("mode", mode)
+    engine.load_bytes(data)
+    try:
+        exp = oracle.train(data, nm)
+    except oracle.OracleEmptyStats:
+        with pytest.raises(ValueError):
+            engine.train(nm)
+        return
+    res = engine.train(nm)
+    assert res["pairs"] == exp[0]
+    assert res["counts"] == exp[1]
+    assert res["lens"] == exp[2]
+
+
+@pytest.mark.parametrize("kind", ["basic", "regex"])
+def test_train_synth_2mb_vs_oracle(engine, native, kind):
+    text = native.synth_text(2_000_000, 11)
+    if kind == "basic":
+        data, offs = text, None
+    else:
+        data, offs = split_chunks(text.decode())
+    nm = 400
+    exp = oracle.train(data, nm, offs)
+    engine.load_bytes(data, offs)
+    res = engine.train(nm)
+    assert res["pairs"] == exp[0]
+    assert res["counts"] == exp[1]
+    assert res["lens"] == exp[2]
+    # re-running from the resident bytes gives the same answer (bench does this)
+    assert engine.train(nm)["pairs"] == exp[0]
+
+
+# ---------------------------------------------------------------------------
+# the drop-in classes
+
+def test_classes_golden(golden, native):
+    from minbpe_amd import BasicTokenizer, RegexTokenizer
+    for case in golden["train"]:
+        cls = BasicTokenizer if case["kind"] == "basic" else RegexTokenizer
+        tok = cls()
+        text = case_text(case, native)
+        if case["raises_value_error"]:
+            with pytest.raises(ValueError):
+                tok.train(text, case["vocab_size"])
+            assert tok.merges == {}
+            continue
+        tok.train(text, case["vocab_size"])
+        assert [list(p) for p in tok.merges] == case["merges"]
+        assert list(tok.merges.values()) == list(range(256, 256 + len(case["merges"])))
+        for enc in case["encode"]:
+            ids = tok.encode(enc["text"])
+            assert ids == enc["ids"], case["name"]
+            assert tok.decode(ids) == enc["text"]
+
+
+def test_wikipedia_example():
+    # the reference's own known-answer test (tests/test_tokenizer.py:80-107)
+    from minbpe_amd import BasicTokenizer, RegexTokenizer
+    for cls in (BasicTokenizer, RegexTokenizer):
+        tok = cls()
+        tok.train("aaabdaaabac", 256 + 3)
+        assert tok.encode("aaabdaaabac") == [258, 100, 258, 97, 99]
+        assert tok.decode(tok.encode("aaabdaaabac")) == "aaabdaaabac"
+
+
+def test_specials_and_save_load(golden, tmp_path):
+    # mirrors tests/test_tokenizer.py:109-132 with our own text
+    from minbpe_amd import RegexTokenizer
+    sp = golden["specials"]
+    tok = RegexTokenizer()
+    tok.train(sp["train_text"], sp["vocab_size"])
+    tok.register_special_tokens(sp["special_tokens"])
+    assert tok.encode(sp["text"], allowed_special="all") == sp["ids_all"]
+    assert tok.encode(sp["text"], allowed_special="none") == sp["ids_none"]
+    assert tok.encode(sp["text"], allowed_special={"<|endoftext|>"}) == sp["ids_set"]
+    assert tok.decode(sp["ids_all"]) == sp["text"]
+    with pytest.raises(AssertionError):
+        tok.encode(sp["text"])
+    prefix = str(tmp_path / "t")
+    tok.save(prefix)
+    t2 = RegexTokenizer()
+    t2.load(prefix + ".model")
+    assert t2.encode(sp["text"], "all") == sp["ids_all"]
+    assert t2.decode(sp["ids_all"]) == sp["text"]
+
+
+def test_verbose_print_matches_reference_format(capsys):
+    from minbpe_amd import BasicTokenizer
+    tok = BasicTokenizer()
+    tok.train("aaabdaaabac", 259, verbose=True)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "merge 1/3: (97, 97) -> 256 (b'aa') had 4 occurrences"
+    assert out[2] == "merge 3/3: (257, 98) -> 258 (b'aaab') had 2 occurrences"
+
+
+def test_module_level_helpers():
+    from minbpe_amd import get_stats, merge
+    assert get_stats([1, 2, 3, 1, 2]) == {(1, 2): 2, (2, 3): 1, (3, 1): 1}
+    assert list(get_stats([5, 6, 7, 8, 5, 6, 7, 8])) == [(5, 6), (6, 7), (7, 8), (8, 5)]
+    assert get_stats([1, 2], {(1, 2): 5}) == {(1, 2): 6}
+    assert merge([1, 2, 3, 1, 2], (1, 2), 4) == [4, 3, 4]
+    assert merge([7, 7, 7, 7, 7], (7, 7), 9) == [9, 9, 7]
+    assert merge([], (1, 2), 4) == [] and get_stats([]) == {} and get_stats([3]) == {}

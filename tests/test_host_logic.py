@@ -1,0 +1,88 @@
+"""CPU: host-side logic of the drop-in classes that needs no GPU: the .model /
+.vocab formats (base.py:97-165), decode (basic.py:51-55, regex.py:78-90),
+vocab construction, chunk concatenation."""
+import os
+
+import numpy as np
+import pytest
+
+from minbpe_amd import BasicTokenizer, RegexTokenizer, Tokenizer
+from minbpe_amd.tokenizer import _concat_chunks, render_token, GPT4_SPLIT_PATTERN
+
+
+def test_model_file_format_matches_reference(golden, tmp_path):
+    tok = RegexTokenizer()
+    tok.merges = {(97, 98): 256, (32, 256): 257}
+    tok.vocab = tok._build_vocab()
+    tok.register_special_tokens({"<|endoftext|>": 1000})
+    prefix = str(tmp_path / "tok")
+    tok.save(prefix)
+    assert open(prefix + ".model", encoding="utf-8").read() == golden["model_file"]["text"]
+    assert open(prefix + ".vocab", encoding="utf-8").read() == golden["model_file"]["vocab"]
+    t2 = RegexTokenizer()
+    t2.load(prefix + ".model")
+    assert t2.merges == tok.merges and list(t2.merges) == list(tok.merges)
+    assert t2.special_tokens == {"<|endoftext|>": 1000}
+    assert t2.pattern == GPT4_SPLIT_PATTERN
+    assert t2.vocab[257] == b" ab" and t2.vocab[1000] == b"<|endoftext|>"
+    # like the reference, load() does not rebuild inverse_special_tokens, yet decode works
+    assert t2.decode([1000, 257]) == "<|endoftext|> ab"
+
+
+def test_load_asserts(tmp_path):
+    t = Tokenizer()
+    with pytest.raises(AssertionError):
+        t.load(str(tmp_path / "x.txt"))
+    p = tmp_path / "bad.model"
+    p.write_text("minbpe v2\n\n0\n")
+    with pytest.raises(AssertionError):
+        t.load(str(p))
+
+
+def test_decode_paths():
+    b = BasicTokenizer()
+    assert b.decode([104, 105]) == "hi"
+    assert b.decode([0xff]) == "�"  # errors="replace"
+    with pytest.raises(KeyError):
+        b.decode([999])
+    r = RegexTokenizer()
+    with pytest.raises(ValueError, match="invalid token id: 999"):
+        r.decode([999])
+    r.register_special_tokens({"<|x|>": 999})
+    assert r.decode([104, 999]) == "h<|x|>"
+
+
+def test_base_class_is_abstract():
+    t = Tokenizer()
+    for call in (lambda: t.train("a", 256), lambda: t.encode("a"), lambda: t.decode([1])):
+        with pytest.raises(NotImplementedError):
+            call()
+    assert len(t.vocab) == 256 and t.pattern == "" and t.merges == {}
+
+
+def test_train_asserts_vocab_size_before_touching_the_gpu():
+    with pytest.raises(AssertionError):
+        BasicTokenizer().train("abc", 255)
+    with pytest.raises(AssertionError):
+        RegexTokenizer().train("abc", 10)
+
+
+def test_encode_allowed_special_validation():
+    r = RegexTokenizer()
+    r.register_special_tokens({"<|x|>": 999})
+    with pytest.raises(ValueError, match="not understood"):
+        r.encode("abc", allowed_special="bogus")
+    with pytest.raises(AssertionError):
+        r.encode("a<|x|>b")  # none_raise
+
+
+def test_concat_chunks_drops_empty():
+    data, offs = _concat_chunks([b"ab", b"", b"c", b"def"])
+    assert data == b"abcdef" and offs.tolist() == [0, 2, 3]
+    data, offs = _concat_chunks([])
+    assert data == b"" and len(offs) == 0
+
+
+def test_render_token():
+    assert render_token(b"a\nb") == "a\\u000ab"
+    assert render_token(b"\xff") == "�"
