@@ -39,6 +39,8 @@ def _load():
     lib.orc_get_stats.argtypes = [p, p, C.c_uint64, p, p, p, p, C.c_uint64]
     lib.orc_merge.restype = C.c_uint64
     lib.orc_merge.argtypes = [p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, p]
+    lib.orc_merge_chunks.restype = C.c_uint64
+    lib.orc_merge_chunks.argtypes = [p, p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
     lib.orc_train.restype = C.c_int64
     lib.orc_train.argtypes = [p, C.c_uint64, p, C.c_uint64, C.c_int32, p, p, p, p]
     lib.orc_encode.restype = C.c_int64
@@ -84,6 +86,15 @@ def merge(ids, pair, idx):
     out = np.empty(max(len(ids), 1), np.int32)
     n = lib.orc_merge(_ptr(ids), len(ids), int(pair[0]), int(pair[1]), int(idx), _ptr(out))
     return out[:n].copy()
+
+
+def merge_chunks(ids, offsets, pair, idx):
+    """merge() on every chunk (regex.py:60).  Returns (new ids, new n_chunks+1 offsets)."""
+    lib = _load()
+    buf = np.array(ids, dtype=np.int32)
+    off = _offsets(len(buf), offsets).copy()
+    n = lib.orc_merge_chunks(_ptr(buf), _ptr(off), len(off) - 1, int(pair[0]), int(pair[1]), int(idx))
+    return buf[:n].copy(), off
 
 
 def train(data: bytes, num_merges: int, offsets=None, raise_on_empty=True):
