@@ -63,8 +63,12 @@ struct bpe_ctx {
     IterRec *h_rec = nullptr;  // pinned, device-visible
     int rec_cap = 0;
     unsigned long long *d_scratch = nullptr;  // 2 x u64 cursor/counter
+    uint32_t *d_delta = nullptr;       // 4 x vcap: decL | decR | incL | incR
+    uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
+    uint32_t *d_dirty_n = nullptr;
+    int depth = 8;  // iterations the host may run ahead of the device
 
-    int mode = 0;     // 0 recount | 1 delta
+    int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // hipEvents around hot kernels
     int k1 = 1;       // 0 simple | 1 LDS-cached pair count
 
@@ -143,6 +147,11 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
     TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
     TRY(dev_realloc(c, c->d_rowmax, (size_t)nv));
+    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4));
+    TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
+    if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
     if (c->d_first) {
         HIPCHK(c, hipFree(c->d_first));
         c->d_first = nullptr;
@@ -287,17 +296,19 @@ int launch_select(bpe_ctx *c, bool rowmax_all, int iter, IterRec *rec) {
         LAUNCHCHK(c, "k_tiebreak");
     }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st, rec,
-                       iter);
+                       iter, c->d_dirty_n);
     LAUNCHCHK(c, "k_finalize");
     TRY(prof_end(c));
     return BPE_OK;
 }
 
 // K3: three passes (summary, tile scan, rewrite); flips the ping-pong parity.
-int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
-    const uint64_t n = c->n;
+// with_delta: the rewrite pass also accumulates the pair-table delta vectors,
+// which k_apply_delta / k_rowmax_list then fold into the table.
+int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_delta) {
+    const uint64_t n = c->n;  // upper bound of the device-side length
     const uint64_t nt = ntiles_of(n);
-    TRY(prof_begin(c, BPE_PROF_MERGE, 4 * n));  // + 4*new_len once known
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (nt) {
         hipLaunchKernelGGL(k_merge_count, dim3((unsigned)nt), dim3(MT), 0, c->stream,
                            c->d_ids[c->par], c->d_st, c->par, c->d_tsum);
@@ -307,12 +318,28 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
                        c->d_tile_sin, c->d_st, c->par, rec, iter);
     LAUNCHCHK(c, "k_tile_scan");
     if (nt) {
-        hipLaunchKernelGGL(k_merge_scatter, dim3((unsigned)nt), dim3(MT), 0, c->stream,
-                           c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_tile_off,
-                           c->d_tile_sin, newid);
+        if (with_delta)
+            hipLaunchKernelGGL(k_merge_scatter<true>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
+                               c->d_tile_off, c->d_tile_sin, newid, c->d_delta, c->vcap);
+        else
+            hipLaunchKernelGGL(k_merge_scatter<false>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
+                               c->d_tile_off, c->d_tile_sin, newid, (uint32_t *)nullptr, c->vcap);
         LAUNCHCHK(c, "k_merge_scatter");
     }
     TRY(prof_end(c));
+    if (with_delta) {
+        TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+        hipLaunchKernelGGL(k_apply_delta, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
+                           c->d_dirty_list, c->d_dirty_n);
+        LAUNCHCHK(c, "k_apply_delta");
+        hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           newid + 1, c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+        LAUNCHCHK(c, "k_rowmax_list");
+        TRY(prof_end(c));
+    }
     c->par ^= 1;
     c->stats_valid = false;
     return BPE_OK;
@@ -375,7 +402,8 @@ void bpe_destroy(bpe_ctx *c) {
     }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
-                    c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch};
+                    c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
+                    c->d_delta,  c->d_dirty_list, c->d_dirty_n};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -402,6 +430,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->profile = value != 0;
     } else if (!strcmp(name, "k1")) {
         c->k1 = (int)value;
+    } else if (!strcmp(name, "depth")) {
+        if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
+        c->depth = (int)value;
     } else {
         return fail(c, BPE_E_ARG, "unknown option '%s'", name);
     }
@@ -570,7 +601,7 @@ int bpe_merge(bpe_ctx *c, int32_t a, int32_t b, int32_t idx, uint64_t *new_len) 
     TRY(ensure_table(c, (uint32_t)std::max(idx, std::max(a, b)) + 1));
     hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->d_st, a, b);
     LAUNCHCHK(c, "k_set_pair");
-    TRY(launch_merge(c, (uint32_t)idx, 0, nullptr));
+    TRY(launch_merge(c, (uint32_t)idx, 0, nullptr, false));
     DevState st;
     TRY(read_state(c, &st));
     c->n = st.n[c->par];
@@ -638,42 +669,94 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_table(c, 256u + (uint32_t)num_merges));
     TRY(ensure_rec(c, std::max(num_merges, 1)));
+    memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
     TRY(start_from_bytes(c));
+    const bool delta = (c->mode == 1);
     std::vector<hipEvent_t> evs;
     if (iter_ms_out) {
         evs.resize((size_t)num_merges + 1);
         for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
-        HIPCHK(c, hipEventRecord(evs[0], c->stream));
     }
-    int done = 0, rc = BPE_OK;
-    for (int i = 0; i < num_merges; i++) {
-        c->vcur = 256u + (uint32_t)i;
-        TRY(clear_table(c));
-        TRY(launch_pair_count(c, false));
-        TRY(launch_select(c, true, i, c->h_rec));
-        TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec));
-        if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const IterRec &r = c->h_rec[i];
-        if (r.status == ST_EMPTY) {
-            rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", i);
-            c->par ^= 1;  // the merge kernels did nothing
-            break;
+    // statistics of the initial byte stream (iteration 0 of both modes)
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(prof_end(c));
+    if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[0], c->stream));
+    const uint64_t n0 = c->n;
+    TRY(launch_pair_count(c, false));
+    if (c->profile) c->prof_bytes[BPE_PROF_PAIR_COUNT] += 4 * n0;
+
+    int done = 0, rc = BPE_OK, consumed = 0;
+    uint64_t cur_len = n0;  // exact length before iteration `consumed`
+    bool stop = false;
+    // The device writes one IterRec per iteration into pinned host memory; the
+    // host runs up to `depth` iterations ahead and only ever waits on those
+    // records, never on the stream (no hipStreamSynchronize in the loop).
+    auto consume = [&](int j) -> int {
+        volatile IterRec *r = &c->h_rec[j];
+        for (uint64_t spins = 1; r->seq != (unsigned long long)j + 1; spins++) {
+            if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
+                r->seq != (unsigned long long)j + 1)
+                return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
         }
-        if (r.status != ST_OK) {
-            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d", r.status, i);
-            break;
+        __sync_synchronize();
+        if (r->status == ST_EMPTY) {
+            stop = true;
+            rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
+            return BPE_OK;
+        }
+        if (r->status != ST_OK) {
+            stop = true;
+            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d", r->status, j);
+            return BPE_OK;
         }
         if (pairs_out) {
-            pairs_out[2 * i] = r.a;
-            pairs_out[2 * i + 1] = r.b;
+            pairs_out[2 * j] = r->a;
+            pairs_out[2 * j + 1] = r->b;
         }
-        if (counts_out) counts_out[i] = r.count;
-        if (len_out) len_out[i] = r.new_len;
-        c->n = r.new_len;
-        if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * r.new_len;
-        done++;
+        if (counts_out) counts_out[j] = r->count;
+        if (len_out) len_out[j] = r->new_len;
+        if (c->profile) {
+            // algorithmic bytes: get_stats reads 4N_i, merge reads 4N_i, writes 4N_{i+1}
+            if (delta) {
+                c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * cur_len + r->new_len);
+            } else {
+                c->prof_bytes[BPE_PROF_MERGE] += 4 * (cur_len + r->new_len);
+                if (j > 0) c->prof_bytes[BPE_PROF_PAIR_COUNT] += 4 * cur_len;
+            }
+        }
+        cur_len = r->new_len;
+        c->n = cur_len;  // tighter launch bound for what is enqueued next
+        done = j + 1;
+        return BPE_OK;
+    };
+
+    for (int i = 0; i < num_merges && !stop; i++) {
+        c->vcur = 256u + (uint32_t)i;
+        bool full_rowmax = (i == 0);
+        if (!delta && i > 0) {
+            TRY(clear_table(c));
+            TRY(launch_pair_count(c, false));
+            full_rowmax = true;
+        }
+        TRY(launch_select(c, full_rowmax, i, c->h_rec));
+        TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
+        if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
+        if (i - consumed >= c->depth) {
+            TRY(consume(consumed));
+            consumed++;
+        }
     }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int enq = consumed + 0;
+    (void)enq;
+    while (!stop && consumed < num_merges && c->h_rec[consumed].seq == (unsigned long long)consumed + 1) {
+        TRY(consume(consumed));
+        consumed++;
+    }
+    // device buffers hold the stream after `done` merges
+    c->par = done & 1;
+    c->n = cur_len;
     c->vcur = 256u + (uint32_t)done;
     if (iter_ms_out) {
         for (int i = 0; i < done; i++) {

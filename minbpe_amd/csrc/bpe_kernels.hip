@@ -307,8 +307,10 @@ k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
     }
 }
 
-__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st, IterRec *rec, int iter) {
+__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st, IterRec *rec, int iter,
+                           uint32_t *dirty_n) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (dirty_n) *dirty_n = 0;
     if (st->status == 0 && !st->found) {
         const unsigned long long p = st->firstpos;
         if (p == NOPOS) {
@@ -354,6 +356,7 @@ struct Tile {
     uint32_t x[MJ][4];  // words
     uint32_t rb[MJ];    // r bits of my 4 elements per stripe
     int E[MJ];          // tile-relative index of the last zero of r before my group (-1: none)
+    uint32_t tail[3];   // the three words after this wave's span (INVALID_WORD past n)
 };
 
 __device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
@@ -371,7 +374,9 @@ __device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ 
         t.x[j][3] = (p0 + 3 < n) ? v.w : INVALID_WORD;
     }
     const uint64_t tailp = wbase + WAVE_SPAN;
-    const uint32_t tail = (tailp < n) ? ids[tailp] : INVALID_WORD;
+#pragma unroll
+    for (int i = 0; i < 3; i++) t.tail[i] = (tailp + i < n) ? ids[tailp + i] : INVALID_WORD;
+    const uint32_t tail = t.tail[0];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const uint32_t nb = (uint32_t)__shfl((int)t.x[j][0], (lane + 1) & 63);
@@ -495,81 +500,125 @@ k_merge_count(const uint32_t *__restrict__ ids, const DevState *__restrict__ st,
     }
 }
 
-// pass 2: one workgroup walks the tile summaries: carry s and output offset per tile.
+// pass 2: one workgroup turns the tile summaries into (carry s, output offset)
+// per tile.  A tile acts on the carry as a 2-state transducer; transducers
+// compose associatively, so the 1024 per-thread range summaries are combined
+// with a wave-shuffle scan instead of a serial walk.
+struct TS {
+    unsigned long long k0, k1;  // ids kept by the range for carry-in 0 / 1
+    uint32_t o;                 // bit 0: carry-out for carry-in 0, bit 1: for carry-in 1
+};
+__device__ __forceinline__ TS ts_then(const TS &A, const TS &B) {  // A followed by B
+    const uint32_t a0 = A.o & 1u, a1 = (A.o >> 1) & 1u, b0 = B.o & 1u, b1 = (B.o >> 1) & 1u;
+    TS r;
+    r.k0 = A.k0 + (a0 ? B.k1 : B.k0);
+    r.k1 = A.k1 + (a1 ? B.k1 : B.k0);
+    r.o = (a0 ? b1 : b0) | ((a1 ? b1 : b0) << 1);
+    return r;
+}
+__device__ __forceinline__ TS ts_shfl_up(const TS &v, int d) {
+    TS r;
+    r.k0 = __shfl_up(v.k0, d);
+    r.k1 = __shfl_up(v.k1, d);
+    r.o = (uint32_t)__shfl_up((int)v.o, d);
+    return r;
+}
+__device__ __forceinline__ void tile_step(uint64_t w, uint32_t len, uint32_t s,
+                                          unsigned long long &kept, uint32_t &sout) {
+    const uint32_t M0 = (uint32_t)w, podd = (w >> 32) & 1, allones = (w >> 33) & 1, o0 = (w >> 34) & 1;
+    const uint32_t Ms = M0 - (s & podd);
+    const uint32_t os = allones ? (o0 ^ s) : o0;
+    kept += len - s - (Ms - os);
+    sout = os;
+}
+
 __global__ void __launch_bounds__(1024)
 k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__restrict__ tile_off,
             uint8_t *__restrict__ tile_sin, DevState *st, int par, IterRec *rec, int iter) {
-    __shared__ unsigned long long s_kept[1024][2];
-    __shared__ uint8_t s_out[1024][2];
-    __shared__ unsigned long long s_off[1024];
-    __shared__ uint8_t s_sin[1024];
+    __shared__ TS s_w[16];
     if (st->status) {
-        if (threadIdx.x == 0 && rec) rec[iter].new_len = st->n[par];
+        if (threadIdx.x == 0 && rec) {
+            rec[iter].new_len = st->n[par];
+            __threadfence_system();
+            rec[iter].seq = (unsigned long long)iter + 1;
+        }
         return;
     }
     const uint64_t n = st->n[par];
     const uint64_t R = (ntiles + 1023) / 1024;
     const uint64_t t0 = min((uint64_t)threadIdx.x * R, ntiles), t1 = min(t0 + R, ntiles);
-    unsigned long long kept[2] = {0, 0};
-    uint32_t sc[2] = {0, 1};
+    TS mine;
+    mine.k0 = mine.k1 = 0;
+    uint32_t sc0 = 0, sc1 = 1;
     for (uint64_t t = t0; t < t1; t++) {
         const uint64_t tb = t * TILE;
         if (tb >= n) break;
         const uint64_t w = tsum[t];
-        const uint32_t M0 = (uint32_t)w, podd = (w >> 32) & 1, allones = (w >> 33) & 1,
-                       o0 = (w >> 34) & 1;
         const uint32_t len = (uint32_t)min((uint64_t)TILE, n - tb);
+        tile_step(w, len, sc0, mine.k0, sc0);
+        tile_step(w, len, sc1, mine.k1, sc1);
+    }
+    mine.o = sc0 | (sc1 << 1);
+    // inclusive scan across the workgroup
+    const int lane = lane_id(), wave = wave_id();
+    TS inc = mine;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t s = sc[q];
-            const uint32_t Ms = M0 - (s & podd);
-            const uint32_t os = allones ? (o0 ^ s) : o0;
-            kept[q] += len - s - (Ms - os);
-            sc[q] = os;
+    for (int d = 1; d < 64; d <<= 1) {
+        const TS p = ts_shfl_up(inc, d);
+        if (lane >= d) inc = ts_then(p, inc);
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    TS pre;  // everything before this thread
+    pre.k0 = pre.k1 = 0;
+    pre.o = 2u;  // identity
+    for (int w = 0; w < wave; w++) pre = ts_then(pre, s_w[w]);
+    TS exl = ts_shfl_up(inc, 1);
+    if (lane == 0) {
+        exl.k0 = exl.k1 = 0;
+        exl.o = 2u;
+    }
+    pre = ts_then(pre, exl);
+    uint32_t s = pre.o & 1u;               // carry-in of my first tile (stream starts with 0)
+    unsigned long long off = pre.k0;
+    if (threadIdx.x == 1023) {
+        const TS all = ts_then(pre, mine);
+        st->n[par ^ 1] = all.k0;
+        if (rec) {
+            rec[iter].new_len = all.k0;
+            __threadfence_system();
+            rec[iter].seq = (unsigned long long)iter + 1;
         }
     }
-    s_kept[threadIdx.x][0] = kept[0];
-    s_kept[threadIdx.x][1] = kept[1];
-    s_out[threadIdx.x][0] = (uint8_t)sc[0];
-    s_out[threadIdx.x][1] = (uint8_t)sc[1];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t s = 0;
-        unsigned long long off = 0;
-        for (int i = 0; i < 1024; i++) {
-            s_sin[i] = (uint8_t)s;
-            s_off[i] = off;
-            off += s_kept[i][s];
-            s = s_out[i][s];
-        }
-        st->n[par ^ 1] = off;
-        if (rec) rec[iter].new_len = off;
-    }
-    __syncthreads();
-    uint32_t s = s_sin[threadIdx.x];
-    unsigned long long off = s_off[threadIdx.x];
     for (uint64_t t = t0; t < t1; t++) {
         const uint64_t tb = t * TILE;
         if (tb >= n) break;
         const uint64_t w = tsum[t];
-        const uint32_t M0 = (uint32_t)w, podd = (w >> 32) & 1, allones = (w >> 33) & 1,
-                       o0 = (w >> 34) & 1;
         const uint32_t len = (uint32_t)min((uint64_t)TILE, n - tb);
         tile_off[t] = off;
         tile_sin[t] = (uint8_t)s;
-        const uint32_t Ms = M0 - (s & podd);
-        const uint32_t os = allones ? (o0 ^ s) : o0;
-        off += len - s - (Ms - os);
-        s = os;
+        tile_step(w, len, s, off, s);
     }
 }
 
 // pass 3: rewrite.  kept[p] = !m[p-1]; a site start emits the new id (and keeps
 // the chunk-start flag of its first element).
+//
+// DELTA: the same pass also records how the pair table changes (SURVEY.md N3,
+// done inside the full streaming pass).  Every old pair with a merged element
+// disappears, every new pair with a new token appears; with (a,b) -> Z they are
+// exactly (L,a), (b,R), (L,Z), (Z,R), so four vectors indexed by one token
+// describe the whole update:
+//   decL[L] : pairs (L,a) destroyed      decR[R] : pairs (b,R) destroyed
+//   incL[L] : pairs (L,Z) created        incR[R] : pairs (Z,R) created (R may be Z)
+// Each destroyed pair is charged to its left element, each created pair to its
+// left output element, so nothing is counted twice.
+template <bool DELTA>
 __global__ void __launch_bounds__(MT)
 k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                 const DevState *__restrict__ st, int par, const uint64_t *__restrict__ tile_off,
-                const uint8_t *__restrict__ tile_sin, uint32_t newid) {
+                const uint8_t *__restrict__ tile_sin, uint32_t newid, uint32_t *__restrict__ delta,
+                uint32_t vcap) {
     __shared__ int s_wave[MT / 64];
     __shared__ uint32_t s_wsum[MT / 64];
     if (st->status) return;
@@ -581,17 +630,16 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     Tile t;
     tile_load(t, in, n, tile_base, a, b, s_wave);
     const int lane = lane_id(), wave = wave_id();
-    uint32_t mb[MJ], kb[MJ], ex[MJ];
+    uint32_t mb[MJ], mp[MJ], kb[MJ], ex[MJ];
     uint32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        uint32_t mprev;
-        mb[j] = group_mbits(t, j, s, mprev);
+        mb[j] = group_mbits(t, j, s, mp[j]);
         // kept bit k = !m[k-1], only for valid positions
         uint32_t valid = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) valid |= (uint32_t)(t.x[j][k] != INVALID_WORD) << k;
-        kb[j] = (~((mb[j] << 1) | mprev)) & valid & 0xFu;
+        kb[j] = (~((mb[j] << 1) | mp[j])) & valid & 0xFu;
         uint32_t v = __popc(kb[j]);
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -616,6 +664,120 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                 dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
             }
         }
+    }
+    if (DELTA) {
+        // m bits and words of the two elements after my group: from the next
+        // lane, the next stripe, or (end of the wave) recomputed from the tail.
+        const uint32_t t0 = t.tail[0], t1 = t.tail[1], t2 = t.tail[2];
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const uint32_t nb_m = (uint32_t)__shfl((int)mb[j], (lane + 1) & 63);
+            const uint32_t nb_x0 = (uint32_t)__shfl((int)t.x[j][0], (lane + 1) & 63);
+            const uint32_t nb_x1 = (uint32_t)__shfl((int)t.x[j][1], (lane + 1) & 63);
+            uint32_t up_m, up_x0, up_x1;
+            if (j < MJ - 1) {
+                up_m = (uint32_t)__shfl((int)mb[(j + 1) % MJ], 0);
+                up_x0 = (uint32_t)__shfl((int)t.x[(j + 1) % MJ][0], 0);
+                up_x1 = (uint32_t)__shfl((int)t.x[(j + 1) % MJ][1], 0);
+            } else {
+                const uint32_t m3 = (mb[j] >> 3) & 1u;  // only lane 63's value is used
+                const uint32_t r4 = (uint32_t)(((t0 & IDMASK) == a) & (t1 == b));
+                const uint32_t m4 = r4 & (m3 ^ 1u);
+                const uint32_t r5 = (uint32_t)(((t1 & IDMASK) == a) & (t2 == b));
+                const uint32_t m5 = r5 & (m4 ^ 1u);
+                up_m = m4 | (m5 << 1);
+                up_x0 = t0;
+                up_x1 = t1;
+            }
+            const bool last = (lane == 63);
+            const uint32_t X[6] = {t.x[j][0], t.x[j][1], t.x[j][2], t.x[j][3],
+                                   last ? up_x0 : nb_x0, last ? up_x1 : nb_x1};
+            // bit (k+1) = m[k], k = -1..5
+            const uint32_t Mx = mp[j] | (mb[j] << 1) | (((last ? up_m : nb_m) & 3u) << 5);
+            if (mb[j] | mp[j] | (Mx >> 5)) {  // nothing to record far from any site
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t Mk = (Mx >> (k + 1)) & 1u, Mkm1 = (Mx >> k) & 1u,
+                                   Mkp1 = (Mx >> (k + 2)) & 1u;
+                    if (X[k] == INVALID_WORD) continue;
+                    if (!(X[k + 1] & FLAG) && !Mk) {  // an old pair that is not the site itself
+                        if (Mkm1) atomicAdd(&delta[1 * (size_t)vcap + X[k + 1]], 1u);
+                        else if (Mkp1) atomicAdd(&delta[0 * (size_t)vcap + (X[k] & IDMASK)], 1u);
+                    }
+                    if (!Mkm1) {  // output element
+                        const uint32_t Xq = Mk ? X[k + 2] : X[k + 1];
+                        const uint32_t Mq = Mk ? ((Mx >> (k + 3)) & 1u) : Mkp1;
+                        if (!(Xq & FLAG)) {
+                            if (Mk) atomicAdd(&delta[3 * (size_t)vcap + (Mq ? newid : Xq)], 1u);
+                            else if (Mq) atomicAdd(&delta[2 * (size_t)vcap + (X[k] & IDMASK)], 1u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Apply the four delta vectors to the dense table and keep rowmax[] current.
+// Thread t owns token t: column a, row b, the new column Z and the new row Z.
+// Rows whose maximum may have dropped are queued for k_rowmax_list; for every
+// other row the only entry that grew is the brand-new column Z.
+__global__ void __launch_bounds__(256)
+k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta,
+              uint32_t vcap, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
+              uint32_t Z, uint32_t *__restrict__ dirty_list, uint32_t *__restrict__ dirty_n) {
+    if (st->status) return;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > Z) return;
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    const uint32_t dl = delta[t], dr = delta[vcap + t], il = delta[2 * (size_t)vcap + t],
+                   ir = delta[3 * (size_t)vcap + t];
+    delta[t] = 0;
+    delta[vcap + t] = 0;
+    delta[2 * (size_t)vcap + t] = 0;
+    delta[3 * (size_t)vcap + t] = 0;
+    bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
+    if (dl) {
+        const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], dl);
+        if (t != Z && old == rowmax[t]) dirty = true;
+    }
+    if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
+    if (il) atomicAdd(&mat[(size_t)t * stride + Z], il);
+    if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+    if (dirty) {
+        dirty_list[atomicAdd(dirty_n, 1u)] = t;
+    } else if (il > rowmax[t]) {
+        rowmax[t] = il;  // column Z was empty before this iteration
+    }
+}
+
+// Recompute rowmax for the queued rows; also retires the merged pair: after the
+// merge no (a,b) remains (F2), whatever the a == b bookkeeping left there.
+__global__ void __launch_bounds__(256)
+k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
+              uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
+              const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
+    __shared__ uint32_t s_red[4];
+    if (st->status) return;
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    const uint32_t nd = *dirty_n;
+    for (uint32_t i = blockIdx.x; i < nd; i += gridDim.x) {
+        const uint32_t x = dirty_list[i];
+        uint32_t *row = mat + (size_t)x * stride;
+        uint32_t m = 0;
+        for (uint32_t y = threadIdx.x; y < vnew; y += 256) {
+            uint32_t v = row[y];
+            if (x == a && y == b) {
+                v = 0;
+                row[y] = 0;
+            }
+            m = max(m, v);
+        }
+        m = wave_max_u32(m);
+        __syncthreads();
+        if (lane_id() == 0) s_red[wave_id()] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     }
 }
 

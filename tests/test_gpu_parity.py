@@ -106,27 +106,37 @@ def test_train_golden_cases(golden, engine, native):
         assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
 
 
-@pytest.mark.parametrize("mode", [0])
-@pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300)])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
+                                    (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
 def test_train_tie_heavy_vs_oracle(engine, mode, k, n, nm):
     rng = random.Random(k * 1000 + n)
     data = bytes(97 + rng.randrange(k) for _ in range(n))
     engine.set_option("mode", mode)
-    engine.load_bytes(data)
     try:
-        exp = oracle.train(data, nm)
-    except oracle.OracleEmptyStats:
-        with pytest.raises(ValueError):
-            engine.train(nm)
-        return
-    res = engine.train(nm)
-    assert res["pairs"] == exp[0]
-    assert res["counts"] == exp[1]
-    assert res["lens"] == exp[2]
+        engine.load_bytes(data)
+        exp = oracle.train(data, nm, raise_on_empty=False)
+        if len(exp[0]) < nm:  # the oracle ran out of pairs: so must we, at the same merge
+            with pytest.raises(ValueError):
+                engine.train(nm)
+            res = engine.last_train
+        else:
+            res = engine.train(nm)
+        assert res["pairs"] == exp[0]
+        assert res["counts"] == exp[1]
+        assert res["lens"] == exp[2]
+        # the resident stream is the oracle's final stream
+        ids = np.frombuffer(data, dtype=np.uint8).astype(np.int32)
+        for i, p in enumerate(exp[0]):
+            ids = oracle.merge(ids, p, 256 + i)
+        assert np.array_equal(engine.read_ids(), ids)
+    finally:
+        engine.set_option("mode", 1)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_train_synth_2mb_vs_oracle(engine, native, kind):
+def test_train_synth_2mb_vs_oracle(engine, native, kind, mode):
     text = native.synth_text(2_000_000, 11)
     if kind == "basic":
         data, offs = text, None
@@ -134,13 +144,21 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind):
         data, offs = split_chunks(text.decode())
     nm = 400
     exp = oracle.train(data, nm, offs)
-    engine.load_bytes(data, offs)
-    res = engine.train(nm)
-    assert res["pairs"] == exp[0]
-    assert res["counts"] == exp[1]
-    assert res["lens"] == exp[2]
-    # re-running from the resident bytes gives the same answer (bench does this)
-    assert engine.train(nm)["pairs"] == exp[0]
+    engine.set_option("mode", mode)
+    try:
+        engine.load_bytes(data, offs)
+        res = engine.train(nm)
+        assert res["pairs"] == exp[0]
+        assert res["counts"] == exp[1]
+        assert res["lens"] == exp[2]
+        # re-running from the resident bytes gives the same answer (bench does this)
+        assert engine.train(nm)["pairs"] == exp[0]
+        # depth 0 = host waits for every iteration: same result
+        engine.set_option("depth", 0)
+        assert engine.train(nm)["pairs"] == exp[0]
+    finally:
+        engine.set_option("mode", 1)
+        engine.set_option("depth", 8)
 
 
 # ---------------------------------------------------------------------------
