@@ -67,6 +67,10 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
+    int merge_impl = 1;  // 0 three-pass | 1 single-pass (decoupled look-back)
+    unsigned long long *d_desc = nullptr;  // look-back descriptors, one per tile
+    uint64_t cap_desc = 0;
+    uint32_t epoch = 0;
 
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // hipEvents around hot kernels
@@ -135,6 +139,8 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_tsum, nt));
         TRY(dev_realloc(c, c->d_tile_off, nt));
         TRY(dev_realloc(c, c->d_tile_sin, nt));
+        TRY(dev_realloc(c, c->d_desc, nt));
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
         c->cap_tiles = nt;
     }
     return BPE_OK;
@@ -147,10 +153,10 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
     TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
     TRY(dev_realloc(c, c->d_rowmax, (size_t)nv));
-    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4));
+    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL));
     TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
     if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
-    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * DELTA_REPL * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
     if (c->d_first) {
         HIPCHK(c, hipFree(c->d_first));
@@ -274,30 +280,23 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
     return BPE_OK;
 }
 
-// K2 + tie-break + finalize: decides st->a, st->b
-int launch_select(bpe_ctx *c, bool rowmax_all, int iter, IterRec *rec) {
+// K2 + tie-break: after these, resolved_pair() gives the pair on the device
+int launch_select(bpe_ctx *c, bool rowmax_all) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     if (rowmax_all) {
         hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
                            c->vcur, c->d_rowmax);
         LAUNCHCHK(c, "k_rowmax_all");
     }
-    hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st);
-    LAUNCHCHK(c, "k_argmax");
-    // growing windows: ties among frequent pairs resolve in the first one
-    const uint64_t n = c->n;
-    const uint64_t edges[4] = {0, 1ull << 20, 1ull << 24, n};
-    for (int s = 0; s < 3; s++) {
-        const uint64_t lo = edges[s], hi = std::min(edges[s + 1], n);
-        if (lo >= hi) break;
-        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(hi - lo, 256, c->num_cus * 8)), dim3(256), 0,
-                           c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat, c->vcap, lo, hi);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
+                       c->vcur, c->d_st, c->d_ids[c->par], c->par);
+    LAUNCHCHK(c, "k_select");
+    if (c->n > TIE_WINDOW0) {
+        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(c->n - TIE_WINDOW0, 256, c->num_cus * 4)),
+                           dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
+                           c->vcap, (uint64_t)TIE_WINDOW0);
         LAUNCHCHK(c, "k_tiebreak");
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st, rec,
-                       iter, c->d_dirty_n);
-    LAUNCHCHK(c, "k_finalize");
     TRY(prof_end(c));
     return BPE_OK;
 }
@@ -309,13 +308,29 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
     const uint64_t n = c->n;  // upper bound of the device-side length
     const uint64_t nt = ntiles_of(n);
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if (c->merge_impl == 1) {
+        if ((++c->epoch & 0x3FFFFFu) == 0) {  // tag wrapped: retire every old descriptor
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+            c->epoch++;
+        }
+        const unsigned grid = (unsigned)std::max<uint64_t>(nt, 1);
+        if (with_delta)
+            hipLaunchKernelGGL(k_merge_lookback<true>, dim3(grid), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
+                               c->epoch, newid, c->d_delta, c->vcap, rec, iter, c->d_dirty_n);
+        else
+            hipLaunchKernelGGL(k_merge_lookback<false>, dim3(grid), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
+                               c->epoch, newid, (uint32_t *)nullptr, c->vcap, rec, iter, c->d_dirty_n);
+        LAUNCHCHK(c, "k_merge_lookback");
+    } else {
     if (nt) {
         hipLaunchKernelGGL(k_merge_count, dim3((unsigned)nt), dim3(MT), 0, c->stream,
                            c->d_ids[c->par], c->d_st, c->par, c->d_tsum);
         LAUNCHCHK(c, "k_merge_count");
     }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tsum, nt, c->d_tile_off,
-                       c->d_tile_sin, c->d_st, c->par, rec, iter);
+                       c->d_tile_sin, c->d_st, c->par, rec, iter, c->d_ids[c->par], c->d_dirty_n);
     LAUNCHCHK(c, "k_tile_scan");
     if (nt) {
         if (with_delta)
@@ -327,6 +342,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
                                c->d_tile_off, c->d_tile_sin, newid, (uint32_t *)nullptr, c->vcap);
         LAUNCHCHK(c, "k_merge_scatter");
+    }
     }
     TRY(prof_end(c));
     if (with_delta) {
@@ -403,7 +419,7 @@ void bpe_destroy(bpe_ctx *c) {
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
                     c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
-                    c->d_delta,  c->d_dirty_list, c->d_dirty_n};
+                    c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -430,6 +446,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->profile = value != 0;
     } else if (!strcmp(name, "k1")) {
         c->k1 = (int)value;
+    } else if (!strcmp(name, "merge")) {
+        if (value != 0 && value != 1) return fail(c, BPE_E_ARG, "merge must be 0 or 1");
+        c->merge_impl = (int)value;
     } else if (!strcmp(name, "depth")) {
         if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
         c->depth = (int)value;
@@ -582,7 +601,9 @@ int bpe_argmax(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *count) {
     TRY(clear_table(c));
     TRY(launch_pair_count(c, false));
     c->stats_valid = false;
-    TRY(launch_select(c, true, 0, nullptr));
+    TRY(launch_select(c, true));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st);
+    LAUNCHCHK(c, "k_finalize");
     DevState st;
     TRY(read_state(c, &st));
     if (st.status == ST_EMPTY) return fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence");
@@ -707,7 +728,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         if (r->status != ST_OK) {
             stop = true;
-            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d", r->status, j);
+            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d%s", r->status, j,
+                      r->status == ST_LOOKBACK ? " (look-back wait timed out; set option merge=0)" : "");
             return BPE_OK;
         }
         if (pairs_out) {
@@ -739,7 +761,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             TRY(launch_pair_count(c, false));
             full_rowmax = true;
         }
-        TRY(launch_select(c, full_rowmax, i, c->h_rec));
+        TRY(launch_select(c, full_rowmax));
         TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
         if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
         if (i - consumed >= c->depth) {

@@ -23,9 +23,12 @@ constexpr int PC_BITS = 13;
 constexpr int PC_THREADS = 512;
 
 constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
-constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_argmax
+constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
+constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select itself searches on a tie
+constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
 
-constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2;
+constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
+constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile
 
 // one per ctx, in device memory
 struct DevState {
@@ -37,6 +40,7 @@ struct DevState {
     uint32_t found;               // (a,b) decided
     uint32_t status;              // ST_*
     int32_t tied[2 * TIE_CAP];
+    int32_t fin_a, fin_b;         // the pair as finalised by the merge pass (read by k_apply_delta)
 };
 
 // one per training iteration, written by the device into pinned host memory

@@ -197,13 +197,29 @@ k_rowmax_all(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur,
     if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
-// Single workgroup: global max over rowmax, then gather every pair that attains
-// it (the candidates of the reference's first-occurrence tie-break, F3).
+// the pair test of the tie-break: is (a, w1) one of the pairs tied at the max?
+__device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint32_t M,
+                                        const uint32_t *__restrict__ mat, uint32_t stride,
+                                        uint32_t a, uint32_t w1) {
+    if (nt <= TIE_CAP) {
+        bool hit = false;
+        for (uint32_t t = 0; t < nt; t++)
+            hit |= (s_tied[2 * t] == (int32_t)a) & (s_tied[2 * t + 1] == (int32_t)w1);
+        return hit;
+    }
+    return mat[(size_t)a * stride + w1] == M;
+}
+
+// K2, single workgroup: global max over rowmax, gather every pair that attains
+// it (the candidates of the reference's first-occurrence tie-break, F3), and --
+// if there is a tie -- search the first TIE_WINDOW0 positions of the stream for
+// the earliest tied pair.  Ties among frequent pairs always resolve there; the
+// rest of the stream is k_tiebreak's job.
 __global__ void __launch_bounds__(1024)
-k_argmax(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st) {
+k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
+         uint32_t vcur, DevState *st, const uint32_t *__restrict__ ids, int par) {
     __shared__ uint32_t s_red[16];
-    __shared__ uint32_t s_M, s_nrows, s_nt;
+    __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
     __shared__ int32_t s_tied[2 * TIE_CAP];
     if (st->status) return;
@@ -214,6 +230,7 @@ k_argmax(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (threadIdx.x == 0) {
         s_nrows = 0;
         s_nt = 0;
+        s_first = 0xFFFFFFFFu;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -257,28 +274,47 @@ k_argmax(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     __syncthreads();
     const uint32_t nt = (nrows > ARGMAX_ROWS) ? (TIE_CAP + 1) : min(s_nt, (uint32_t)TIE_CAP + 1);
     if (threadIdx.x < 2 * min(nt, (uint32_t)TIE_CAP)) st->tied[threadIdx.x] = s_tied[threadIdx.x];
+    if (nt > 1) {  // tie: first window, positions ascending per thread
+        const uint64_t n = st->n[par];
+        const uint32_t hi = (uint32_t)min((uint64_t)TIE_WINDOW0, n);
+        for (uint32_t p = threadIdx.x; p < hi && (uint64_t)p + 1 < n; p += 1024) {
+            const uint32_t w1 = ids[p + 1];
+            if (w1 & FLAG) continue;
+            if (tie_hit(s_tied, nt, M, mat, stride, ids[p] & IDMASK, w1)) {
+                atomicMin(&s_first, p);
+                break;
+            }
+        }
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         st->count = M;
         st->ntied = nt;
-        st->found = (nt == 1);
-        st->a = s_tied[0];
-        st->b = s_tied[1];
         st->firstpos = NOPOS;
+        if (nt == 1) {
+            st->found = 1;
+            st->a = s_tied[0];
+            st->b = s_tied[1];
+        } else if (s_first != 0xFFFFFFFFu) {
+            st->found = 1;
+            st->a = (int32_t)(ids[s_first] & IDMASK);
+            st->b = (int32_t)ids[s_first + 1];
+        } else {
+            st->found = 0;
+        }
     }
 }
 
-// Tie-break (F3): the winner among the pairs tied at the maximum is the one
-// whose first occurrence is earliest, i.e. the pair found at the FIRST position
-// of the stream that holds any tied pair.  Searched over growing windows; every
-// launch is a no-op unless a tie exists and earlier windows found nothing.
+// Tie-break beyond the first window.  The grid sweeps the stream front to back
+// (each sweep step covers gridDim*256 consecutive positions), so a block stops
+// as soon as an earlier position has been reported.  No-op unless a tie is
+// still unresolved.
 __global__ void __launch_bounds__(256)
 k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
-           const uint32_t *__restrict__ mat, uint32_t stride, uint64_t lo, uint64_t hi) {
+           const uint32_t *__restrict__ mat, uint32_t stride, uint64_t lo) {
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ uint32_t s_go;
-    if (threadIdx.x == 0)
-        s_go = (st->status == 0 && st->found == 0 &&
-                __atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) == NOPOS);
+    if (threadIdx.x == 0) s_go = (st->status == 0 && st->found == 0);
     __syncthreads();
     if (!s_go) return;
     const uint32_t nt = st->ntied;
@@ -286,46 +322,46 @@ k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
     if (nt <= TIE_CAP && threadIdx.x < 2 * nt) s_tied[threadIdx.x] = st->tied[threadIdx.x];
     __syncthreads();
     const uint64_t n = st->n[par];
-    if (hi > n) hi = n;
     const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p + 1 < n && p < hi;
-         p += total) {
+    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p + 1 < n; p += total) {
+        if (__atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) < p) break;
         const uint32_t w1 = ids[p + 1];
         if (w1 & FLAG) continue;
-        const uint32_t a = ids[p] & IDMASK;
-        bool hit = false;
-        if (nt <= TIE_CAP) {
-            for (uint32_t t = 0; t < nt; t++)
-                hit |= (s_tied[2 * t] == (int32_t)a) & (s_tied[2 * t + 1] == (int32_t)w1);
-        } else {
-            hit = mat[(size_t)a * stride + w1] == M;
-        }
-        if (hit) {
+        if (tie_hit(s_tied, nt, M, mat, stride, ids[p] & IDMASK, w1)) {
             atomicMin(&st->firstpos, (unsigned long long)p);
             break;  // later positions of this thread cannot be earlier
         }
     }
 }
 
-__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st, IterRec *rec, int iter,
-                           uint32_t *dirty_n) {
+// The pair to merge as every kernel after K2 sees it: decided by k_select, or
+// the pair found at the earliest tied position by k_tiebreak.
+__device__ __forceinline__ bool resolved_pair(const DevState *st, const uint32_t *__restrict__ ids,
+                                              uint32_t &a, uint32_t &b) {
+    if (st->found) {
+        a = (uint32_t)st->a;
+        b = (uint32_t)st->b;
+        return true;
+    }
+    const unsigned long long p = st->firstpos;
+    if (p == NOPOS) return false;
+    a = ids[p] & IDMASK;
+    b = ids[p + 1];
+    return true;
+}
+
+// single-step API (bpe_argmax): make the decision final in st
+__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (dirty_n) *dirty_n = 0;
     if (st->status == 0 && !st->found) {
-        const unsigned long long p = st->firstpos;
-        if (p == NOPOS) {
+        uint32_t a, b;
+        if (!resolved_pair(st, ids, a, b)) {
             st->status = ST_INTERNAL;  // a tie was reported but no tied pair is in the stream
         } else {
-            st->a = (int32_t)(ids[p] & IDMASK);
-            st->b = (int32_t)ids[p + 1];
+            st->a = (int32_t)a;
+            st->b = (int32_t)b;
             st->found = 1;
         }
-    }
-    if (rec) {
-        rec[iter].a = st->a;
-        rec[iter].b = st->b;
-        rec[iter].count = st->count;
-        rec[iter].status = st->status;
     }
 }
 
@@ -445,27 +481,21 @@ __device__ __forceinline__ uint32_t group_mbits(const Tile &t, int j, uint32_t s
     return mb;
 }
 
-// pass 1: per-tile summary, as a function of the unknown carry s:
+// Per-tile summary, as a function of the unknown carry s (packed in 64 bits):
 //   M0      sites in the tile for s = 0
 //   Podd    length of the all-ones prefix of r is odd   (M1 = M0 - Podd)
 //   allones r is 1 on the whole tile                    (o1 = !o0, else o1 = o0)
 //   o0      m[last] for s = 0 (carry into the next tile)
-__global__ void __launch_bounds__(MT)
-k_merge_count(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
-              uint64_t *__restrict__ tsum) {
-    __shared__ int s_wave[MT / 64];
-    __shared__ uint32_t s_cnt[MT / 64];
-    __shared__ int s_fz[MT / 64];
-    __shared__ uint32_t s_o0;
-    if (st->status) return;
-    const uint64_t n = st->n[par];
-    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
-    if (tile_base >= n) return;
-    const int len = (int)min((uint64_t)TILE, n - tile_base);
-    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
-    if (threadIdx.x == 0) s_o0 = 0;
-    Tile t;
-    tile_load(t, ids, n, tile_base, a, b, s_wave);  // contains a __syncthreads
+// Returned to every thread of the workgroup.
+struct SummaryLds {
+    uint32_t cnt[MT / 64];
+    int fz[MT / 64];
+    uint32_t o0;
+    unsigned long long packed;
+};
+__device__ __forceinline__ uint64_t tile_summary(const Tile &t, int len, SummaryLds &L) {
+    if (threadIdx.x == 0) L.o0 = 0;
+    __syncthreads();
     uint32_t cnt = 0;
     int fz = 0x7fffffff;
     const int gb0 = wave_id() * WAVE_SPAN + lane_id() * 4;
@@ -477,27 +507,47 @@ k_merge_count(const uint32_t *__restrict__ ids, const DevState *__restrict__ st,
         const uint32_t z = (~t.rb[j]) & 0xFu;
         if (z) fz = min(fz, gb0 + j * 256 + (__ffs((int)z) - 1));
         const int q0 = gb0 + j * 256;
-        if (len - 1 >= q0 && len - 1 < q0 + 4) s_o0 = (mb >> (len - 1 - q0)) & 1u;
+        if (len - 1 >= q0 && len - 1 < q0 + 4) L.o0 = (mb >> (len - 1 - q0)) & 1u;
     }
     cnt = wave_sum_u32(cnt);
     fz = wave_min_i32(fz);
     if (lane_id() == 0) {
-        s_cnt[wave_id()] = cnt;
-        s_fz[wave_id()] = fz;
+        L.cnt[wave_id()] = cnt;
+        L.fz[wave_id()] = fz;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t M0 = 0;
         int F = 0x7fffffff;
         for (int w = 0; w < MT / 64; w++) {
-            M0 += s_cnt[w];
-            F = min(F, s_fz[w]);
+            M0 += L.cnt[w];
+            F = min(F, L.fz[w]);
         }
         const int P = min(F, len);
-        const uint64_t podd = (uint64_t)(P & 1);
-        const uint64_t allones = (uint64_t)(F >= len);
-        tsum[blockIdx.x] = (uint64_t)M0 | (podd << 32) | (allones << 33) | ((uint64_t)s_o0 << 34);
+        L.packed = (uint64_t)M0 | ((uint64_t)(P & 1) << 32) | ((uint64_t)(F >= len) << 33) |
+                   ((uint64_t)L.o0 << 34);
     }
+    __syncthreads();
+    return L.packed;
+}
+
+// pass 1 of the three-pass merge
+__global__ void __launch_bounds__(MT)
+k_merge_count(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+              uint64_t *__restrict__ tsum) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ SummaryLds s_sum;
+    if (st->status) return;
+    const uint64_t n = st->n[par];
+    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
+    if (tile_base >= n) return;
+    const int len = (int)min((uint64_t)TILE, n - tile_base);
+    uint32_t a, b;
+    if (!resolved_pair(st, ids, a, b)) return;  // k_tile_scan raises ST_INTERNAL
+    Tile t;
+    tile_load(t, ids, n, tile_base, a, b, s_wave);  // contains a __syncthreads
+    const uint64_t w = tile_summary(t, len, s_sum);
+    if (threadIdx.x == 0) tsum[blockIdx.x] = w;
 }
 
 // pass 2: one workgroup turns the tile summaries into (carry s, output offset)
@@ -534,9 +584,35 @@ __device__ __forceinline__ void tile_step(uint64_t w, uint32_t len, uint32_t s,
 
 __global__ void __launch_bounds__(1024)
 k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__restrict__ tile_off,
-            uint8_t *__restrict__ tile_sin, DevState *st, int par, IterRec *rec, int iter) {
+            uint8_t *__restrict__ tile_sin, DevState *st, int par, IterRec *rec, int iter,
+            const uint32_t *__restrict__ ids, uint32_t *dirty_n) {
     __shared__ TS s_w[16];
-    if (st->status) {
+    __shared__ uint32_t s_status;
+    if (threadIdx.x == 0) {
+        // make the pair decision final (k_select / k_tiebreak) and report it
+        if (dirty_n) *dirty_n = 0;
+        if (st->status == 0 && !st->found) {
+            uint32_t a, b;
+            if (resolved_pair(st, ids, a, b)) {
+                st->a = (int32_t)a;
+                st->b = (int32_t)b;
+                st->found = 1;
+            } else {
+                st->status = ST_INTERNAL;
+            }
+        }
+        st->fin_a = st->a;
+        st->fin_b = st->b;
+        s_status = st->status;
+        if (rec) {
+            rec[iter].a = st->a;
+            rec[iter].b = st->b;
+            rec[iter].count = st->count;
+            rec[iter].status = st->status;
+        }
+    }
+    __syncthreads();
+    if (s_status) {
         if (threadIdx.x == 0 && rec) {
             rec[iter].new_len = st->n[par];
             __threadfence_system();
@@ -601,8 +677,9 @@ k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__rest
     }
 }
 
-// pass 3: rewrite.  kept[p] = !m[p-1]; a site start emits the new id (and keeps
-// the chunk-start flag of its first element).
+// Rewrite of one tile.  kept[p] = !m[p-1]; a site start emits the new id (and
+// keeps the chunk-start flag of its first element).  dst = where the tile's
+// first kept id goes.
 //
 // DELTA: the same pass also records how the pair table changes (SURVEY.md N3,
 // done inside the full streaming pass).  Every old pair with a merged element
@@ -614,21 +691,10 @@ k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__rest
 // Each destroyed pair is charged to its left element, each created pair to its
 // left output element, so nothing is counted twice.
 template <bool DELTA>
-__global__ void __launch_bounds__(MT)
-k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                const DevState *__restrict__ st, int par, const uint64_t *__restrict__ tile_off,
-                const uint8_t *__restrict__ tile_sin, uint32_t newid, uint32_t *__restrict__ delta,
-                uint32_t vcap) {
-    __shared__ int s_wave[MT / 64];
-    __shared__ uint32_t s_wsum[MT / 64];
-    if (st->status) return;
-    const uint64_t n = st->n[par];
-    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
-    if (tile_base >= n) return;
-    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
-    const uint32_t s = tile_sin[blockIdx.x];
-    Tile t;
-    tile_load(t, in, n, tile_base, a, b, s_wave);
+__device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t a, uint32_t b,
+                                             uint32_t newid, uint32_t *__restrict__ dst_tile,
+                                             uint32_t *s_wsum, uint32_t *__restrict__ delta,
+                                             uint32_t vcap) {
     const int lane = lane_id(), wave = wave_id();
     uint32_t mb[MJ], mp[MJ], kb[MJ], ex[MJ];
     uint32_t carry = 0;
@@ -653,7 +719,7 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     __syncthreads();
     uint32_t wbase = 0;
     for (int w = 0; w < wave; w++) wbase += s_wsum[w];
-    uint32_t *dst = out + tile_off[blockIdx.x] + wbase;
+    uint32_t *dst = dst_tile + wbase;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         uint32_t o = ex[j];
@@ -669,6 +735,14 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
         // m bits and words of the two elements after my group: from the next
         // lane, the next stripe, or (end of the wave) recomputed from the tail.
         const uint32_t t0 = t.tail[0], t1 = t.tail[1], t2 = t.tail[2];
+        // most waves are far from any site: skip the whole section for them
+        uint32_t near = 0;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) near |= mb[j] | mp[j];
+        near |= (uint32_t)((((t0 & IDMASK) == a) & (t1 == b)) | (((t1 & IDMASK) == a) & (t2 == b)));
+        if (!__any(near != 0)) return;
+        // same-address atomics serialise (~11 ns each): spread them over replicas
+        delta += (size_t)(blockIdx.x & (DELTA_REPL - 1)) * 4 * vcap;
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             const uint32_t nb_m = (uint32_t)__shfl((int)mb[j], (lane + 1) & 63);
@@ -718,6 +792,196 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     }
 }
 
+// pass 3 of the three-pass merge
+template <bool DELTA>
+__global__ void __launch_bounds__(MT)
+k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                const DevState *__restrict__ st, int par, const uint64_t *__restrict__ tile_off,
+                const uint8_t *__restrict__ tile_sin, uint32_t newid, uint32_t *__restrict__ delta,
+                uint32_t vcap) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ uint32_t s_wsum[MT / 64];
+    if (st->status) return;
+    const uint64_t n = st->n[par];
+    const uint64_t tile_base = (uint64_t)blockIdx.x * TILE;
+    if (tile_base >= n) return;
+    const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
+    Tile t;
+    tile_load(t, in, n, tile_base, a, b, s_wave);
+    tile_rewrite<DELTA>(t, tile_sin[blockIdx.x], a, b, newid, out + tile_off[blockIdx.x], s_wsum,
+                        delta, vcap);
+}
+
+// ---------------------------------------------------------------------------
+// Single-pass merge: summary, carry/offset resolution and rewrite in ONE sweep
+// over the ids (reads 4N, writes 4N' -- the three-pass form reads 8N).
+//
+// Chained scan with decoupled look-back.  Tile t publishes its transducer
+// summary ("aggregate") as soon as it has read its ids, then wave 0 looks back
+// over the descriptors of tiles t-1, t-2, ... 64 at a time: aggregates are
+// composed until a tile is found whose inclusive prefix is already known.
+// Descriptors are single 8-byte words written/read with agent-scope relaxed
+// atomics (sc1: bypass the non-coherent per-CU L1 and per-XCD L2), so the data
+// IS the flag and no fence is needed (cdna_hip_programming.md G16, recipe R2).
+// They carry an epoch, so they never need clearing between launches.
+//   bits 63..62 status (1 aggregate, 2 inclusive prefix)   bits 61..40 epoch
+//   aggregate: bits 0..12 k0, 13..25 k1, 26 o0, 27 o1   (kept ids / carry-out per carry-in)
+//   prefix   : bits 0..35 inclusive kept count, bit 36 carry-out
+// Progress: tiles are workgroup ids, dispatched in order, so every tile a
+// workgroup waits on is resident or done; the spin is bounded anyway and raises
+// ST_LOOKBACK instead of hanging.
+__device__ __forceinline__ unsigned long long desc_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void desc_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool DELTA>
+__global__ void __launch_bounds__(MT)
+k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, DevState *st, int par,
+                 unsigned long long *__restrict__ desc, uint32_t epoch, uint32_t newid,
+                 uint32_t *__restrict__ delta, uint32_t vcap, IterRec *rec, int iter,
+                 uint32_t *dirty_n) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ uint32_t s_wsum[MT / 64];
+    __shared__ SummaryLds s_sum;
+    __shared__ unsigned long long s_excl;
+    __shared__ uint32_t s_sin, s_fail;
+    const uint64_t n = st->n[par];
+    const uint64_t tile = blockIdx.x;
+    const uint64_t tile_base = tile * TILE;
+    uint32_t a = 0, b = 0;
+    const bool ok = (st->status == 0) && resolved_pair(st, in, a, b);
+    if (!ok) {
+        // nothing to merge: tile 0 reports (empty stats, or a tie nobody resolved)
+        if (tile == 0 && threadIdx.x == 0) {
+            if (st->status == 0) st->status = ST_INTERNAL;
+            if (dirty_n) *dirty_n = 0;
+            if (rec) {
+                rec[iter].a = st->a;
+                rec[iter].b = st->b;
+                rec[iter].count = st->count;
+                rec[iter].status = st->status;
+                rec[iter].new_len = n;
+                __threadfence_system();
+                rec[iter].seq = (unsigned long long)iter + 1;
+            }
+        }
+        return;
+    }
+    if (tile_base >= n) return;
+    const int len = (int)min((uint64_t)TILE, n - tile_base);
+    Tile t;
+    tile_load(t, in, n, tile_base, a, b, s_wave);
+    const uint64_t w = tile_summary(t, len, s_sum);
+    // the tile as a transducer
+    unsigned long long k0 = 0, k1 = 0;
+    uint32_t o0 = 0, o1 = 1;
+    tile_step(w, (uint32_t)len, 0u, k0, o0);
+    tile_step(w, (uint32_t)len, 1u, k1, o1);
+    const unsigned long long tag = ((unsigned long long)(epoch & 0x3FFFFFu)) << 40;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned long long excl = 0;
+        uint32_t sin = 0, fail = 0;
+        if (tile > 0) {
+            if (lane == 0)
+                desc_store(&desc[tile], (1ull << 62) | tag | k0 | (k1 << 13) |
+                                            ((unsigned long long)o0 << 26) | ((unsigned long long)o1 << 27));
+            TS acc;  // composition of the tiles between the window and this one
+            acc.k0 = acc.k1 = 0;
+            acc.o = 2u;
+            long long base = (long long)tile - 1;  // lane 0 looks at tile `base`
+            for (;;) {
+                const long long idx = base - lane;
+                unsigned long long d = 0;
+                uint32_t stt = 0;
+                unsigned long long pmask = 0;
+                uint32_t spins = 0;
+                for (;;) {
+                    if (idx >= 0) {
+                        d = desc_load(&desc[idx]);
+                        stt = ((d >> 40) & 0x3FFFFFu) == (epoch & 0x3FFFFFu) ? (uint32_t)(d >> 62) : 0u;
+                    } else {  // before the stream: prefix 0, carry 0
+                        d = 0;
+                        stt = 2;
+                    }
+                    pmask = __ballot(stt == 2);
+                    const int np = pmask ? (__ffsll((long long)pmask) - 1) : 63;
+                    const unsigned long long waiting = __ballot(stt == 0 && lane <= np);
+                    if (!waiting) break;
+                    if (++spins > LOOKBACK_SPINS) {
+                        fail = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (fail) break;
+                const int np = pmask ? (__ffsll((long long)pmask) - 1) : 64;
+                TS v;  // this lane's tile as a transducer; identity beyond the nearest prefix
+                if (lane > np) {
+                    v.k0 = v.k1 = 0;
+                    v.o = 2u;
+                } else if (stt == 2) {
+                    v.k0 = v.k1 = d & 0xFFFFFFFFFull;
+                    v.o = ((d >> 36) & 1u) ? 3u : 0u;
+                } else {
+                    v.k0 = d & 0x1FFFu;
+                    v.k1 = (d >> 13) & 0x1FFFu;
+                    v.o = (uint32_t)((d >> 26) & 3u);
+                }
+                // ordered reduction: far tiles first, lane 0 (nearest) last
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    TS far;
+                    far.k0 = __shfl_down(v.k0, sft);
+                    far.k1 = __shfl_down(v.k1, sft);
+                    far.o = (uint32_t)__shfl_down((int)v.o, sft);
+                    if (lane + sft < 64) v = ts_then(far, v);
+                }
+                TS win;
+                win.k0 = __shfl(v.k0, 0);
+                win.k1 = __shfl(v.k1, 0);
+                win.o = (uint32_t)__shfl((int)v.o, 0);
+                acc = ts_then(win, acc);
+                if (pmask) break;
+                base -= 64;
+            }
+            excl = acc.k0;  // the chain starts from a prefix: input-independent
+            sin = acc.o & 1u;
+        }
+        if (lane == 0) {
+            const unsigned long long incl = excl + (sin ? k1 : k0);
+            const uint32_t sout = sin ? o1 : o0;
+            desc_store(&desc[tile], (2ull << 62) | tag | (incl & 0xFFFFFFFFFull) |
+                                        ((unsigned long long)sout << 36));
+            s_excl = excl;
+            s_sin = sin;
+            s_fail = fail;
+            if (fail) atomicExch(&st->status, ST_LOOKBACK);
+            if (tile_base + TILE >= n) {  // last tile: totals, report, final pair
+                st->n[par ^ 1] = incl;
+                st->fin_a = (int32_t)a;
+                st->fin_b = (int32_t)b;
+                if (dirty_n) *dirty_n = 0;
+                if (rec) {
+                    rec[iter].a = (int32_t)a;
+                    rec[iter].b = (int32_t)b;
+                    rec[iter].count = st->count;
+                    rec[iter].status = fail ? ST_LOOKBACK : 0u;
+                    rec[iter].new_len = incl;
+                    __threadfence_system();
+                    rec[iter].seq = (unsigned long long)iter + 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) return;
+    tile_rewrite<DELTA>(t, s_sin, a, b, newid, out + s_excl, s_wsum, delta, vcap);
+}
+
 // Apply the four delta vectors to the dense table and keep rowmax[] current.
 // Thread t owns token t: column a, row b, the new column Z and the new row Z.
 // Rows whose maximum may have dropped are queued for k_rowmax_list; for every
@@ -729,13 +993,22 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     if (st->status) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > Z) return;
-    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
-    const uint32_t dl = delta[t], dr = delta[vcap + t], il = delta[2 * (size_t)vcap + t],
-                   ir = delta[3 * (size_t)vcap + t];
-    delta[t] = 0;
-    delta[vcap + t] = 0;
-    delta[2 * (size_t)vcap + t] = 0;
-    delta[3 * (size_t)vcap + t] = 0;
+    const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
+    uint32_t dl = 0, dr = 0, il = 0, ir = 0;
+#pragma unroll 4
+    for (int r = 0; r < DELTA_REPL; r++) {
+        uint32_t *d = delta + (size_t)r * 4 * vcap;
+        const uint32_t v0 = d[t], v1 = d[vcap + t], v2 = d[2 * (size_t)vcap + t],
+                       v3 = d[3 * (size_t)vcap + t];
+        if (v0) d[t] = 0;
+        if (v1) d[vcap + t] = 0;
+        if (v2) d[2 * (size_t)vcap + t] = 0;
+        if (v3) d[3 * (size_t)vcap + t] = 0;
+        dl += v0;
+        dr += v1;
+        il += v2;
+        ir += v3;
+    }
     bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
     if (dl) {
         const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], dl);
@@ -759,7 +1032,7 @@ k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
               const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
     __shared__ uint32_t s_red[4];
     if (st->status) return;
-    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     const uint32_t nd = *dirty_n;
     for (uint32_t i = blockIdx.x; i < nd; i += gridDim.x) {
         const uint32_t x = dirty_list[i];
@@ -847,6 +1120,7 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->ntied = 0;
     st->found = 0;
     st->status = 0;
+    st->fin_a = st->fin_b = 0;
 }
 
 }  // namespace bpe

@@ -75,9 +75,11 @@ def test_get_stats_argmax_merge_vs_oracle(engine, k, n):
                 assert engine.read_chunk_starts().tolist() == exp
 
 
-def test_long_runs_cross_tile_boundaries(engine):
+@pytest.mark.parametrize("mimpl", [0, 1])
+def test_long_runs_cross_tile_boundaries(engine, mimpl):
     # a == b merges with runs spanning many 4096-id tiles, odd/even lengths
-    for n in (4095, 4096, 4097, 12289, 100001):
+    engine.set_option("merge", mimpl)
+    for n in (4095, 4096, 4097, 12289, 100001, 64 * 4096 + 3, 300 * 4096):
         ids = np.full(n, 7, np.int32)
         engine.load_ids(ids)
         engine.merge((7, 7), 300)
@@ -88,6 +90,13 @@ def test_long_runs_cross_tile_boundaries(engine):
     engine.load_ids(ids)
     engine.merge((7, 7), 300)
     assert np.array_equal(engine.read_ids(), oracle.merge(ids, (7, 7), 300))
+    # a != b over many tiles, sites straddling tile boundaries (period 3 vs tile 4096)
+    ids = np.tile(np.array([1, 2, 3], np.int32), 200000)
+    for pair in ((1, 2), (3, 1), (2, 3)):
+        engine.load_ids(ids)
+        engine.merge(pair, 300)
+        assert np.array_equal(engine.read_ids(), oracle.merge(ids, pair, 300))
+    engine.set_option("merge", 1)
 
 
 # ---------------------------------------------------------------------------
@@ -106,13 +115,14 @@ def test_train_golden_cases(golden, engine, native):
         assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,mimpl", [(0, 0), (1, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
                                     (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
-def test_train_tie_heavy_vs_oracle(engine, mode, k, n, nm):
+def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, k, n, nm):
     rng = random.Random(k * 1000 + n)
     data = bytes(97 + rng.randrange(k) for _ in range(n))
     engine.set_option("mode", mode)
+    engine.set_option("merge", mimpl)
     try:
         engine.load_bytes(data)
         exp = oracle.train(data, nm, raise_on_empty=False)
@@ -132,11 +142,12 @@ def test_train_tie_heavy_vs_oracle(engine, mode, k, n, nm):
         assert np.array_equal(engine.read_ids(), ids)
     finally:
         engine.set_option("mode", 1)
+        engine.set_option("merge", 1)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode,mimpl", [(0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_train_synth_2mb_vs_oracle(engine, native, kind, mode):
+def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl):
     text = native.synth_text(2_000_000, 11)
     if kind == "basic":
         data, offs = text, None
@@ -145,6 +156,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode):
     nm = 400
     exp = oracle.train(data, nm, offs)
     engine.set_option("mode", mode)
+    engine.set_option("merge", mimpl)
     try:
         engine.load_bytes(data, offs)
         res = engine.train(nm)
@@ -158,6 +170,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode):
         assert engine.train(nm)["pairs"] == exp[0]
     finally:
         engine.set_option("mode", 1)
+        engine.set_option("merge", 1)
         engine.set_option("depth", 8)
 
 
