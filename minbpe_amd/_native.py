@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbpe_hip.so")
+LIB_PATH = os.environ.get("MINBPE_AMD_LIB", os.path.join(_HERE, "lib", "libbpe_hip.so"))
 
 BPE_OK = 0
 BPE_E_HIP = -1

@@ -67,13 +67,16 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
-    int merge_impl = 1;  // 0 three-pass | 1 single-pass (decoupled look-back)
-    unsigned long long *d_desc = nullptr;  // look-back descriptors, one per tile
+    int merge_impl = 0;  // 0 three-pass | 1 single-pass (two-level decoupled look-back)
+    unsigned long long *d_desc = nullptr;   // look-back descriptors, one per tile
+    unsigned long long *d_gdesc = nullptr;  // ... and one per group of 64 tiles
     uint64_t cap_desc = 0;
     uint32_t epoch = 0;
+    uint32_t lb_tune = 1;  // bits 0..7: s_sleep(8) units between polls; bit 8: measurement-only 'no wait'
 
     int mode = 1;     // 0 recount | 1 delta
-    int profile = 0;  // hipEvents around hot kernels
+    int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
+    bool prof_active = false;
     int k1 = 1;       // 0 simple | 1 LDS-cached pair count
 
     std::vector<ProfEv> prof_open;
@@ -140,7 +143,9 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_tile_off, nt));
         TRY(dev_realloc(c, c->d_tile_sin, nt));
         TRY(dev_realloc(c, c->d_desc, nt));
+        TRY(dev_realloc(c, c->d_gdesc, nt / 64 + 2));
         HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (nt / 64 + 2) * sizeof(unsigned long long), c->stream));
         c->cap_tiles = nt;
     }
     return BPE_OK;
@@ -178,7 +183,10 @@ int ensure_rec(bpe_ctx *c, int n) {
 
 // ---- profiling --------------------------------------------------------------
 int prof_begin(bpe_ctx *c, int kind, uint64_t bytes) {
-    if (!c->profile) return BPE_OK;
+    // level 1: only the dominant kernel class (merge) -- two event records per
+    // iteration; level 2: every class (adds marker packets between all kernels)
+    c->prof_active = c->profile >= 2 || (c->profile == 1 && kind == BPE_PROF_MERGE);
+    if (!c->prof_active) return BPE_OK;
     ProfEv ev;
     ev.kind = kind;
     ev.bytes = bytes;
@@ -195,7 +203,8 @@ int prof_begin(bpe_ctx *c, int kind, uint64_t bytes) {
     return BPE_OK;
 }
 int prof_end(bpe_ctx *c) {
-    if (!c->profile) return BPE_OK;
+    if (!c->prof_active) return BPE_OK;
+    c->prof_active = false;
     HIPCHK(c, hipEventRecord(c->prof_open.back().e1, c->stream));
     return BPE_OK;
 }
@@ -309,19 +318,21 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
     const uint64_t nt = ntiles_of(n);
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->merge_impl == 1) {
-        if ((++c->epoch & 0x3FFFFFu) == 0) {  // tag wrapped: retire every old descriptor
+        if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
             HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
             c->epoch++;
         }
         const unsigned grid = (unsigned)std::max<uint64_t>(nt, 1);
         if (with_delta)
             hipLaunchKernelGGL(k_merge_lookback<true>, dim3(grid), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
-                               c->epoch, newid, c->d_delta, c->vcap, rec, iter, c->d_dirty_n);
+                               c->d_gdesc, c->epoch, newid, c->d_delta, c->vcap, rec, iter, c->d_dirty_n, c->lb_tune);
         else
             hipLaunchKernelGGL(k_merge_lookback<false>, dim3(grid), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
-                               c->epoch, newid, (uint32_t *)nullptr, c->vcap, rec, iter, c->d_dirty_n);
+                               c->d_gdesc, c->epoch, newid, (uint32_t *)nullptr, c->vcap, rec, iter, c->d_dirty_n,
+                               c->lb_tune);
         LAUNCHCHK(c, "k_merge_lookback");
     } else {
     if (nt) {
@@ -419,7 +430,7 @@ void bpe_destroy(bpe_ctx *c) {
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
                     c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
-                    c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc};
+                    c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -443,12 +454,15 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         if (value != 0 && value != 1) return fail(c, BPE_E_ARG, "mode must be 0 or 1");
         c->mode = (int)value;
     } else if (!strcmp(name, "profile")) {
-        c->profile = value != 0;
+        if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "profile must be 0, 1 or 2");
+        c->profile = (int)value;
     } else if (!strcmp(name, "k1")) {
         c->k1 = (int)value;
     } else if (!strcmp(name, "merge")) {
         if (value != 0 && value != 1) return fail(c, BPE_E_ARG, "merge must be 0 or 1");
         c->merge_impl = (int)value;
+    } else if (!strcmp(name, "lb_tune")) {
+        c->lb_tune = (uint32_t)value;
     } else if (!strcmp(name, "depth")) {
         if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
         c->depth = (int)value;
@@ -622,10 +636,12 @@ int bpe_merge(bpe_ctx *c, int32_t a, int32_t b, int32_t idx, uint64_t *new_len) 
     TRY(ensure_table(c, (uint32_t)std::max(idx, std::max(a, b)) + 1));
     hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->d_st, a, b);
     LAUNCHCHK(c, "k_set_pair");
+    const uint64_t n_before = c->n;
     TRY(launch_merge(c, (uint32_t)idx, 0, nullptr, false));
     DevState st;
     TRY(read_state(c, &st));
     c->n = st.n[c->par];
+    if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (n_before + c->n);
     c->vcur = std::max<uint32_t>(c->vcur, (uint32_t)idx + 1);
     if (new_len) *new_len = c->n;
     return BPE_OK;

@@ -14,7 +14,10 @@ constexpr unsigned long long NOPOS = ~0ull;
 
 // merge tile geometry: 4 waves x MJ stripes x 64 lanes x 4 ids
 constexpr int MT = 256;
-constexpr int MJ = 4;
+#ifndef BPE_MJ
+#define BPE_MJ 4
+#endif
+constexpr int MJ = BPE_MJ;  // <= 8: a group of 64 tiles must fit 20-bit aggregates
 constexpr int WAVE_SPAN = MJ * 256;
 constexpr int TILE = (MT / 64) * WAVE_SPAN;  // 4096 ids = 16 KiB
 
@@ -28,6 +31,7 @@ constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select itself searche
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
 
 constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
+constexpr uint32_t EPOCH_MASK = 0xFFFFFu;  // look-back descriptors carry a 20-bit launch tag
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile
 
 // one per ctx, in device memory
