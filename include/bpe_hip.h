@@ -92,6 +92,19 @@ int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
               uint64_t *counts_out, double *iter_ms_out, uint64_t *len_out,
               int32_t *n_done);
 
+/* ---- encode ----------------------------------------------------------------- */
+/* _encode_chunk for a batch of chunks (regex.py:92-121; basic.py:57-74 when
+ * n_chunks == 1).  merges: 2*M int32, in PRIORITY order (the reference's
+ * `min(stats, key=merges.get)` picks the lowest merges[pair] value; pass the
+ * pairs sorted by that value); the pair at position r merges to id merge_ids[r]
+ * (NULL: 256 + r).  ids_out needs n entries; out_offsets n_chunks+1 entries
+ * (token offset of each chunk in ids_out).  Invalidates the ids loaded by
+ * bpe_load_bytes/bpe_load_ids (buffers are shared). */
+int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                     const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                     uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
+                     uint64_t *n_out);
+
 /* ---- measurement ------------------------------------------------------------ */
 #define BPE_PROF_WIDEN 0
 #define BPE_PROF_PAIR_COUNT 1

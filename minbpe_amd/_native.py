@@ -49,6 +49,7 @@ _SIGS = {
     "bpe_read_ids": (C.c_int, [_p, _p, _u64]),
     "bpe_read_chunk_starts": (C.c_int, [_p, _p, _u64, C.POINTER(_u64)]),
     "bpe_train": (C.c_int, [_p, _i32, _p, _p, _p, _p, C.POINTER(_i32)]),
+    "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
     "bpe_synth_text": (C.c_int, [_p, _u64, _u64]),
@@ -215,6 +216,24 @@ class Engine:
             iter_ms=None if ms is None else ms[:d].copy(), n_done=d)
         self._check(rc)
         return self.last_train
+
+    # -- encoding ----------------------------------------------------------------------
+    def encode_batch(self, pairs, merge_ids, data, offsets=None):
+        """pairs: (M,2) int32 in priority order; merge_ids: (M,) int32 or None.
+        Returns (ids ndarray int32, out_offsets ndarray uint64 of n_chunks+1)."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        off, n_off = self._offsets(offsets)
+        n_chunks = n_off if off is not None else 1
+        pm = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1)
+        M = len(pm) // 2
+        mi = None if merge_ids is None else np.ascontiguousarray(merge_ids, dtype=np.int32)
+        out = np.empty(max(len(buf), 1), np.int32)
+        oo = np.zeros(n_chunks + 1, np.uint64)
+        n_out = _u64(0)
+        self._check(_lib.bpe_encode_batch(self._h, _ptr(pm) if M else None, _ptr(mi), M,
+                                          _ptr(buf) if len(buf) else None, len(buf), _ptr(off),
+                                          n_off, _ptr(out), _ptr(oo), C.byref(n_out)))
+        return out[:n_out.value], oo
 
     # -- measurement ----------------------------------------------------------------
     def prof_reset(self):

@@ -30,6 +30,11 @@ constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_selec
 constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select itself searches on a tie
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
 
+// encode: one chunk per lane, token lists in lane-private LDS columns
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_LMAX = 32;  // longer chunks take the stream-wide path
+constexpr int SCAN_TILE = 4096;
+
 constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
 constexpr uint32_t EPOCH_MASK = 0xFFFFFu;  // look-back descriptors carry a 20-bit launch tag
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile

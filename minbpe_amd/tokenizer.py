@@ -135,16 +135,25 @@ class Tokenizer:
     # -- device encoding of a batch of byte chunks ----------------------------------
     def _encode_chunks(self, chunks):
         """chunks: list[bytes] -> (ids ndarray, token start offset of each
-        non-empty chunk).  Applies the merges in ascending idx order, which is
-        what the reference's lowest-rank-first loop computes."""
+        non-empty chunk).  One device batch: K4 (bpe_encode_batch)."""
         data, offs = _concat_chunks(chunks)
         if not data:
             return np.empty(0, np.int32), np.empty(0, np.uint64)
-        eng = engine()
-        eng.load_bytes(data, offs)
-        for pair, idx in sorted(self.merges.items(), key=lambda kv: kv[1]):
-            eng.merge(pair, idx)
-        return eng.read_ids(), eng.read_chunk_starts()
+        pairs, mids = self._merge_table()
+        ids, out_off = engine().encode_batch(pairs, mids, data, offs)
+        return ids, out_off[:-1]
+
+    def _merge_table(self):
+        """merges as device arrays, ordered by priority = the dict's value
+        (`min(stats, key=merges.get)` in the reference, basic.py:64)."""
+        key = (id(self.merges), len(self.merges))
+        cached = getattr(self, "_mt_cache", None)
+        if cached is None or cached[0] != key:
+            items = sorted(self.merges.items(), key=lambda kv: kv[1])
+            pairs = np.array([p for p, _ in items], dtype=np.int32).reshape(-1, 2)
+            mids = np.array([i for _, i in items], dtype=np.int32)
+            self._mt_cache = (key, pairs, mids)
+        return self._mt_cache[1], self._mt_cache[2]
 
     # -- persistence (file formats of base.py:97-165, byte for byte) -----------------
     def save(self, file_prefix):

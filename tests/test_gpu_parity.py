@@ -245,3 +245,73 @@ def test_module_level_helpers():
     assert merge([1, 2, 3, 1, 2], (1, 2), 4) == [4, 3, 4]
     assert merge([7, 7, 7, 7, 7], (7, 7), 9) == [9, 9, 7]
     assert merge([], (1, 2), 4) == [] and get_stats([]) == {} and get_stats([3]) == {}
+
+
+# ---------------------------------------------------------------------------
+# K4: batched encode through the C-ABI
+
+def _train_pairs(native, n, nm, seed, kind):
+    text = native.synth_text(n, seed)
+    data, offs = (text, None) if kind == "basic" else split_chunks(text.decode())
+    return oracle.train(data, nm, offs)[0]
+
+
+@pytest.mark.parametrize("kind", ["basic", "regex"])
+def test_encode_batch_vs_oracle(engine, native, kind):
+    pairs = _train_pairs(native, 300_000, 600, 21, kind)
+    text = native.synth_text(150_000, 22)
+    data, offs = (text, None) if kind == "basic" else split_chunks(text.decode())
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    assert np.array_equal(ids, exp_ids)
+    assert np.array_equal(out_off, exp_off)
+
+
+def test_encode_batch_long_and_short_chunks_mixed(engine, native):
+    # chunk lengths around ENC_LMAX (32) and far beyond it, runs of one symbol, empty batch
+    pairs = _train_pairs(native, 200_000, 500, 23, "regex")
+    rng = np.random.default_rng(3)
+    words = []
+    base = native.synth_text(60_000, 24)
+    pos = 0
+    for L in [1, 2, 31, 32, 33, 34, 64, 65, 200, 5000, 3, 32, 33, 1, 40000, 7]:
+        words.append(base[pos:pos + L])
+        pos += L
+    words += [b"a" * 33, b"a" * 32, b"ab" * 40, b"z"]
+    data = b"".join(words)
+    offs = np.cumsum([0] + [len(w) for w in words[:-1]]).astype(np.uint64)
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    assert np.array_equal(ids, exp_ids)
+    assert np.array_equal(out_off, exp_off)
+    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, b"", None)
+    assert len(ids) == 0
+
+
+def test_encode_batch_custom_ids_and_no_merges(engine):
+    # merge ids need not be 256 + rank (GPT4Tokenizer: id = rank value)
+    pairs = np.array([[104, 105], [1000, 33]], np.int32)
+    mids = np.array([1000, 2000], np.int32)
+    ids, off = engine.encode_batch(pairs, mids, b"hi!hi!", np.array([0, 3], np.uint64))
+    assert ids.tolist() == [2000, 2000] and off.tolist() == [0, 1, 2]
+    ids, off = engine.encode_batch(np.zeros((0, 2), np.int32), None, b"abc", None)
+    assert ids.tolist() == [97, 98, 99] and off.tolist() == [0, 3]
+
+
+def test_encode_many_docs(engine, native):
+    # cfg5 in miniature: a batch of documents, regex-chunked, against the oracle
+    pairs = _train_pairs(native, 400_000, 1000, 31, "regex")
+    text = native.synth_text(1_000_000, 32).decode()
+    docs = [d for d in text.split("\n\n") if d]
+    assert len(docs) > 500
+    chunks = []
+    import regex as re
+    from minbpe_amd.tokenizer import GPT4_SPLIT_PATTERN
+    pat = re.compile(GPT4_SPLIT_PATTERN)
+    for d in docs:
+        chunks += [c.encode() for c in re.findall(pat, d)]
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    assert np.array_equal(ids, exp_ids) and np.array_equal(out_off, exp_off)
