@@ -50,34 +50,53 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dp = os.environ.get("BENCH_FORCE_DP") == "1"  # exercise the sharded path on one GPU
+    if world > 1 or force_dp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import minbpe_amd
     from minbpe_amd import Engine
 
     num_merges = args.vocab - 256
-    # BasicTokenizer's single stream does not shard ("replicas only"):
-    # with N > 1 each rank trains its own stream (different seed), weak scaling.
-    data = minbpe_amd.synth_text(args.bytes, args.seed + rank)
     eng = Engine(local_rank)
     if args.mode >= 0:
         eng.set_option("mode", args.mode)
     if "BPE_MERGE" in os.environ:  # experiments: 0 three-pass | 1 single-pass look-back
         eng.set_option("merge", int(os.environ["BPE_MERGE"]))
-    eng.load_bytes(data)  # H2D once, outside the timed region
+    if world == 1 and not force_dp:
+        # configs[1]: BasicTokenizer.train, one unchunked stream, one GPU
+        data = minbpe_amd.synth_text(args.bytes, args.seed)
+        eng.load_bytes(data)  # H2D once, outside the timed region
+        step = lambda: eng.train(num_merges)
+    else:
+        # BasicTokenizer's single stream does not shard; N > 1 runs the
+        # chunked (RegexTokenizer-style) training sharded by chunks, `bytes` per GPU
+        # (weak scaling), with the two per-merge all-reduces over RCCL.  Chunks are
+        # cut before every space/newline (a vectorised stand-in for the regex split,
+        # which runs at 5 MB/s on the host and is not part of the timed path).
+        import numpy as np
+        from minbpe_amd.dist import GpuShard, TorchComm, train_sharded
+        data = minbpe_amd.synth_text(args.bytes, args.seed + rank)
+        arr = np.frombuffer(data, dtype=np.uint8)
+        cut = np.flatnonzero((arr == 32) | (arr == 10)).astype(np.uint64)
+        offs = np.unique(np.concatenate([np.zeros(1, np.uint64), cut]))
+        eng.load_bytes(data, offs)
+        shard, comm = GpuShard(eng, local_rank), TorchComm()
+        step = lambda: train_sharded(shard, comm, num_merges)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        eng.train(num_merges)
+        step()
     # one untimed step with events around every kernel class: the breakdown
     eng.set_option("profile", 2)
     eng.prof_reset()
-    eng.train(num_merges)
+    step()
     breakdown = eng.prof_read()
     # timed steps: events only around the dominant kernel (two records per iteration)
     eng.set_option("profile", 1)
@@ -85,16 +104,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = eng.train(num_merges)
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.prof_read()
-    if world > 1:
+    if world > 1 or force_dp:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    merges_total = num_merges * args.steps * world
+    # sharded training is ONE job: it performs num_merges merges over world x bytes of text
+    merges_total = num_merges * args.steps
     value = merges_total / dt
 
     # dominant kernel class by device time -> roofline (timed live in the timed region)
@@ -120,7 +140,7 @@ def main():
     }
 
     cpu_baseline = None
-    if rank == 0 and args.cpu_iters > 0:
+    if rank == 0 and args.cpu_iters > 0 and world == 1:
         import oracle
         t0 = time.perf_counter()
         cp, _, _ = oracle.train(data, args.cpu_iters)
@@ -138,14 +158,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"BasicTokenizer.train, {args.bytes} B synthetic UTF-8 per GPU, "
+            "config": {"workload": (f"BasicTokenizer.train, {args.bytes} B synthetic UTF-8, " if world == 1 else
+                                    f"chunked (RegexTokenizer-style) train sharded over {world} GPUs, "
+                                    f"{args.bytes} B synthetic UTF-8 per GPU, ") +
                                    f"vocab {args.vocab} ({num_merges} merges), bit-exact vs oracle",
                        "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
-                       "parallelism": f"replicas x{world}" if world > 1 else "single"},
+                       "parallelism": f"dp{world} (chunk shards; per-merge all-reduce of tie key + table deltas)"
+                                      if world > 1 else "single"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, **extra,
         }))
     eng.close()
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

@@ -92,6 +92,36 @@ int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
               uint64_t *counts_out, double *iter_ms_out, uint64_t *len_out,
               int32_t *n_done);
 
+/* ---- data-parallel training over sharded chunks ------------------- */
+/* One ctx per rank; each rank bpe_load_bytes() its contiguous range of chunks.
+ * Every rank keeps a replica of the GLOBAL pair table; per iteration the host
+ * all-reduces two tiny device buffers (RCCL through torch.distributed, see
+ * minbpe_amd/dist.py) -- ids and the table never move:
+ *
+ *   bpe_dp_begin(num_merges, rank, nranks)   widen + local byte-pair counts
+ *   [all-reduce SUM   table   (int32 x 65536)]
+ *   bpe_dp_table_ready()
+ *   for i in range(num_merges):
+ *       bpe_dp_select(i)                     arg-max on the replica; local tie-break candidate
+ *       [all-reduce MIN   tiekey  (int64 x 2)]   lowest (rank, position) wins the tie (F3/F5)
+ *       bpe_dp_merge(i)                      merge locally, produce the 4 delta vectors
+ *       [all-reduce SUM   delta   (int32 x delta_count)]
+ *       bpe_dp_apply(i)                      fold them into the replica
+ *   bpe_dp_poll(i, ...) any time after bpe_dp_merge(i): the iteration's record
+ *   bpe_dp_end()
+ * All calls only enqueue work on the ctx's stream (bpe_set_stream) except
+ * bpe_dp_poll, which waits for the device to report iteration i. */
+int bpe_dp_begin(bpe_ctx *ctx, int32_t num_merges, int32_t rank, int32_t nranks);
+int bpe_dp_buffers(bpe_ctx *ctx, void **table, uint64_t *table_count, void **delta,
+                   uint64_t *delta_count, void **tiekey);
+int bpe_dp_table_ready(bpe_ctx *ctx);
+int bpe_dp_select(bpe_ctx *ctx, int32_t iter);
+int bpe_dp_merge(bpe_ctx *ctx, int32_t iter);
+int bpe_dp_apply(bpe_ctx *ctx, int32_t iter);
+int bpe_dp_poll(bpe_ctx *ctx, int32_t iter, int32_t *a, int32_t *b, uint64_t *count,
+                uint64_t *local_len, int32_t *status);
+int bpe_dp_end(bpe_ctx *ctx);
+
 /* ---- encode ----------------------------------------------------------------- */
 /* _encode_chunk for a batch of chunks (regex.py:92-121; basic.py:57-74 when
  * n_chunks == 1).  merges: 2*M int32, in PRIORITY order (the reference's

@@ -49,6 +49,16 @@ _SIGS = {
     "bpe_read_ids": (C.c_int, [_p, _p, _u64]),
     "bpe_read_chunk_starts": (C.c_int, [_p, _p, _u64, C.POINTER(_u64)]),
     "bpe_train": (C.c_int, [_p, _i32, _p, _p, _p, _p, C.POINTER(_i32)]),
+    "bpe_dp_begin": (C.c_int, [_p, _i32, _i32, _i32]),
+    "bpe_dp_buffers": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_u64), C.POINTER(_p), C.POINTER(_u64),
+                                 C.POINTER(_p)]),
+    "bpe_dp_table_ready": (C.c_int, [_p]),
+    "bpe_dp_select": (C.c_int, [_p, _i32]),
+    "bpe_dp_merge": (C.c_int, [_p, _i32]),
+    "bpe_dp_apply": (C.c_int, [_p, _i32]),
+    "bpe_dp_poll": (C.c_int, [_p, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64),
+                              C.POINTER(_u64), C.POINTER(_i32)]),
+    "bpe_dp_end": (C.c_int, [_p]),
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
@@ -216,6 +226,42 @@ class Engine:
             iter_ms=None if ms is None else ms[:d].copy(), n_done=d)
         self._check(rc)
         return self.last_train
+
+    # -- data-parallel stepping (minbpe_amd/dist.py drives these) ------------------------
+    def dp_begin(self, num_merges, rank, nranks):
+        self._check(_lib.bpe_dp_begin(self._h, num_merges, rank, nranks))
+
+    def dp_buffers(self):
+        """(table_ptr, table_count, delta_ptr, delta_count, tiekey_ptr): raw device
+        pointers of the three all-reduce payloads (int32, int32, int64 x 2)."""
+        t, d, k = _p(), _p(), _p()
+        tc, dc = _u64(0), _u64(0)
+        self._check(_lib.bpe_dp_buffers(self._h, C.byref(t), C.byref(tc), C.byref(d), C.byref(dc),
+                                        C.byref(k)))
+        return t.value, tc.value, d.value, dc.value, k.value
+
+    def dp_table_ready(self):
+        self._check(_lib.bpe_dp_table_ready(self._h))
+
+    def dp_select(self, i):
+        self._check(_lib.bpe_dp_select(self._h, i))
+
+    def dp_merge(self, i):
+        self._check(_lib.bpe_dp_merge(self._h, i))
+
+    def dp_apply(self, i):
+        self._check(_lib.bpe_dp_apply(self._h, i))
+
+    def dp_poll(self, i):
+        """(pair, count, local_len, status) of iteration i; blocks until reported."""
+        a, b, st = _i32(0), _i32(0), _i32(0)
+        cnt, ln = _u64(0), _u64(0)
+        self._check(_lib.bpe_dp_poll(self._h, i, C.byref(a), C.byref(b), C.byref(cnt), C.byref(ln),
+                                     C.byref(st)))
+        return (a.value, b.value), cnt.value, ln.value, st.value
+
+    def dp_end(self):
+        self._check(_lib.bpe_dp_end(self._h))
 
     # -- encoding ----------------------------------------------------------------------
     def encode_batch(self, pairs, merge_ids, data, offsets=None):

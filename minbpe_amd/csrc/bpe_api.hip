@@ -67,6 +67,12 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
+    // data-parallel stepping (bpe_dp_*)
+    int dp_rank = 0, dp_nranks = 1, dp_merges = 0;
+    bool dp_active = false;  // between bpe_dp_begin and bpe_dp_end
+    uint32_t *d_dp_folded = nullptr, *d_dp_table = nullptr;
+    long long *d_dp_key = nullptr;
+    uint64_t dp_cur_len = 0;
     int merge_impl = 0;  // 0 three-pass | 1 single-pass (two-level decoupled look-back)
     unsigned long long *d_desc = nullptr;   // look-back descriptors, one per tile
     unsigned long long *d_gdesc = nullptr;  // ... and one per group of 64 tiles
@@ -307,7 +313,7 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
         LAUNCHCHK(c, "k_rowmax_all");
     }
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st, c->d_ids[c->par], c->par);
+                       c->vcur, c->d_st, c->d_ids[c->par], c->par, c->dp_active ? 1 : 0);
     LAUNCHCHK(c, "k_select");
     if (c->n > TIE_WINDOW0) {
         hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(c->n - TIE_WINDOW0, 256, c->num_cus * 4)),
@@ -365,9 +371,14 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
     }
     }
     TRY(prof_end(c));
-    if (with_delta) {
+    if (with_delta && c->dp_active) {
+        // sharded: fold the replicas into the all-reduce payload; bpe_dp_apply does the rest
+        hipLaunchKernelGGL(k_dp_fold, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta,
+                           c->vcap, newid, c->d_dp_folded);
+        LAUNCHCHK(c, "k_dp_fold");
+    } else if (with_delta) {
         TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-        hipLaunchKernelGGL(k_apply_delta, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
                            c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
                            c->d_dirty_list, c->d_dirty_n);
         LAUNCHCHK(c, "k_apply_delta");
@@ -440,7 +451,8 @@ void bpe_destroy(bpe_ctx *c) {
     void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
                     c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
                     c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc, c->d_enc_tmp, c->d_enc_len, c->d_enc_out,
-                    c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids};
+                    c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids,
+                    c->d_dp_folded, c->d_dp_table, c->d_dp_key};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -712,6 +724,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
               double *iter_ms_out, uint64_t *len_out, int32_t *n_done) {
     if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
     if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
+    if (c->dp_active) return fail(c, BPE_E_STATE, "bpe_dp_end first");
     if (n_done) *n_done = 0;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_table(c, 256u + (uint32_t)num_merges));
@@ -1024,6 +1037,130 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     }
     if (n_out) *n_out = total;
     TRY(prof_drain(c));
+    return BPE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// data-parallel stepping: one ctx per rank, the host runs the two all-reduces
+
+extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_t nranks) {
+    if (!c || num_merges < 0 || rank < 0 || nranks < 1 || rank >= nranks || nranks > 1024)
+        return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->dp_rank = rank;
+    c->dp_nranks = nranks;
+    c->dp_merges = num_merges;
+    c->dp_active = true;
+    TRY(ensure_table(c, 256u + (uint32_t)num_merges));
+    TRY(ensure_rec(c, std::max(num_merges, 1)));
+    memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
+    if (c->d_dp_folded) (void)hipFree(c->d_dp_folded);
+    c->d_dp_folded = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, (size_t)c->vcap * 4 * sizeof(uint32_t)));
+    if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
+    if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 2 * sizeof(long long)));
+    TRY(start_from_bytes(c));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(launch_pair_count(c, false));
+    // the byte-pair block of the table, packed, is the first all-reduce payload
+    HIPCHK(c, hipMemcpy2DAsync(c->d_dp_table, 256 * 4, c->d_mat, (size_t)c->vcap * 4, 256 * 4, 256,
+                               hipMemcpyDeviceToDevice, c->stream));
+    c->dp_cur_len = c->n;
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_buffers(bpe_ctx *c, void **table, uint64_t *table_count, void **delta,
+                              uint64_t *delta_count, void **tiekey) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    if (table) *table = c->d_dp_table;
+    if (table_count) *table_count = 256 * 256;
+    if (delta) *delta = c->d_dp_folded;
+    if (delta_count) *delta_count = (uint64_t)c->vcap * 4;
+    if (tiekey) *tiekey = c->d_dp_key;
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_table_ready(bpe_ctx *c) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_mat, (size_t)c->vcap * 4, c->d_dp_table, 256 * 4, 256 * 4, 256,
+                               hipMemcpyDeviceToDevice, c->stream));
+    c->vcur = 256;
+    hipLaunchKernelGGL(k_rowmax_all, dim3(256), dim3(256), 0, c->stream, c->d_mat, c->vcap, 256u,
+                       c->d_rowmax);
+    LAUNCHCHK(c, "k_rowmax_all");
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->vcur = 256u + (uint32_t)iter;
+    TRY(launch_select(c, false));
+    hipLaunchKernelGGL(k_dp_key, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st,
+                       (unsigned long long)c->dp_rank, c->d_dp_key);
+    LAUNCHCHK(c, "k_dp_key");
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_dp_resolve, dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
+    LAUNCHCHK(c, "k_dp_resolve");
+    const int saved = c->merge_impl;
+    c->merge_impl = 0;  // the three-pass form finalises the pair before the rewrite
+    const int rc = launch_merge(c, 256u + (uint32_t)iter, iter, c->h_rec, true);
+    c->merge_impl = saved;
+    return rc;
+}
+
+extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t Z = 256u + (uint32_t)iter;
+    hipLaunchKernelGGL(k_apply_delta<true>, dim3((Z + 1 + 255) / 256), dim3(256), 0, c->stream, c->d_mat,
+                       c->vcap, c->d_dp_folded, c->vcap, c->d_rowmax, c->d_st, Z, c->d_dirty_list,
+                       c->d_dirty_n);
+    LAUNCHCHK(c, "k_apply_delta");
+    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, Z + 1,
+                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    LAUNCHCHK(c, "k_rowmax_list");
+    return BPE_OK;
+}
+
+// Wait for iteration `iter`'s record (written by the device into pinned memory).
+extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uint64_t *count,
+                           uint64_t *local_len, int32_t *status) {
+    if (!c || !c->d_dp_folded || iter < 0 || iter >= std::max(c->dp_merges, 1))
+        return fail(c, BPE_E_ARG, "bad iteration");
+    volatile IterRec *r = &c->h_rec[iter];
+    for (uint64_t spins = 1; r->seq != (unsigned long long)iter + 1; spins++) {
+        if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
+            r->seq != (unsigned long long)iter + 1)
+            return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", iter);
+    }
+    __sync_synchronize();
+    if (a) *a = r->a;
+    if (b) *b = r->b;
+    if (count) *count = r->count;
+    if (local_len) *local_len = r->new_len;
+    if (status) *status = (r->status == ST_OK) ? BPE_OK : (r->status == ST_EMPTY ? BPE_E_EMPTY_STATS : BPE_E_INTERNAL);
+    if (r->status == ST_OK) {
+        c->n = r->new_len;  // tighter launch bound
+        c->par = (iter + 1) & 1;
+    }
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_end(bpe_ctx *c) {
+    if (!c) return BPE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dp_nranks = 1;
+    c->dp_rank = 0;
+    c->dp_active = false;
     return BPE_OK;
 }
 

@@ -217,7 +217,7 @@ __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint
 // rest of the stream is k_tiebreak's job.
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, const uint32_t *__restrict__ ids, int par) {
+         uint32_t vcur, DevState *st, const uint32_t *__restrict__ ids, int par, int dist) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
@@ -296,6 +296,9 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             st->found = 1;
             st->a = s_tied[0];
             st->b = s_tied[1];
+        } else if (s_first != 0xFFFFFFFFu && dist) {
+            st->found = 0;  // sharded stream: only a candidate, the ranks compare positions
+            st->firstpos = s_first;
         } else if (s_first != 0xFFFFFFFFu) {
             st->found = 1;
             st->a = (int32_t)(ids[s_first] & IDMASK);
@@ -315,7 +318,9 @@ k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
            const uint32_t *__restrict__ mat, uint32_t stride, uint64_t lo) {
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ uint32_t s_go;
-    if (threadIdx.x == 0) s_go = (st->status == 0 && st->found == 0);
+    if (threadIdx.x == 0)
+        s_go = (st->status == 0 && st->found == 0 &&
+                __atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) == NOPOS);
     __syncthreads();
     if (!s_go) return;
     const uint32_t nt = st->ntied;
@@ -1117,6 +1122,7 @@ k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, De
 // Thread t owns token t: column a, row b, the new column Z and the new row Z.
 // Rows whose maximum may have dropped are queued for k_rowmax_list; for every
 // other row the only entry that grew is the brand-new column Z.
+template <bool FOLDED>
 __global__ void __launch_bounds__(256)
 k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta,
               uint32_t vcap, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
@@ -1126,6 +1132,10 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     if (t > Z) return;
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     uint32_t acc4[4] = {0, 0, 0, 0};
+    if (FOLDED) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc4[v] = delta[(size_t)v * vcap + t];
+    } else {
 #pragma unroll
     for (int v = 0; v < 4; v++) {
         uint32_t x[DELTA_REPL];
@@ -1136,6 +1146,7 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             if (x[r]) delta[((size_t)r * 4 + v) * vcap + t] = 0;
             acc4[v] += x[r];
         }
+    }
     }
     const uint32_t dl = acc4[0], dr = acc4[1], il = acc4[2], ir = acc4[3];
     bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
@@ -1180,6 +1191,67 @@ k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
         if (lane_id() == 0) s_red[wave_id()] = m;
         __syncthreads();
         if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Data-parallel training over sharded chunks: every rank holds a
+// contiguous range of chunks and a replica of the GLOBAL pair table.  Per
+// iteration the ranks exchange (1) two 64-bit words that decide the tie-break
+// and (2) the four delta vectors -- never ids, never the table.
+//
+// Tie-break across ranks: global first occurrence = lowest (rank, local
+// position).  w0 = key<<16 | a, w1 = key<<16 | b with key = rank<<32 | pos: the
+// element-wise MIN all-reduce of (w0, w1) returns the pair of the winning rank,
+// because the keys are distinct per rank.  No tie: every rank sends key 0 and
+// the same pair.  No local occurrence: INT64_MAX.
+__global__ void k_dp_key(const uint32_t *__restrict__ ids, const DevState *__restrict__ st,
+                         unsigned long long rank, long long *__restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long w0 = 0x7FFFFFFFFFFFFFFFll, w1 = 0x7FFFFFFFFFFFFFFFll;
+    if (st->status == 0) {
+        if (st->found) {
+            w0 = (long long)(uint32_t)st->a;
+            w1 = (long long)(uint32_t)st->b;
+        } else if (st->firstpos != NOPOS) {
+            const unsigned long long k = ((rank << 32) | st->firstpos) + 1;  // > 0: a tie never ties with "no tie"
+            w0 = (long long)((k << 16) | (ids[st->firstpos] & IDMASK));
+            w1 = (long long)((k << 16) | ids[st->firstpos + 1]);
+        }
+    }
+    key[0] = w0;
+    key[1] = w1;
+}
+__global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->status) return;
+    if (key[0] == 0x7FFFFFFFFFFFFFFFll) {
+        st->status = ST_INTERNAL;  // a tie at the maximum, yet no rank holds a tied pair
+        return;
+    }
+    st->a = (int32_t)(key[0] & 0xFFFF);
+    st->b = (int32_t)(key[1] & 0xFFFF);
+    st->found = 1;
+}
+// fold the replicated delta vectors into one compact 4 x vcap buffer (the SUM all-reduce payload)
+__global__ void __launch_bounds__(256)
+k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__restrict__ folded) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= vcap) return;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        uint32_t acc = 0;
+        if (t <= Z) {
+            uint32_t x[DELTA_REPL];
+#pragma unroll
+            for (int r = 0; r < DELTA_REPL; r++) x[r] = delta[((size_t)r * 4 + v) * vcap + t];
+#pragma unroll
+            for (int r = 0; r < DELTA_REPL; r++) {
+                if (x[r]) delta[((size_t)r * 4 + v) * vcap + t] = 0;
+                acc += x[r];
+            }
+        }
+        folded[(size_t)v * vcap + t] = acc;
     }
 }
 

@@ -1,0 +1,102 @@
+"""CPU, world_size 2, gloo: the data-parallel training protocol of
+minbpe_amd/dist.py (sharding by chunks, SUM all-reduce of the table deltas, MIN
+all-reduce of the tie-break key, lock-step stop on exhaustion) against the
+single-process oracle.  The per-rank engine is tests/cpu_shard.py (numpy); the
+GPU kernels behind the same protocol are covered by test_gpu_parity.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, chunks, num_merges, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from minbpe_amd.dist import TorchComm, shard_chunks, train_sharded
+        from cpu_shard import CpuShard
+        lo, hi = shard_chunks(len(chunks), rank, world)
+        mine = chunks[lo:hi]
+        data = b"".join(mine)
+        offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
+        try:
+            res = train_sharded(CpuShard(data, offs), TorchComm(), num_merges, depth=3)
+            out_q.put((rank, "ok", res["pairs"], res["counts"], res["lens"]))
+        except ValueError as e:
+            out_q.put((rank, "empty", e.partial["pairs"], e.partial["counts"], e.partial["lens"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(chunks, num_merges, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, num_merges, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(outs)
+
+
+def _chunks(text: bytes):
+    # split before every space: " word" chunks, like the GPT patterns' common case
+    import re
+    return [c for c in re.findall(rb" ?[^ ]+| +", text) if c]
+
+
+def _oracle(chunks, num_merges):
+    import oracle
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    return oracle.train(data, num_merges, offs, raise_on_empty=False)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_training_matches_single_process(native, world):
+    text = native.synth_text(6000, 41)
+    chunks = _chunks(text)
+    exp = _oracle(chunks, 60)
+    outs = _run(chunks, 60, world)
+    for rank, status, pairs, counts, lens in outs:
+        assert status == "ok"
+        assert pairs == exp[0] and counts == exp[1] and lens == exp[2], f"rank {rank}"
+
+
+def test_sharded_ties_prefer_lowest_rank_then_position(native):
+    # tie-heavy: a tiny alphabet, so first-occurrence order across shards decides most merges
+    rng = np.random.default_rng(9)
+    words = [bytes(97 + rng.integers(0, 3, size=rng.integers(1, 6))) for _ in range(400)]
+    chunks = [b" " + w for w in words]
+    exp = _oracle(chunks, 25)
+    for rank, status, pairs, counts, lens in _run(chunks, 25):
+        assert status == "ok" and pairs == exp[0] and counts == exp[1] and lens == exp[2]
+
+
+def test_sharded_exhaustion_stops_all_ranks_together():
+    chunks = [b"ab", b"ab", b"cd", b"ab"]
+    exp = _oracle(chunks, 6)
+    assert len(exp[0]) < 6
+    for rank, status, pairs, counts, lens in _run(chunks, 6):
+        assert status == "empty" and pairs == exp[0] and lens == exp[2]

@@ -315,3 +315,96 @@ def test_encode_many_docs(engine, native):
     exp_ids, exp_off = oracle.encode(pairs, data, offs)
     ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
     assert np.array_equal(ids, exp_ids) and np.array_equal(out_off, exp_off)
+
+
+# ---------------------------------------------------------------------------
+# data-parallel path (bpe_dp_*): several ranks emulated on the one GPU we have
+
+def _space_chunks(text: bytes):
+    import re
+    return [c for c in re.findall(rb" ?[^ ]+| +", text) if c]
+
+
+def _lockstep(native, chunks, nm, world):
+    """Drive `world` ctxs through the dist.py protocol in lock-step; reductions done by hand."""
+    import torch
+    from minbpe_amd.dist import GpuShard, shard_chunks
+    shards = []
+    for r in range(world):
+        lo, hi = shard_chunks(len(chunks), r, world)
+        mine = chunks[lo:hi]
+        eng = native.Engine(0)
+        data = b"".join(mine)
+        offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
+        eng.load_bytes(data, offs)
+        sh = GpuShard(eng, 0)
+        sh.begin(nm, r, world)
+        shards.append(sh)
+
+    def allreduce(name, op):
+        stack = torch.stack([getattr(sh, name) for sh in shards])
+        red = stack.sum(0) if op == "sum" else stack.min(0).values
+        for sh in shards:
+            getattr(sh, name).copy_(red.to(getattr(sh, name).dtype))
+
+    allreduce("table", "sum")
+    for sh in shards:
+        sh.table_ready()
+    for i in range(nm):
+        for sh in shards:
+            sh.select(i)
+        allreduce("key", "min")
+        for sh in shards:
+            sh.merge(i)
+        allreduce("delta", "sum")
+        for sh in shards:
+            sh.apply(i)
+    pairs, counts, lens = [], [], []
+    for i in range(nm):
+        recs = [sh.poll(i) for sh in shards]
+        if recs[0][3] != 0:
+            assert all(r[3] == recs[0][3] for r in recs)
+            break
+        assert all(r[0] == recs[0][0] and r[1] == recs[0][1] for r in recs)
+        pairs.append(recs[0][0])
+        counts.append(recs[0][1])
+        lens.append(sum(r[2] for r in recs))
+    for sh in shards:
+        sh.end()
+        sh.eng.close()
+    return pairs, counts, lens
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_dp_lockstep_matches_oracle(native, world):
+    torch = pytest.importorskip("torch")
+    chunks = _space_chunks(native.synth_text(300_000, 51))
+    nm = 200
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, nm, offs)
+    got = _lockstep(native, chunks, nm, world)
+    assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2]
+
+
+def test_dp_lockstep_ties_and_exhaustion(native):
+    pytest.importorskip("torch")
+    rng = np.random.default_rng(9)
+    chunks = [b" " + bytes(97 + rng.integers(0, 3, size=rng.integers(1, 6))) for _ in range(3000)]
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, 400, offs, raise_on_empty=False)
+    got = _lockstep(native, chunks, 400, 3)
+    assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2]
+    assert len(exp[0]) < 400  # the table ran empty: every rank stopped at the same merge
+
+
+def test_dp_train_sharded_solo(native, engine):
+    pytest.importorskip("torch")
+    from minbpe_amd.dist import GpuShard, SoloComm, train_sharded
+    text = native.synth_text(500_000, 52)
+    data, offs = split_chunks(text.decode())
+    exp = oracle.train(data, 300, offs)
+    engine.load_bytes(data, offs)
+    res = train_sharded(GpuShard(engine, 0), SoloComm(), 300)
+    assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
