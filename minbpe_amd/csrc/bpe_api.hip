@@ -1148,6 +1148,8 @@ extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uin
     if (local_len) *local_len = r->new_len;
     if (status) *status = (r->status == ST_OK) ? BPE_OK : (r->status == ST_EMPTY ? BPE_E_EMPTY_STATS : BPE_E_INTERNAL);
     if (r->status == ST_OK) {
+        if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
+        c->dp_cur_len = r->new_len;
         c->n = r->new_len;  // tighter launch bound
         c->par = (iter + 1) & 1;
     }
@@ -1158,6 +1160,7 @@ extern "C" int bpe_dp_end(bpe_ctx *c) {
     if (!c) return BPE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    TRY(prof_drain(c));
     c->dp_nranks = 1;
     c->dp_rank = 0;
     c->dp_active = false;
