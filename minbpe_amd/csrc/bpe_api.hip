@@ -92,7 +92,8 @@ struct bpe_ctx {
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
     bool prof_active = false;
-    int k1 = 1;       // 0 simple | 1 LDS-cached pair count
+    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache | 2 = 1 + dense 16-bit LDS table for byte streams
+    bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
 
     std::vector<ProfEv> prof_open;
     std::vector<hipEvent_t> ev_pool;
@@ -270,6 +271,7 @@ int start_from_bytes(bpe_ctx *c) {
     c->vcur = 256;
     c->have_ids = true;
     c->stats_valid = false;
+    c->stream_is_bytes = true;
     return BPE_OK;
 }
 
@@ -293,10 +295,14 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
             hipLaunchKernelGGL(k_pair_count_simple<false>, dim3(grid_for(n, 1024, c->num_cus * 8)),
                                dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
                                c->vcap, (uint32_t *)nullptr);
+        } else if (c->k1 == 2 && c->vcur <= 256 && c->stream_is_bytes) {
+            hipLaunchKernelGGL(k_pair_count_bytes, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
+                               dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
+                               c->par, c->d_mat, c->vcap);
         } else {
-            hipLaunchKernelGGL(k_pair_count_lds, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus * 2)),
-                               dim3(PC_THREADS), 0, c->stream, c->d_ids[c->par], c->d_st, c->par,
-                               c->d_mat, c->vcap);
+            hipLaunchKernelGGL(k_pair_count_lds, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
+                               dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
+                               c->par, c->d_mat, c->vcap);
         }
         LAUNCHCHK(c, "k_pair_count");
     }
@@ -389,6 +395,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
     }
     c->par ^= 1;
     c->stats_valid = false;
+    c->stream_is_bytes = false;
     return BPE_OK;
 }
 
@@ -432,6 +439,9 @@ int bpe_create(int device_id, bpe_ctx **out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     c->own_stream = true;
+    for (const void *fn : {(const void *)k_pair_count_lds, (const void *)k_pair_count_bytes})
+        if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES)) != hipSuccess)
+            return bail("hipFuncSetAttribute(dynamic LDS)", e);
     if ((e = hipMalloc((void **)&c->d_st, sizeof(DevState))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&c->d_scratch, 4 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
@@ -565,6 +575,7 @@ int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chu
     LAUNCHCHK(c, "k_init_state");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_bytes = false;
+    c->stream_is_bytes = false;
     c->par = 0;
     c->n = n;
     c->vcur = (uint32_t)mx + 1;

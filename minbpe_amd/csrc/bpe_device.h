@@ -21,9 +21,11 @@ constexpr int MJ = BPE_MJ;  // <= 8: a group of 64 tiles must fit 20-bit aggrega
 constexpr int WAVE_SPAN = MJ * 256;
 constexpr int TILE = (MT / 64) * WAVE_SPAN;  // 4096 ids = 16 KiB
 
-// pair-count kernel: LDS cache of 2^PC_BITS {key,count} slots per workgroup
-constexpr int PC_BITS = 13;
-constexpr int PC_THREADS = 512;
+// pair-count kernels: one 1024-thread workgroup per CU using all 128 KiB of dynamic LDS
+constexpr int PC_BITS = 14;       // general kernel: 2^14 {key,count} slots
+constexpr int PC_THREADS = 1024;
+constexpr int PC_LDS_BYTES = 131072;
+constexpr int PCB_ROUND = 61440;  // byte-stream kernel: positions between flushes (< 65536)
 
 constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
 constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
