@@ -67,6 +67,16 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
+    // slotted stream (training loop, a != b merges)
+    int use_slots = 1;
+    bool slotted = false;
+    uint64_t slot_T = 0;
+    int mq = 0;
+    uint32_t *d_meta[2] = {nullptr, nullptr};
+    uint32_t *d_slot_lens = nullptr;
+    unsigned long long *d_slot_off = nullptr, *d_slot_bsum = nullptr;
+    uint32_t *d_ids2 = nullptr;  // third stream buffer: target of compactions
+    uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0;
     bool dp_active = false;  // between bpe_dp_begin and bpe_dp_end
@@ -151,6 +161,7 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
     if (need > c->cap_ids) {
         TRY(dev_realloc(c, c->d_ids[0], need));
         TRY(dev_realloc(c, c->d_ids[1], need));
+        TRY(dev_realloc(c, c->d_ids2, need));
         c->cap_ids = need;
     }
     const uint64_t nt = ntiles_of(n) + 1;
@@ -158,6 +169,11 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_tsum, nt));
         TRY(dev_realloc(c, c->d_tile_off, nt));
         TRY(dev_realloc(c, c->d_tile_sin, nt));
+        TRY(dev_realloc(c, c->d_meta[0], nt));
+        TRY(dev_realloc(c, c->d_meta[1], nt));
+        TRY(dev_realloc(c, c->d_slot_lens, nt));
+        TRY(dev_realloc(c, c->d_slot_off, nt + 1));
+        TRY(dev_realloc(c, c->d_slot_bsum, nt / SCAN_TILE + 2));
         TRY(dev_realloc(c, c->d_desc, nt));
         TRY(dev_realloc(c, c->d_gdesc, nt / 64 + 2));
         HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
@@ -310,6 +326,22 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
     return BPE_OK;
 }
 
+SlotRef stream_ref(const bpe_ctx *c) {
+    SlotRef r;
+    if (c->slotted) {
+        r.b0 = c->d_ids[0];
+        r.b1 = c->d_ids[1];
+        r.meta = c->d_meta[c->mq];
+        r.T = c->slot_T;
+    } else {
+        r.b0 = c->d_ids[c->par];
+        r.b1 = nullptr;
+        r.meta = nullptr;
+        r.T = 0;
+    }
+    return r;
+}
+
 // K2 + tie-break: after these, resolved_pair() gives the pair on the device
 int launch_select(bpe_ctx *c, bool rowmax_all) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
@@ -318,13 +350,15 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
                            c->vcur, c->d_rowmax);
         LAUNCHCHK(c, "k_rowmax_all");
     }
+    const SlotRef ref = stream_ref(c);
+    const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st, c->d_ids[c->par], c->par, c->dp_active ? 1 : 0);
+                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0);
     LAUNCHCHK(c, "k_select");
-    if (c->n > TIE_WINDOW0) {
-        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(c->n - TIE_WINDOW0, 256, c->num_cus * 4)),
-                           dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
-                           c->vcap, (uint64_t)TIE_WINDOW0);
+    if (space > TIE_WINDOW0) {
+        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(space - TIE_WINDOW0, 256, c->num_cus * 4)),
+                           dim3(256), 0, c->stream, ref, c->d_st, c->par, c->d_mat, c->vcap,
+                           (uint64_t)TIE_WINDOW0);
         LAUNCHCHK(c, "k_tiebreak");
     }
     TRY(prof_end(c));
@@ -386,7 +420,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         TRY(prof_begin(c, BPE_PROF_TABLE, 0));
         hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
                            c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
-                           c->d_dirty_list, c->d_dirty_n);
+                           c->d_dirty_list, c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
         LAUNCHCHK(c, "k_apply_delta");
         hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap,
                            newid + 1, c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
@@ -394,6 +428,72 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         TRY(prof_end(c));
     }
     c->par ^= 1;
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    return BPE_OK;
+}
+
+
+// ---- slotted stream ---------------------------------------------------------------
+// contiguous (d_ids[par], st->n[par]) -> slots of TILE ids, all full but the last
+int slots_enter(bpe_ctx *c) {
+    c->slot_T = ntiles_of(c->n);
+    c->mq = 0;
+    hipLaunchKernelGGL(k_slot_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
+                       dim3(256), 0, c->stream, c->d_meta[0], c->slot_T, c->d_st, c->par,
+                       (uint32_t)c->par);
+    LAUNCHCHK(c, "k_slot_init");
+    c->slotted = true;
+    return BPE_OK;
+}
+
+// slots -> contiguous in d_ids[0] (par 0); st->n[0] = the stream length
+int slots_leave(bpe_ctx *c) {
+    const uint64_t T = c->slot_T;
+    if (T) {
+        const uint64_t nb = (T + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_slot_lens, dim3(grid_for(T, 256, c->num_cus * 4)), dim3(256), 0, c->stream,
+                           c->d_meta[c->mq], T, c->d_slot_lens);
+        hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_slot_bsum, nb,
+                           c->d_scratch + 3);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum, c->d_slot_off);
+        hipLaunchKernelGGL(k_slot_compact, dim3((unsigned)T), dim3(256), 0, c->stream, c->d_ids[0],
+                           c->d_ids[1], c->d_meta[c->mq], c->d_slot_off, c->d_ids2);
+        LAUNCHCHK(c, "k_slot_compact");
+    }
+    std::swap(c->d_ids[0], c->d_ids2);
+    if (c->par != 0) {
+        hipLaunchKernelGGL(k_move_n, dim3(1), dim3(1), 0, c->stream, c->d_st, c->par, 0);
+        LAUNCHCHK(c, "k_move_n");
+    }
+    c->par = 0;
+    c->slotted = false;
+    return BPE_OK;
+}
+
+// one slotted merge pass + table update (delta mode only)
+int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    hipLaunchKernelGGL(k_merge_slot<true>, dim3((unsigned)std::max<uint64_t>(c->slot_T, 1)), dim3(MT), 0,
+                       c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
+                       c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, c->vcap,
+                       c->d_dirty_n);
+    LAUNCHCHK(c, "k_merge_slot");
+    TRY(prof_end(c));
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
+                       c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
+                       c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, 1);
+    LAUNCHCHK(c, "k_apply_delta");
+    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, newid + 1,
+                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    LAUNCHCHK(c, "k_rowmax_list");
+    TRY(prof_end(c));
+    c->par ^= 1;
+    c->mq ^= 1;
     c->stats_valid = false;
     c->stream_is_bytes = false;
     return BPE_OK;
@@ -462,7 +562,8 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
                     c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc, c->d_enc_tmp, c->d_enc_len, c->d_enc_out,
                     c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids,
-                    c->d_dp_folded, c->d_dp_table, c->d_dp_key};
+                    c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
+                    c->d_slot_off, c->d_slot_bsum, c->d_ids2};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -495,6 +596,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->merge_impl = (int)value;
     } else if (!strcmp(name, "lb_tune")) {
         c->lb_tune = (uint32_t)value;
+    } else if (!strcmp(name, "slots")) {
+        c->use_slots = value != 0;
     } else if (!strcmp(name, "depth")) {
         if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
         c->depth = (int)value;
@@ -649,7 +752,7 @@ int bpe_argmax(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *count) {
     TRY(launch_pair_count(c, false));
     c->stats_valid = false;
     TRY(launch_select(c, true));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st);
     LAUNCHCHK(c, "k_finalize");
     DevState st;
     TRY(read_state(c, &st));
@@ -760,6 +863,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     int done = 0, rc = BPE_OK, consumed = 0;
     uint64_t cur_len = n0;  // exact length before iteration `consumed`
     bool stop = false;
+    int samepair_at = -1;
+    const bool slots = delta && c->use_slots && c->merge_impl == 0;
+    if (slots) TRY(slots_enter(c));
     // The device writes one IterRec per iteration into pinned host memory; the
     // host runs up to `depth` iterations ahead and only ever waits on those
     // records, never on the stream (no hipStreamSynchronize in the loop).
@@ -771,6 +877,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
         }
         __sync_synchronize();
+        if (r->status == ST_SAMEPAIR) {  // slotted pass refused a == b: redo merge j contiguously
+            samepair_at = j;
+            return BPE_OK;
+        }
         if (r->status == ST_EMPTY) {
             stop = true;
             rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
@@ -803,33 +913,81 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         return BPE_OK;
     };
 
-    for (int i = 0; i < num_merges && !stop; i++) {
-        c->vcur = 256u + (uint32_t)i;
-        bool full_rowmax = (i == 0);
-        if (!delta && i > 0) {
-            TRY(clear_table(c));
-            TRY(launch_pair_count(c, false));
-            full_rowmax = true;
+    int i = 0;
+    while (!stop) {
+        // enqueue iteration i (if any is left), then look at the record `depth` back
+        if (i < num_merges) {
+            c->vcur = 256u + (uint32_t)i;
+            bool full_rowmax = (i == 0);
+            if (!delta && i > 0) {
+                TRY(clear_table(c));
+                TRY(launch_pair_count(c, false));
+                full_rowmax = true;
+            }
+            // slots running low: re-pack (between merges nothing is pending)
+            if (c->slotted && c->slot_T > 64 && c->n * 2 < c->slot_T * (uint64_t)TILE) {
+                TRY(slots_leave(c));
+                TRY(slots_enter(c));
+            }
+            TRY(launch_select(c, full_rowmax));
+            if (c->slotted)
+                TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));
+            else
+                TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
+            if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
+            i++;
         }
-        TRY(launch_select(c, full_rowmax));
-        TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
-        if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
-        if (i - consumed >= c->depth) {
+        if (consumed < i && (i - consumed > c->depth || i == num_merges)) {
             TRY(consume(consumed));
-            consumed++;
+            if (samepair_at >= 0) {
+                // Everything enqueued after merge j was a no-op (status is sticky).  Drain,
+                // restore the host's view of iteration j, redo it on the contiguous path.
+                const int j = samepair_at;
+                samepair_at = -1;
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                const int back = i - j;  // iterations whose parity flips must be undone
+                if (back & 1) {
+                    c->par ^= 1;
+                    c->mq ^= 1;
+                }
+                memset(&c->h_rec[j], 0, sizeof(IterRec) * (size_t)(num_merges - j));
+                hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
+                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par,
+                                   c->d_st);  // pin the pair before positions move
+                LAUNCHCHK(c, "k_finalize");
+                TRY(slots_leave(c));
+                c->vcur = 256u + (uint32_t)j;
+                c->n = cur_len;
+                TRY(launch_merge(c, 256u + (uint32_t)j, j, c->h_rec, true));
+                TRY(slots_enter(c));
+                i = j + 1;
+                continue;
+            }
+            if (!stop) consumed++;
         }
+        if (consumed >= num_merges) break;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int enq = consumed + 0;
-    (void)enq;
-    while (!stop && consumed < num_merges && c->h_rec[consumed].seq == (unsigned long long)consumed + 1) {
-        TRY(consume(consumed));
-        consumed++;
+    if (c->slotted) {
+        // leave the ids contiguous for whoever reads them next
+        if (stop) {  // parity of the no-op iterations enqueued after the failing one
+            const int back = i - done;
+            if (back & 1) {
+                c->par ^= 1;
+                c->mq ^= 1;
+            }
+            hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
+        }
+        TRY(slots_leave(c));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n = cur_len;
+        c->vcur = 256u + (uint32_t)done;
+    } else {
+        c->par = done & 1;
+        c->n = cur_len;
+        c->vcur = 256u + (uint32_t)done;
     }
     // device buffers hold the stream after `done` merges
-    c->par = done & 1;
-    c->n = cur_len;
-    c->vcur = 256u + (uint32_t)done;
     if (iter_ms_out) {
         for (int i = 0; i < done; i++) {
             float ms = 0.f;
@@ -1133,7 +1291,7 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     const uint32_t Z = 256u + (uint32_t)iter;
     hipLaunchKernelGGL(k_apply_delta<true>, dim3((Z + 1 + 255) / 256), dim3(256), 0, c->stream, c->d_mat,
                        c->vcap, c->d_dp_folded, c->vcap, c->d_rowmax, c->d_st, Z, c->d_dirty_list,
-                       c->d_dirty_n);
+                       c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
     LAUNCHCHK(c, "k_apply_delta");
     hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, Z + 1,
                        c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);

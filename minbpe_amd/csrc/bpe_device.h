@@ -38,8 +38,19 @@ constexpr int ENC_LMAX = 32;  // longer chunks take the stream-wide path
 constexpr int SCAN_TILE = 4096;
 
 constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
+constexpr uint32_t ST_SAMEPAIR = 4;  // slotted merge met a == b: the host redoes this merge on the contiguous path
 constexpr uint32_t EPOCH_MASK = 0xFFFFFu;  // look-back descriptors carry a 20-bit launch tag
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile
+
+// A view of the id stream.  meta == nullptr: contiguous, b0[0..n).  Otherwise
+// slotted: slot t occupies [t*TILE, t*TILE + len) of buffer b0 or b1, with
+// meta[t] = len | (which buffer) << 31.  Stream order = slot order, so a
+// slot-space position p = t*TILE + offset still orders first occurrences.
+struct SlotRef {
+    const uint32_t *b0, *b1;
+    const uint32_t *meta;
+    unsigned long long T;
+};
 
 // one per ctx, in device memory
 struct DevState {
@@ -52,6 +63,7 @@ struct DevState {
     uint32_t status;              // ST_*
     int32_t tied[2 * TIE_CAP];
     int32_t fin_a, fin_b;         // the pair as finalised by the merge pass (read by k_apply_delta)
+    unsigned long long removed;   // slotted merge: ids removed by the current pass
 };
 
 // one per training iteration, written by the device into pinned host memory

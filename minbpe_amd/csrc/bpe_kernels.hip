@@ -247,6 +247,35 @@ k_rowmax_all(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur,
     if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
+// ---------------------------------------------------------------------------
+// stream views (contiguous or slotted), used by the tie-break scans
+
+__device__ __forceinline__ bool slot_get(const SlotRef &r, uint64_t n, uint64_t p, uint32_t &w) {
+    if (!r.meta) {
+        if (p >= n) return false;
+        w = r.b0[p];
+        return true;
+    }
+    const uint64_t t = p / TILE;
+    if (t >= r.T) return false;
+    const uint32_t m = r.meta[t];
+    if ((uint32_t)(p % TILE) >= (m & 0x7FFFFFFFu)) return false;
+    w = ((m >> 31) ? r.b1 : r.b0)[p];
+    return true;
+}
+// the word that follows position p in stream order
+__device__ __forceinline__ bool slot_next(const SlotRef &r, uint64_t n, uint64_t p, uint32_t &w) {
+    if (!r.meta) return slot_get(r, n, p + 1, w);
+    uint64_t t = p / TILE;
+    if ((uint32_t)(p % TILE) + 1 < (r.meta[t] & 0x7FFFFFFFu)) return slot_get(r, n, p + 1, w);
+    for (t = t + 1; t < r.T; t++)
+        if (r.meta[t] & 0x7FFFFFFFu) return slot_get(r, n, t * TILE, w);
+    return false;
+}
+__device__ __forceinline__ uint64_t slot_space(const SlotRef &r, uint64_t n) {
+    return r.meta ? r.T * (uint64_t)TILE : n;
+}
+
 // the pair test of the tie-break: is (a, w1) one of the pairs tied at the max?
 __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint32_t M,
                                         const uint32_t *__restrict__ mat, uint32_t stride,
@@ -267,7 +296,7 @@ __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint
 // rest of the stream is k_tiebreak's job.
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, const uint32_t *__restrict__ ids, int par, int dist) {
+         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
@@ -326,12 +355,12 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (threadIdx.x < 2 * min(nt, (uint32_t)TIE_CAP)) st->tied[threadIdx.x] = s_tied[threadIdx.x];
     if (nt > 1) {  // tie: first window, positions ascending per thread
         const uint64_t n = st->n[par];
-        const uint32_t hi = (uint32_t)min((uint64_t)TIE_WINDOW0, n);
-        for (uint32_t p = threadIdx.x; p < hi && (uint64_t)p + 1 < n; p += 1024) {
+        const uint32_t hi = (uint32_t)min((uint64_t)TIE_WINDOW0, slot_space(ref, n));
+        for (uint32_t p = threadIdx.x; p < hi; p += 1024) {
             if (__atomic_load_n(&s_first, __ATOMIC_RELAXED) < p) break;  // an earlier hit exists
-            const uint32_t w1 = ids[p + 1];
-            if (w1 & FLAG) continue;
-            if (tie_hit(s_tied, nt, M, mat, stride, ids[p] & IDMASK, w1)) {
+            uint32_t w0, w1;
+            if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;
+            if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1)) {
                 atomicMin(&s_first, p);
                 break;
             }
@@ -350,9 +379,12 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             st->found = 0;  // sharded stream: only a candidate, the ranks compare positions
             st->firstpos = s_first;
         } else if (s_first != 0xFFFFFFFFu) {
+            uint32_t w0 = 0, w1 = 0;
+            slot_get(ref, st->n[par], s_first, w0);
+            slot_next(ref, st->n[par], s_first, w1);
             st->found = 1;
-            st->a = (int32_t)(ids[s_first] & IDMASK);
-            st->b = (int32_t)ids[s_first + 1];
+            st->a = (int32_t)(w0 & IDMASK);
+            st->b = (int32_t)w1;
         } else {
             st->found = 0;
         }
@@ -364,8 +396,8 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
 // as soon as an earlier position has been reported.  No-op unless a tie is
 // still unresolved.
 __global__ void __launch_bounds__(256)
-k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
-           const uint32_t *__restrict__ mat, uint32_t stride, uint64_t lo) {
+k_tiebreak(SlotRef ref, DevState *st, int par, const uint32_t *__restrict__ mat, uint32_t stride,
+           uint64_t lo) {
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ uint32_t s_go;
     if (threadIdx.x == 0)
@@ -378,12 +410,13 @@ k_tiebreak(const uint32_t *__restrict__ ids, DevState *st, int par,
     if (nt <= TIE_CAP && threadIdx.x < 2 * nt) s_tied[threadIdx.x] = st->tied[threadIdx.x];
     __syncthreads();
     const uint64_t n = st->n[par];
+    const uint64_t space = slot_space(ref, n);
     const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p + 1 < n; p += total) {
+    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < space; p += total) {
         if (__atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) < p) break;
-        const uint32_t w1 = ids[p + 1];
-        if (w1 & FLAG) continue;
-        if (tie_hit(s_tied, nt, M, mat, stride, ids[p] & IDMASK, w1)) {
+        uint32_t w0, w1;
+        if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;
+        if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1)) {
             atomicMin(&st->firstpos, (unsigned long long)p);
             break;  // later positions of this thread cannot be earlier
         }
@@ -406,12 +439,27 @@ __device__ __forceinline__ bool resolved_pair(const DevState *st, const uint32_t
     return true;
 }
 
+__device__ __forceinline__ bool resolved_pair(const DevState *st, const SlotRef &ref, uint64_t n,
+                                              uint32_t &a, uint32_t &b) {
+    if (st->found) {
+        a = (uint32_t)st->a;
+        b = (uint32_t)st->b;
+        return true;
+    }
+    const unsigned long long p = st->firstpos;
+    uint32_t w0, w1;
+    if (p == NOPOS || !slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1)) return false;
+    a = w0 & IDMASK;
+    b = w1;
+    return true;
+}
+
 // single-step API (bpe_argmax): make the decision final in st
-__global__ void k_finalize(const uint32_t *__restrict__ ids, DevState *st) {
+__global__ void k_finalize(SlotRef ref, int par, DevState *st) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->status == 0 && !st->found) {
         uint32_t a, b;
-        if (!resolved_pair(st, ids, a, b)) {
+        if (!resolved_pair(st, ref, st->n[par], a, b)) {
             st->status = ST_INTERNAL;  // a tie was reported but no tied pair is in the stream
         } else {
             st->a = (int32_t)a;
@@ -451,11 +499,11 @@ struct Tile {
     uint32_t tail[3];   // the three words after this wave's span (INVALID_WORD past n)
 };
 
-__device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
-                                          uint64_t tile_base, uint32_t a, uint32_t b, int *s_wave) {
+// fetch from a contiguous stream of n ids
+__device__ __forceinline__ void tile_fetch(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
+                                           uint64_t tile_base) {
     const int lane = lane_id(), wave = wave_id();
     const uint64_t wbase = tile_base + (uint64_t)wave * WAVE_SPAN;
-    uint32_t nx[MJ];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const uint64_t p0 = wbase + j * 256 + lane * 4;
@@ -468,6 +516,38 @@ __device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ 
     const uint64_t tailp = wbase + WAVE_SPAN;
 #pragma unroll
     for (int i = 0; i < 3; i++) t.tail[i] = (tailp + i < n) ? ids[tailp + i] : INVALID_WORD;
+}
+
+// fetch slot `src` holding `len` owned ids, followed (in stream order) by the
+// three words halo[0..2] that belong to later slots (INVALID_WORD at the end of
+// the stream).  Positions >= len + 3 are INVALID_WORD.
+__device__ __forceinline__ void tile_fetch_slot(Tile &t, const uint32_t *__restrict__ src, int len,
+                                                const uint32_t *halo) {
+    const int lane = lane_id(), wave = wave_id();
+    const int wrel = wave * WAVE_SPAN;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const int q0 = wrel + j * 256 + lane * 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q0 < len) v = *reinterpret_cast<const uint4 *>(src + q0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int q = q0 + k;
+            t.x[j][k] = (q < len) ? w[k] : ((q < len + 3) ? halo[q - len] : INVALID_WORD);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int q = wrel + WAVE_SPAN + i;
+        t.tail[i] = (q < len) ? src[q] : ((q < len + 3) ? halo[q - len] : INVALID_WORD);
+    }
+}
+
+// r bits, last-zero scan: everything the m bits need (contains one __syncthreads)
+__device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, int *s_wave) {
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t nx[MJ];
     const uint32_t tail = t.tail[0];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
@@ -511,6 +591,12 @@ __device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ 
     for (int w = 0; w < wave; w++) win = max(win, s_wave[w]);
 #pragma unroll
     for (int j = 0; j < MJ; j++) t.E[j] = max(t.E[j], win);
+}
+
+__device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
+                                          uint64_t tile_base, uint32_t a, uint32_t b, int *s_wave) {
+    tile_fetch(t, ids, n, tile_base);
+    tile_prepare(t, a, b, s_wave);
 }
 
 // m bit of tile-relative position q given lz = index of the last zero at or
@@ -746,21 +832,27 @@ k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__rest
 //   incL[L] : pairs (L,Z) created        incR[R] : pairs (Z,R) created (R may be Z)
 // Each destroyed pair is charged to its left element, each created pair to its
 // left output element, so nothing is counted twice.
-template <bool DELTA>
+// own_len: the tile owns positions [0, own_len); words beyond are context only.
+// SKIP_UNCHANGED: do not store when no owned element changes (slotted streams:
+// the slot simply stays where it is).  *kept_out / *changed_out: block totals.
+template <bool DELTA, bool SKIP_UNCHANGED>
 __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t a, uint32_t b,
                                              uint32_t newid, uint32_t *__restrict__ dst_tile,
                                              uint32_t *s_wsum, uint32_t *__restrict__ delta,
-                                             uint32_t vcap) {
+                                             uint32_t vcap, int own_len, uint32_t *kept_out,
+                                             bool *changed_out) {
     const int lane = lane_id(), wave = wave_id();
     uint32_t mb[MJ], mp[MJ], kb[MJ], ex[MJ];
-    uint32_t carry = 0;
+    uint32_t carry = 0, chg = 0;
+    const int qw = wave * WAVE_SPAN + lane * 4;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         mb[j] = group_mbits(t, j, s, mp[j]);
-        // kept bit k = !m[k-1], only for valid positions
+        // kept bit k = !m[k-1], only for owned positions
         uint32_t valid = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) valid |= (uint32_t)(t.x[j][k] != INVALID_WORD) << k;
+        for (int k = 0; k < 4; k++) valid |= (uint32_t)(qw + j * 256 + k < own_len) << k;
+        chg |= mb[j] & valid;
         kb[j] = (~((mb[j] << 1) | mp[j])) & valid & 0xFu;
         uint32_t v = __popc(kb[j]);
 #pragma unroll
@@ -771,19 +863,30 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         ex[j] = carry + v - __popc(kb[j]);
         carry += (uint32_t)__shfl((int)v, 63);
     }
-    if (lane == 0) s_wsum[wave] = carry;
+    const bool wchg = __any(chg != 0);
+    if (lane == 0) s_wsum[wave] = carry | (wchg ? 0x80000000u : 0u);
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += s_wsum[w];
-    uint32_t *dst = dst_tile + wbase;
+    uint32_t wbase = 0, total = 0;
+    bool changed = (s != 0);
+    for (int w = 0; w < MT / 64; w++) {
+        const uint32_t v = s_wsum[w];
+        if (w < wave) wbase += v & 0x7FFFFFFFu;
+        total += v & 0x7FFFFFFFu;
+        changed |= (v >> 31) != 0;
+    }
+    if (kept_out) *kept_out = total;
+    if (changed_out) *changed_out = changed;
+    if (!SKIP_UNCHANGED || changed) {
+        uint32_t *dst = dst_tile + wbase;
 #pragma unroll
-    for (int j = 0; j < MJ; j++) {
-        uint32_t o = ex[j];
+        for (int j = 0; j < MJ; j++) {
+            uint32_t o = ex[j];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if ((kb[j] >> k) & 1u) {
-                const uint32_t w = t.x[j][k];
-                dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+            for (int k = 0; k < 4; k++) {
+                if ((kb[j] >> k) & 1u) {
+                    const uint32_t w = t.x[j][k];
+                    dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                }
             }
         }
     }
@@ -829,7 +932,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                 for (int k = 0; k < 4; k++) {
                     const uint32_t Mk = (Mx >> (k + 1)) & 1u, Mkm1 = (Mx >> k) & 1u,
                                    Mkp1 = (Mx >> (k + 2)) & 1u;
-                    if (X[k] == INVALID_WORD) continue;
+                    if (qw + j * 256 + k >= own_len) continue;  // context word, not mine
                     if (!(X[k + 1] & FLAG) && !Mk) {  // an old pair that is not the site itself
                         if (Mkm1) atomicAdd(&delta[1 * (size_t)vcap + X[k + 1]], 1u);
                         else if (Mkp1) atomicAdd(&delta[0 * (size_t)vcap + (X[k] & IDMASK)], 1u);
@@ -864,8 +967,8 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     Tile t;
     tile_load(t, in, n, tile_base, a, b, s_wave);
-    tile_rewrite<DELTA>(t, tile_sin[blockIdx.x], a, b, newid, out + tile_off[blockIdx.x], s_wsum,
-                        delta, vcap);
+    tile_rewrite<DELTA, false>(t, tile_sin[blockIdx.x], a, b, newid, out + tile_off[blockIdx.x], s_wsum,
+                               delta, vcap, (int)min((uint64_t)TILE, n - tile_base), nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -1165,8 +1268,143 @@ k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, De
     }
     __syncthreads();
     if (s_fail) return;
-    tile_rewrite<DELTA>(t, s_sin, a, b, newid, out + s_excl, s_wsum, delta, vcap);
+    tile_rewrite<DELTA, false>(t, s_sin, a, b, newid, out + s_excl, s_wsum, delta, vcap, len, nullptr,
+                               nullptr);
 }
+
+// ---------------------------------------------------------------------------
+// Slotted merge (the training loop's default for a != b).
+//
+// The contiguous form moves every id every iteration (8N + 4N' bytes with the
+// count pass) although late in training a merge touches a few ids per
+// thousand.  Here the stream is a sequence of TILE-sized slots, each holding
+// `len` ids at its start; a merge rewrites a slot only if one of its ids
+// changes, into the same slot of the other buffer, and flips that slot's
+// buffer bit.  No prefix sum, no second pass: one read of the ids (4N) plus the
+// slots that actually change.  Stream order is slot order, so first-occurrence
+// order (F3) is preserved; k_slot_compact restores a contiguous stream when the
+// slots run low or when a == b needs the cross-tile pairing of the scan path.
+//
+// For a != b the carry into a slot is local knowledge: the previous slot's
+// last id is a and my first word is b.
+
+__global__ void __launch_bounds__(256)
+k_slot_init(uint32_t *__restrict__ meta, uint64_t T, const DevState *__restrict__ st, int par,
+            uint32_t which) {
+    const uint64_t n = st->n[par];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride) {
+        const uint64_t b0 = t * TILE;
+        const uint32_t len = b0 >= n ? 0u : (uint32_t)min((uint64_t)TILE, n - b0);
+        meta[t] = len | (which << 31);
+    }
+}
+
+template <bool DELTA>
+__global__ void __launch_bounds__(MT)
+k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, uint32_t *__restrict__ w0,
+             uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
+             uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
+             uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n) {
+    __shared__ int s_wave[MT / 64];
+    __shared__ uint32_t s_wsum[MT / 64];
+    __shared__ uint32_t s_ctx[4];  // halo[0..2], previous slot's last word
+    const uint64_t t = blockIdx.x;
+    if (t == 0 && threadIdx.x == 0 && dirty_n) *dirty_n = 0;
+    if (t >= T || st->status) return;
+    SlotRef ref;
+    ref.b0 = b0;
+    ref.b1 = b1;
+    ref.meta = meta_in;
+    ref.T = T;
+    uint32_t a, b;
+    if (!resolved_pair(st, ref, 0, a, b)) {
+        if (t == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
+        return;
+    }
+    if (a == b) {  // needs cross-slot run parity: the host takes the contiguous path
+        if (t == 0 && threadIdx.x == 0) st->status = ST_SAMEPAIR;
+        return;
+    }
+    const uint32_t mi = meta_in[t];
+    const int len = (int)(mi & 0x7FFFFFFFu);
+    if (t == 0 && threadIdx.x == 0) {
+        st->fin_a = (int32_t)a;
+        st->fin_b = (int32_t)b;
+    }
+    if (len == 0) {
+        if (threadIdx.x == 0) meta_out[t] = mi;
+        return;
+    }
+    const uint32_t cur = mi >> 31;
+    const uint32_t *src = (cur ? b1 : b0) + t * TILE;
+    if (threadIdx.x == 0) {
+        // the three words after my slot, and the word before it, in stream order
+        uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
+        int got = 0;
+        for (uint64_t u = t + 1; u < T && got < 3; u++) {
+            const uint32_t mu = meta_in[u];
+            const uint32_t lu = mu & 0x7FFFFFFFu;
+            const uint32_t *pu = ((mu >> 31) ? b1 : b0) + u * TILE;
+            for (uint32_t i = 0; i < lu && got < 3; i++) h[got++] = pu[i];
+        }
+        uint32_t prev = INVALID_WORD;
+        for (uint64_t u = t; u-- > 0;) {
+            const uint32_t mu = meta_in[u];
+            const uint32_t lu = mu & 0x7FFFFFFFu;
+            if (lu) {
+                prev = (((mu >> 31) ? b1 : b0) + u * TILE)[lu - 1];
+                break;
+            }
+        }
+        s_ctx[0] = h[0];
+        s_ctx[1] = h[1];
+        s_ctx[2] = h[2];
+        s_ctx[3] = prev;
+    }
+    __syncthreads();
+    const uint32_t halo[3] = {s_ctx[0], s_ctx[1], s_ctx[2]};
+    const uint32_t prev = s_ctx[3];
+    Tile tl;
+    tile_fetch_slot(tl, src, len, halo);
+    tile_prepare(tl, a, b, s_wave);
+    // carry: the previous slot ended with a site start iff its last id is a and my first word is b
+    const uint32_t first = src[0];
+    const uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (first == b));
+    uint32_t kept = 0;
+    bool changed = false;
+    uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
+    tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed);
+    if (threadIdx.x == 0) {
+        if (changed) {
+            meta_out[t] = kept | ((cur ^ 1u) << 31);
+            atomicAdd(&st->removed, (unsigned long long)((uint32_t)len - kept));
+        } else {
+            meta_out[t] = mi;
+        }
+    }
+}
+
+// slots -> contiguous: tile t's ids go to out[off[t] ...]; the stream length is left in st->n[par]
+__global__ void __launch_bounds__(256)
+k_slot_lens(const uint32_t *__restrict__ meta, uint64_t T, uint32_t *__restrict__ lens) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride)
+        lens[t] = meta[t] & 0x7FFFFFFFu;
+}
+__global__ void __launch_bounds__(256)
+k_slot_compact(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1,
+               const uint32_t *__restrict__ meta, const unsigned long long *__restrict__ off,
+               uint32_t *__restrict__ out) {
+    const uint64_t t = blockIdx.x;
+    const uint32_t m = meta[t];
+    const uint32_t len = m & 0x7FFFFFFFu;
+    const uint32_t *src = ((m >> 31) ? b1 : b0) + t * TILE;
+    uint32_t *dst = out + off[t];
+    for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+}
+__global__ void k_set_status(DevState *st, uint32_t status) { st->status = status; }
+__global__ void k_move_n(DevState *st, int from, int to) { st->n[to] = st->n[from]; }
 
 // Apply the four delta vectors to the dense table and keep rowmax[] current.
 // Thread t owns token t: column a, row b, the new column Z and the new row Z.
@@ -1175,8 +1413,28 @@ k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, De
 template <bool FOLDED>
 __global__ void __launch_bounds__(256)
 k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta,
-              uint32_t vcap, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
-              uint32_t Z, uint32_t *__restrict__ dirty_list, uint32_t *__restrict__ dirty_n) {
+              uint32_t vcap, uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
+              uint32_t *__restrict__ dirty_list, uint32_t *__restrict__ dirty_n, int par, IterRec *rec,
+              int iter, int slot_finish) {
+    if (slot_finish && blockIdx.x == 0 && threadIdx.x == 0) {
+        // slotted pass: new stream length and this iteration's record
+        const unsigned long long n = st->n[par];
+        unsigned long long nn = n;
+        if (st->status == 0) {
+            nn = n - st->removed;
+            st->n[par ^ 1] = nn;
+        }
+        st->removed = 0;
+        if (rec) {
+            rec[iter].a = st->status == 0 ? st->fin_a : st->a;
+            rec[iter].b = st->status == 0 ? st->fin_b : st->b;
+            rec[iter].count = st->count;
+            rec[iter].status = st->status;
+            rec[iter].new_len = nn;
+            __threadfence_system();
+            rec[iter].seq = (unsigned long long)iter + 1;
+        }
+    }
     if (st->status) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > Z) return;
@@ -1580,6 +1838,7 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->found = 0;
     st->status = 0;
     st->fin_a = st->fin_b = 0;
+    st->removed = 0;
 }
 
 }  // namespace bpe

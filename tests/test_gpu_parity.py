@@ -96,7 +96,7 @@ def test_long_runs_cross_tile_boundaries(engine, mimpl):
         engine.load_ids(ids)
         engine.merge(pair, 300)
         assert np.array_equal(engine.read_ids(), oracle.merge(ids, pair, 300))
-    engine.set_option("merge", 1)
+    engine.set_option("merge", 0)
 
 
 # ---------------------------------------------------------------------------
@@ -115,14 +115,15 @@ def test_train_golden_cases(golden, engine, native):
         assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
 
 
-@pytest.mark.parametrize("mode,mimpl", [(0, 0), (1, 0), (1, 1), (0, 1)])
+@pytest.mark.parametrize("mode,mimpl,slots", [(0, 0, 0), (1, 0, 1), (1, 0, 0), (1, 1, 0), (0, 1, 0)])
 @pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
                                     (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
-def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, k, n, nm):
+def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, k, n, nm):
     rng = random.Random(k * 1000 + n)
     data = bytes(97 + rng.randrange(k) for _ in range(n))
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
+    engine.set_option("slots", slots)
     try:
         engine.load_bytes(data)
         exp = oracle.train(data, nm, raise_on_empty=False)
@@ -142,12 +143,13 @@ def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, k, n, nm):
         assert np.array_equal(engine.read_ids(), ids)
     finally:
         engine.set_option("mode", 1)
-        engine.set_option("merge", 1)
+        engine.set_option("merge", 0)
+        engine.set_option("slots", 1)
 
 
-@pytest.mark.parametrize("mode,mimpl", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("mode,mimpl,slots", [(0, 0, 0), (1, 0, 1), (1, 0, 0), (1, 1, 0)])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl):
+def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots):
     text = native.synth_text(2_000_000, 11)
     if kind == "basic":
         data, offs = text, None
@@ -157,6 +159,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl):
     exp = oracle.train(data, nm, offs)
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
+    engine.set_option("slots", slots)
     try:
         engine.load_bytes(data, offs)
         res = engine.train(nm)
@@ -168,9 +171,17 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl):
         # depth 0 = host waits for every iteration: same result
         engine.set_option("depth", 0)
         assert engine.train(nm)["pairs"] == exp[0]
+        # the resident stream after training is the oracle's (slots are re-packed at the end)
+        ids = np.frombuffer(data, dtype=np.uint8).astype(np.int32)
+        o = None if offs is None else offs
+        for i, p in enumerate(exp[0]):
+            ids, off_full = oracle.merge_chunks(ids, o, p, 256 + i)
+            o = off_full[:-1]
+        assert np.array_equal(engine.read_ids(), ids)
     finally:
         engine.set_option("mode", 1)
-        engine.set_option("merge", 1)
+        engine.set_option("merge", 0)
+        engine.set_option("slots", 1)
         engine.set_option("depth", 8)
 
 
@@ -408,3 +419,21 @@ def test_dp_train_sharded_solo(native, engine):
     engine.load_bytes(data, offs)
     res = train_sharded(GpuShard(engine, 0), SoloComm(), 300)
     assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+
+
+def test_train_slotted_edge_cases(engine):
+    """slotted loop: runs of one symbol (every merge is a == b: contiguous fallback each time),
+    tiny streams, streams of exactly one / several tiles, chunk starts at slot boundaries."""
+    cases = [(b"a" * 50000, None, 12), (b"ab" * 4096, None, 5), (b"abc" * 4096 + b"x", None, 20),
+             (b"ab" * 30000, np.arange(0, 60000, 4096, dtype=np.uint64), 10),
+             (b"", None, 3), (b"z", None, 2)]
+    for data, offs, nm in cases:
+        exp = oracle.train(data, nm, offs, raise_on_empty=False)
+        engine.load_bytes(data, offs)
+        if len(exp[0]) < nm:
+            with pytest.raises(ValueError):
+                engine.train(nm)
+            res = engine.last_train
+        else:
+            res = engine.train(nm)
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], (len(data), nm)
