@@ -69,6 +69,8 @@ struct bpe_ctx {
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
     int use_slots = 1;
+    int rep_shift = 5;        // log2(delta-vector replicas in use): shrinks as merges get rarer
+    bool rows_in_select = false;  // the next k_select recomputes the queued rows itself
     bool slotted = false;
     uint64_t slot_T = 0;
     int mq = 0;
@@ -326,6 +328,8 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
     return BPE_OK;
 }
 
+inline uint32_t vcap_rep(const bpe_ctx *c) { return c->vcap | ((uint32_t)c->rep_shift << 24); }
+
 SlotRef stream_ref(const bpe_ctx *c) {
     SlotRef r;
     if (c->slotted) {
@@ -353,7 +357,9 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
     const SlotRef ref = stream_ref(c);
     const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0);
+                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, c->d_rowmax, c->d_mat,
+                       c->rows_in_select ? c->d_dirty_list : (uint32_t *)nullptr, c->d_dirty_n);
+    c->rows_in_select = false;
     LAUNCHCHK(c, "k_select");
     if (space > TIE_WINDOW0) {
         hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(space - TIE_WINDOW0, 256, c->num_cus * 4)),
@@ -382,7 +388,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         if (with_delta)
             hipLaunchKernelGGL(k_merge_lookback<true>, dim3(grid), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
-                               c->d_gdesc, c->epoch, newid, c->d_delta, c->vcap, rec, iter, c->d_dirty_n, c->lb_tune);
+                               c->d_gdesc, c->epoch, newid, c->d_delta, vcap_rep(c), rec, iter, c->d_dirty_n, c->lb_tune);
         else
             hipLaunchKernelGGL(k_merge_lookback<false>, dim3(grid), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
@@ -402,7 +408,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         if (with_delta)
             hipLaunchKernelGGL(k_merge_scatter<true>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
-                               c->d_tile_off, c->d_tile_sin, newid, c->d_delta, c->vcap);
+                               c->d_tile_off, c->d_tile_sin, newid, c->d_delta, vcap_rep(c));
         else
             hipLaunchKernelGGL(k_merge_scatter<false>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
                                c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
@@ -414,12 +420,12 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
     if (with_delta && c->dp_active) {
         // sharded: fold the replicas into the all-reduce payload; bpe_dp_apply does the rest
         hipLaunchKernelGGL(k_dp_fold, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta,
-                           c->vcap, newid, c->d_dp_folded);
+                           vcap_rep(c), newid, c->d_dp_folded);
         LAUNCHCHK(c, "k_dp_fold");
     } else if (with_delta) {
         TRY(prof_begin(c, BPE_PROF_TABLE, 0));
         hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
+                           c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
                            c->d_dirty_list, c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
         LAUNCHCHK(c, "k_apply_delta");
         hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap,
@@ -477,21 +483,24 @@ int slots_leave(bpe_ctx *c) {
 // one slotted merge pass + table update (delta mode only)
 int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
+        c->epoch++;
+    }
     hipLaunchKernelGGL(k_merge_slot<true>, dim3((unsigned)std::max<uint64_t>(c->slot_T, 1)), dim3(MT), 0,
                        c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
-                       c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, c->vcap,
-                       c->d_dirty_n);
+                       c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, vcap_rep(c),
+                       c->d_dirty_n, c->d_desc, c->epoch);
     LAUNCHCHK(c, "k_merge_slot");
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
-                       c->d_mat, c->vcap, c->d_delta, c->vcap, c->d_rowmax, c->d_st, newid,
+                       c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
                        c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, 1);
     LAUNCHCHK(c, "k_apply_delta");
-    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, newid + 1,
-                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
-    LAUNCHCHK(c, "k_rowmax_list");
     TRY(prof_end(c));
+    c->rows_in_select = true;  // the queued rows are recomputed by the next k_select
     c->par ^= 1;
     c->mq ^= 1;
     c->stats_valid = false;
@@ -864,6 +873,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     uint64_t cur_len = n0;  // exact length before iteration `consumed`
     bool stop = false;
     int samepair_at = -1;
+    c->rep_shift = 5;
+    c->rows_in_select = false;
     const bool slots = delta && c->use_slots && c->merge_impl == 0;
     if (slots) TRY(slots_enter(c));
     // The device writes one IterRec per iteration into pinned host memory; the
@@ -909,6 +920,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         cur_len = r->new_len;
         c->n = cur_len;  // tighter launch bound for what is enqueued next
+        // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
+        c->rep_shift = r->count > 400000 ? 5 : r->count > 50000 ? 3 : r->count > 5000 ? 1 : 0;
         done = j + 1;
         return BPE_OK;
     };
@@ -958,6 +971,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 TRY(slots_leave(c));
                 c->vcur = 256u + (uint32_t)j;
                 c->n = cur_len;
+                c->rows_in_select = false;
                 TRY(launch_merge(c, 256u + (uint32_t)j, j, c->h_rec, true));
                 TRY(slots_enter(c));
                 i = j + 1;

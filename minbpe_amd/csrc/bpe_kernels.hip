@@ -296,12 +296,43 @@ __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint
 // rest of the stream is k_tiebreak's job.
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist) {
+         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist, uint32_t *__restrict__ rowmax_w,
+         uint32_t *__restrict__ mat_w, const uint32_t *__restrict__ dirty_list,
+         const uint32_t *__restrict__ dirty_n) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
     __shared__ int32_t s_tied[2 * TIE_CAP];
     if (st->status) return;
+    if (dirty_list) {
+        // rows whose maximum may have dropped in the last table update (k_apply_delta queued
+        // them): recompute here instead of in a kernel of their own.  Also retires the merged
+        // pair: after the merge no (a,b) remains (F2), whatever the a == b bookkeeping left.
+        const uint32_t nd = *dirty_n, fa = (uint32_t)st->fin_a, fb = (uint32_t)st->fin_b;
+        for (uint32_t i = 0; i < nd; i++) {
+            const uint32_t x = dirty_list[i];
+            uint32_t *row = mat_w + (size_t)x * stride;
+            uint32_t mm = 0;
+            for (uint32_t y = threadIdx.x; y < vcur; y += 1024) {
+                uint32_t v = row[y];
+                if (x == fa && y == fb) {
+                    v = 0;
+                    row[y] = 0;
+                }
+                mm = max(mm, v);
+            }
+            mm = wave_max_u32(mm);
+            __syncthreads();
+            if (lane_id() == 0) s_red[wave_id()] = mm;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t M = 0;
+                for (int w = 0; w < 16; w++) M = max(M, s_red[w]);
+                rowmax_w[x] = M;
+            }
+        }
+        __syncthreads();
+    }
     uint32_t m = 0;
     for (uint32_t x = threadIdx.x; x < vcur; x += 1024) m = max(m, rowmax[x]);
     m = wave_max_u32(m);
@@ -356,6 +387,26 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (nt > 1) {  // tie: first window, positions ascending per thread
         const uint64_t n = st->n[par];
         const uint32_t hi = (uint32_t)min((uint64_t)TIE_WINDOW0, slot_space(ref, n));
+        if (ref.meta) {
+            // slot by slot: one meta lookup per slot, coalesced reads inside it
+            for (uint32_t u = 0; u < hi / TILE + 1 && (uint64_t)u < ref.T; u++) {
+                if (__atomic_load_n(&s_first, __ATOMIC_RELAXED) != 0xFFFFFFFFu) break;  // earlier slot hit
+                const uint32_t mu = ref.meta[u];
+                const uint32_t len = mu & 0x7FFFFFFFu;
+                const uint32_t *src = ((mu >> 31) ? ref.b1 : ref.b0) + (size_t)u * TILE;
+                for (uint32_t q = threadIdx.x; q < len; q += 1024) {
+                    uint32_t w1;
+                    if (q + 1 < len) w1 = src[q + 1];
+                    else if (!slot_next(ref, n, (uint64_t)u * TILE + q, w1)) continue;
+                    if (w1 & FLAG) continue;
+                    if (tie_hit(s_tied, nt, M, mat, stride, src[q] & IDMASK, w1)) {
+                        atomicMin(&s_first, u * TILE + q);
+                        break;
+                    }
+                }
+                __syncthreads();
+            }
+        } else
         for (uint32_t p = threadIdx.x; p < hi; p += 1024) {
             if (__atomic_load_n(&s_first, __ATOMIC_RELAXED) < p) break;  // an earlier hit exists
             uint32_t w0, w1;
@@ -520,17 +571,32 @@ __device__ __forceinline__ void tile_fetch(Tile &t, const uint32_t *__restrict__
 
 // fetch slot `src` holding `len` owned ids, followed (in stream order) by the
 // three words halo[0..2] that belong to later slots (INVALID_WORD at the end of
-// the stream).  Positions >= len + 3 are INVALID_WORD.
-__device__ __forceinline__ void tile_fetch_slot(Tile &t, const uint32_t *__restrict__ src, int len,
-                                                const uint32_t *halo) {
-    const int lane = lane_id(), wave = wave_id();
-    const int wrel = wave * WAVE_SPAN;
+// the stream).  Positions >= len + 3 are INVALID_WORD.  Two steps, so that the
+// slot's own loads are in flight while thread 0 looks the neighbours up.
+struct SlotRaw {
+    uint4 v[MJ];
+    uint32_t tail[3];
+};
+__device__ __forceinline__ void slot_raw_load(SlotRaw &r, const uint32_t *__restrict__ src, int len) {
+    const int lane = lane_id(), wrel = wave_id() * WAVE_SPAN;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const int q0 = wrel + j * 256 + lane * 4;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q0 < len) v = *reinterpret_cast<const uint4 *>(src + q0);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        r.v[j] = make_uint4(0, 0, 0, 0);
+        if (q0 < len) r.v[j] = *reinterpret_cast<const uint4 *>(src + q0);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int q = wrel + WAVE_SPAN + i;
+        r.tail[i] = (q < len) ? src[q] : 0u;
+    }
+}
+__device__ __forceinline__ void tile_from_slot(Tile &t, const SlotRaw &r, int len, const uint32_t *halo) {
+    const int lane = lane_id(), wrel = wave_id() * WAVE_SPAN;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const int q0 = wrel + j * 256 + lane * 4;
+        const uint32_t w[4] = {r.v[j].x, r.v[j].y, r.v[j].z, r.v[j].w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int q = q0 + k;
@@ -540,7 +606,7 @@ __device__ __forceinline__ void tile_fetch_slot(Tile &t, const uint32_t *__restr
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int q = wrel + WAVE_SPAN + i;
-        t.tail[i] = (q < len) ? src[q] : ((q < len + 3) ? halo[q - len] : INVALID_WORD);
+        t.tail[i] = (q < len) ? r.tail[i] : ((q < len + 3) ? halo[q - len] : INVALID_WORD);
     }
 }
 
@@ -901,7 +967,9 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         near |= (uint32_t)((((t0 & IDMASK) == a) & (t1 == b)) | (((t1 & IDMASK) == a) & (t2 == b)));
         if (!__any(near != 0)) return;
         // same-address atomics serialise (~11 ns each): spread them over replicas
-        delta += (size_t)(blockIdx.x & (DELTA_REPL - 1)) * 4 * vcap;
+        const uint32_t nrep = 1u << (vcap >> 24);  // host packs log2(replicas) above the stride
+        vcap &= 0xFFFFFFu;
+        delta += (size_t)(blockIdx.x & (nrep - 1)) * 4 * vcap;
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             const uint32_t nb_m = (uint32_t)__shfl((int)mb[j], (lane + 1) & 63);
@@ -1305,10 +1373,11 @@ __global__ void __launch_bounds__(MT)
 k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, uint32_t *__restrict__ w0,
              uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
              uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
-             uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n) {
+             uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n,
+             unsigned long long *__restrict__ sdesc, uint32_t epoch) {
     __shared__ int s_wave[MT / 64];
     __shared__ uint32_t s_wsum[MT / 64];
-    __shared__ uint32_t s_ctx[4];  // halo[0..2], previous slot's last word
+    __shared__ uint32_t s_ctx[6];  // halo[0..2], previous slot's last word, my first word, carry (a == b)
     const uint64_t t = blockIdx.x;
     if (t == 0 && threadIdx.x == 0 && dirty_n) *dirty_n = 0;
     if (t >= T || st->status) return;
@@ -1320,10 +1389,6 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
     uint32_t a, b;
     if (!resolved_pair(st, ref, 0, a, b)) {
         if (t == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
-        return;
-    }
-    if (a == b) {  // needs cross-slot run parity: the host takes the contiguous path
-        if (t == 0 && threadIdx.x == 0) st->status = ST_SAMEPAIR;
         return;
     }
     const uint32_t mi = meta_in[t];
@@ -1338,6 +1403,8 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
     }
     const uint32_t cur = mi >> 31;
     const uint32_t *src = (cur ? b1 : b0) + t * TILE;
+    SlotRaw raw;
+    slot_raw_load(raw, src, len);  // in flight during the neighbour lookup below
     if (threadIdx.x == 0) {
         // the three words after my slot, and the word before it, in stream order
         uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
@@ -1361,16 +1428,85 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
         s_ctx[1] = h[1];
         s_ctx[2] = h[2];
         s_ctx[3] = prev;
+        s_ctx[4] = raw.v[0].x;  // my first word (lane 0 of wave 0 holds it; len > 0)
     }
     __syncthreads();
     const uint32_t halo[3] = {s_ctx[0], s_ctx[1], s_ctx[2]};
     const uint32_t prev = s_ctx[3];
+    const uint32_t s_first_word = s_ctx[4];
     Tile tl;
-    tile_fetch_slot(tl, src, len, halo);
+    tile_from_slot(tl, raw, len, halo);
     tile_prepare(tl, a, b, s_wave);
     // carry: the previous slot ended with a site start iff its last id is a and my first word is b
-    const uint32_t first = src[0];
-    const uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (first == b));
+    // (thread 0 stored my first word next to the neighbours' in s_ctx)
+    uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (s_first_word == b));
+    if (a == b) {
+        // a == b: the carry is the PARITY of the run of a's that ends at the previous slot's
+        // last id (F2).  Walk that run backwards, 64 ids per step; only if it swallows the whole
+        // previous slot does this tile need that slot's own carry (published below by every
+        // tile; tiles are dispatched in order, so the wait is on a running or finished tile).
+        const unsigned long long tag = ((unsigned long long)(epoch & EPOCH_MASK)) << 42;
+        if (wave_id() == 0) {
+            const int lane = lane_id();
+            uint32_t sc = 0;
+            bool failed = false;
+            if (s) {  // the boundary pair matches: r[last of previous slot] = 1
+                uint64_t u = t;
+                uint32_t mu = 0;
+                while (u-- > 0) {
+                    mu = meta_in[u];
+                    if (mu & 0x7FFFFFFFu) break;
+                }
+                const int lu = (int)(mu & 0x7FFFFFFFu);
+                const uint32_t *pu = ((mu >> 31) ? b1 : b0) + u * TILE;
+                int ones = 0;       // r-ones counted so far, walking back from the last id
+                bool open = true;   // no zero met yet
+                uint32_t nextw = s_first_word;  // the word after the current position
+                for (int base = lu - 1; base >= 0 && open; base -= 64) {
+                    const int q = base - lane;
+                    const uint32_t xq = (q >= 0) ? pu[q] : INVALID_WORD;
+                    uint32_t nx = (uint32_t)__shfl_up((int)xq, 1);
+                    if (lane == 0) nx = nextw;
+                    const bool r = (q >= 0) && ((xq & IDMASK) == a) && (nx == a);
+                    const unsigned long long zeros = __ballot(!r);
+                    if (zeros) {
+                        ones += __ffsll((long long)zeros) - 1;
+                        // a zero caused by running off the slot (q < 0) means the whole slot is ones
+                        const int zl = __ffsll((long long)zeros) - 1;
+                        open = (base - zl < 0);
+                        break;
+                    }
+                    ones += 64;
+                    nextw = (uint32_t)__shfl((int)xq, 63);
+                }
+                if (!open || ones < lu) {
+                    sc = (uint32_t)(ones & 1);  // m[last] = r[last] & (run length odd)
+                } else {
+                    // the whole previous slot is one run: m[q] = (q even) ^ its carry
+                    uint32_t su = 0;
+                    bool got = false;
+                    for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
+                        const unsigned long long d = desc_load(&sdesc[u]);
+                        if ((d >> 42) == (tag >> 42) + (1ull << 20)) {  // status bit above the epoch
+                            su = (uint32_t)(d & 1u);
+                            got = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    failed = !got;
+                    sc = (uint32_t)(((lu - 1) & 1) == 0) ^ su;
+                }
+            }
+            if (lane == 0) {
+                s_ctx[5] = sc;
+                desc_store(&sdesc[t], tag | (1ull << 62) | sc);
+                if (failed) atomicExch(&st->status, ST_LOOKBACK);
+            }
+        }
+        __syncthreads();
+        s = s_ctx[5];
+    }
     uint32_t kept = 0;
     bool changed = false;
     uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
@@ -1440,21 +1576,26 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     if (t > Z) return;
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     uint32_t acc4[4] = {0, 0, 0, 0};
+    const uint32_t nrep = 1u << (vcap >> 24);
+    vcap &= 0xFFFFFFu;
     if (FOLDED) {
 #pragma unroll
         for (int v = 0; v < 4; v++) acc4[v] = delta[(size_t)v * vcap + t];
     } else {
 #pragma unroll
-    for (int v = 0; v < 4; v++) {
-        uint32_t x[DELTA_REPL];
+        for (int v = 0; v < 4; v++) {
+            for (uint32_t r0 = 0; r0 < nrep; r0 += 8) {  // up to 8 loads in flight
+                uint32_t x[8];
 #pragma unroll
-        for (int r = 0; r < DELTA_REPL; r++) x[r] = delta[((size_t)r * 4 + v) * vcap + t];
+                for (int r = 0; r < 8; r++)
+                    x[r] = (r0 + r < nrep) ? delta[((size_t)(r0 + r) * 4 + v) * vcap + t] : 0u;
 #pragma unroll
-        for (int r = 0; r < DELTA_REPL; r++) {
-            if (x[r]) delta[((size_t)r * 4 + v) * vcap + t] = 0;
-            acc4[v] += x[r];
+                for (int r = 0; r < 8; r++) {
+                    if (x[r]) delta[((size_t)(r0 + r) * 4 + v) * vcap + t] = 0;
+                    acc4[v] += x[r];
+                }
+            }
         }
-    }
     }
     const uint32_t dl = acc4[0], dr = acc4[1], il = acc4[2], ir = acc4[3];
     bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
@@ -1544,19 +1685,18 @@ __global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
 // fold the replicated delta vectors into one compact 4 x vcap buffer (the SUM all-reduce payload)
 __global__ void __launch_bounds__(256)
 k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__restrict__ folded) {
+    const uint32_t nrep = 1u << (vcap >> 24);
+    vcap &= 0xFFFFFFu;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= vcap) return;
 #pragma unroll
     for (int v = 0; v < 4; v++) {
         uint32_t acc = 0;
         if (t <= Z) {
-            uint32_t x[DELTA_REPL];
-#pragma unroll
-            for (int r = 0; r < DELTA_REPL; r++) x[r] = delta[((size_t)r * 4 + v) * vcap + t];
-#pragma unroll
-            for (int r = 0; r < DELTA_REPL; r++) {
-                if (x[r]) delta[((size_t)r * 4 + v) * vcap + t] = 0;
-                acc += x[r];
+            for (uint32_t r = 0; r < nrep; r++) {
+                const uint32_t x = delta[((size_t)r * 4 + v) * vcap + t];
+                if (x) delta[((size_t)r * 4 + v) * vcap + t] = 0;
+                acc += x;
             }
         }
         folded[(size_t)v * vcap + t] = acc;
