@@ -75,6 +75,7 @@ struct bpe_ctx {
     uint64_t slot_T = 0;
     int mq = 0;
     uint32_t *d_meta[2] = {nullptr, nullptr};
+    uint4 *d_hdr[2] = {nullptr, nullptr};  // per slot: first three words, last word
     uint32_t *d_slot_lens = nullptr;
     unsigned long long *d_slot_off = nullptr, *d_slot_bsum = nullptr;
     uint32_t *d_ids2 = nullptr;  // third stream buffer: target of compactions
@@ -173,6 +174,8 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_tile_sin, nt));
         TRY(dev_realloc(c, c->d_meta[0], nt));
         TRY(dev_realloc(c, c->d_meta[1], nt));
+        TRY(dev_realloc(c, c->d_hdr[0], nt));
+        TRY(dev_realloc(c, c->d_hdr[1], nt));
         TRY(dev_realloc(c, c->d_slot_lens, nt));
         TRY(dev_realloc(c, c->d_slot_off, nt + 1));
         TRY(dev_realloc(c, c->d_slot_bsum, nt / SCAN_TILE + 2));
@@ -357,9 +360,7 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
     const SlotRef ref = stream_ref(c);
     const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
     hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, c->d_rowmax, c->d_mat,
-                       c->rows_in_select ? c->d_dirty_list : (uint32_t *)nullptr, c->d_dirty_n);
-    c->rows_in_select = false;
+                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0);
     LAUNCHCHK(c, "k_select");
     if (space > TIE_WINDOW0) {
         hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(space - TIE_WINDOW0, 256, c->num_cus * 4)),
@@ -446,8 +447,8 @@ int slots_enter(bpe_ctx *c) {
     c->slot_T = ntiles_of(c->n);
     c->mq = 0;
     hipLaunchKernelGGL(k_slot_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
-                       dim3(256), 0, c->stream, c->d_meta[0], c->slot_T, c->d_st, c->par,
-                       (uint32_t)c->par);
+                       dim3(256), 0, c->stream, c->d_meta[0], c->d_hdr[0], c->slot_T, c->d_st, c->par,
+                       (uint32_t)c->par, c->d_ids[c->par]);
     LAUNCHCHK(c, "k_slot_init");
     c->slotted = true;
     return BPE_OK;
@@ -491,7 +492,7 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     hipLaunchKernelGGL(k_merge_slot<true>, dim3((unsigned)std::max<uint64_t>(c->slot_T, 1)), dim3(MT), 0,
                        c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
                        c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, vcap_rep(c),
-                       c->d_dirty_n, c->d_desc, c->epoch);
+                       c->d_dirty_n, c->d_desc, c->epoch, c->d_hdr[c->mq], c->d_hdr[c->mq ^ 1]);
     LAUNCHCHK(c, "k_merge_slot");
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
@@ -499,8 +500,10 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
                        c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
                        c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, 1);
     LAUNCHCHK(c, "k_apply_delta");
+    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, newid + 1,
+                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    LAUNCHCHK(c, "k_rowmax_list");
     TRY(prof_end(c));
-    c->rows_in_select = true;  // the queued rows are recomputed by the next k_select
     c->par ^= 1;
     c->mq ^= 1;
     c->stats_valid = false;
@@ -572,7 +575,7 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc, c->d_enc_tmp, c->d_enc_len, c->d_enc_out,
                     c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids,
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
-                    c->d_slot_off, c->d_slot_bsum, c->d_ids2};
+                    c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);

@@ -296,43 +296,12 @@ __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint
 // rest of the stream is k_tiebreak's job.
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist, uint32_t *__restrict__ rowmax_w,
-         uint32_t *__restrict__ mat_w, const uint32_t *__restrict__ dirty_list,
-         const uint32_t *__restrict__ dirty_n) {
+         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
     __shared__ int32_t s_tied[2 * TIE_CAP];
     if (st->status) return;
-    if (dirty_list) {
-        // rows whose maximum may have dropped in the last table update (k_apply_delta queued
-        // them): recompute here instead of in a kernel of their own.  Also retires the merged
-        // pair: after the merge no (a,b) remains (F2), whatever the a == b bookkeeping left.
-        const uint32_t nd = *dirty_n, fa = (uint32_t)st->fin_a, fb = (uint32_t)st->fin_b;
-        for (uint32_t i = 0; i < nd; i++) {
-            const uint32_t x = dirty_list[i];
-            uint32_t *row = mat_w + (size_t)x * stride;
-            uint32_t mm = 0;
-            for (uint32_t y = threadIdx.x; y < vcur; y += 1024) {
-                uint32_t v = row[y];
-                if (x == fa && y == fb) {
-                    v = 0;
-                    row[y] = 0;
-                }
-                mm = max(mm, v);
-            }
-            mm = wave_max_u32(mm);
-            __syncthreads();
-            if (lane_id() == 0) s_red[wave_id()] = mm;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                uint32_t M = 0;
-                for (int w = 0; w < 16; w++) M = max(M, s_red[w]);
-                rowmax_w[x] = M;
-            }
-        }
-        __syncthreads();
-    }
     uint32_t m = 0;
     for (uint32_t x = threadIdx.x; x < vcur; x += 1024) m = max(m, rowmax[x]);
     m = wave_max_u32(m);
@@ -906,7 +875,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                                              uint32_t newid, uint32_t *__restrict__ dst_tile,
                                              uint32_t *s_wsum, uint32_t *__restrict__ delta,
                                              uint32_t vcap, int own_len, uint32_t *kept_out,
-                                             bool *changed_out) {
+                                             bool *changed_out, uint32_t *__restrict__ hdr4 = nullptr) {
     const int lane = lane_id(), wave = wave_id();
     uint32_t mb[MJ], mp[MJ], kb[MJ], ex[MJ];
     uint32_t carry = 0, chg = 0;
@@ -951,7 +920,13 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
             for (int k = 0; k < 4; k++) {
                 if ((kb[j] >> k) & 1u) {
                     const uint32_t w = t.x[j][k];
-                    dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                    const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                    if (hdr4) {  // the slot's first three and last output words (neighbours read them)
+                        const uint32_t gi = wbase + o;
+                        if (gi < 3) hdr4[gi] = ow;
+                        if (gi + 1 == total) hdr4[3] = ow;
+                    }
+                    dst[o++] = ow;
                 }
             }
         }
@@ -1357,14 +1332,20 @@ k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, De
 // last id is a and my first word is b.
 
 __global__ void __launch_bounds__(256)
-k_slot_init(uint32_t *__restrict__ meta, uint64_t T, const DevState *__restrict__ st, int par,
-            uint32_t which) {
+k_slot_init(uint32_t *__restrict__ meta, uint4 *__restrict__ hdr, uint64_t T,
+            const DevState *__restrict__ st, int par, uint32_t which, const uint32_t *__restrict__ ids) {
     const uint64_t n = st->n[par];
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride) {
         const uint64_t b0 = t * TILE;
         const uint32_t len = b0 >= n ? 0u : (uint32_t)min((uint64_t)TILE, n - b0);
         meta[t] = len | (which << 31);
+        uint4 h = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD);
+        if (len > 0) h.x = ids[b0];
+        if (len > 1) h.y = ids[b0 + 1];
+        if (len > 2) h.z = ids[b0 + 2];
+        if (len > 0) h.w = ids[b0 + len - 1];
+        hdr[t] = h;
     }
 }
 
@@ -1374,10 +1355,11 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
              uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
              uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
              uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n,
-             unsigned long long *__restrict__ sdesc, uint32_t epoch) {
+             unsigned long long *__restrict__ sdesc, uint32_t epoch, const uint4 *__restrict__ hdr_in,
+             uint4 *__restrict__ hdr_out) {
     __shared__ int s_wave[MT / 64];
     __shared__ uint32_t s_wsum[MT / 64];
-    __shared__ uint32_t s_ctx[6];  // halo[0..2], previous slot's last word, my first word, carry (a == b)
+    __shared__ uint32_t s_ctx[9];  // halo[0..2], previous last word, my header x, carry (a == b), my header y z w
     const uint64_t t = blockIdx.x;
     if (t == 0 && threadIdx.x == 0 && dirty_n) *dirty_n = 0;
     if (t >= T || st->status) return;
@@ -1398,38 +1380,68 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
         st->fin_b = (int32_t)b;
     }
     if (len == 0) {
-        if (threadIdx.x == 0) meta_out[t] = mi;
+        if (threadIdx.x == 0) {
+            meta_out[t] = mi;
+            hdr_out[t] = hdr_in[t];
+        }
         return;
     }
     const uint32_t cur = mi >> 31;
     const uint32_t *src = (cur ? b1 : b0) + t * TILE;
-    SlotRaw raw;
-    slot_raw_load(raw, src, len);  // in flight during the neighbour lookup below
     if (threadIdx.x == 0) {
-        // the three words after my slot, and the word before it, in stream order
-        uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
-        int got = 0;
-        for (uint64_t u = t + 1; u < T && got < 3; u++) {
-            const uint32_t mu = meta_in[u];
-            const uint32_t lu = mu & 0x7FFFFFFFu;
-            const uint32_t *pu = ((mu >> 31) ? b1 : b0) + u * TILE;
-            for (uint32_t i = 0; i < lu && got < 3; i++) h[got++] = pu[i];
+        // The three words after my slot and the word before it, in stream order.  Every slot
+        // keeps {first three words, last word} in a header array, so in the common case these
+        // are independent loads that fly together with the slot's own; only a neighbour with
+        // fewer than 3 ids sends us walking.
+        const uint4 hme = hdr_in[t];
+        uint32_t mn = 0, mp = 0;
+        uint4 hn = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD), hp = hn;
+        if (t + 1 < T) {
+            mn = meta_in[t + 1];
+            hn = hdr_in[t + 1];
         }
-        uint32_t prev = INVALID_WORD;
-        for (uint64_t u = t; u-- > 0;) {
-            const uint32_t mu = meta_in[u];
-            const uint32_t lu = mu & 0x7FFFFFFFu;
-            if (lu) {
-                prev = (((mu >> 31) ? b1 : b0) + u * TILE)[lu - 1];
-                break;
+        if (t > 0) {
+            mp = meta_in[t - 1];
+            hp = hdr_in[t - 1];
+        }
+        uint32_t h0 = hn.x, h1 = hn.y, h2 = hn.z;
+        if (t + 1 < T && (mn & 0x7FFFFFFFu) < 3) {  // rare: gather across short / empty slots
+            h0 = h1 = h2 = INVALID_WORD;
+            int got = 0;
+            for (uint64_t u = t + 1; u < T && got < 3; u++) {
+                const uint32_t mu = meta_in[u];
+                const uint32_t lu = mu & 0x7FFFFFFFu;
+                const uint32_t *pu = ((mu >> 31) ? b1 : b0) + u * TILE;
+                for (uint32_t i = 0; i < lu && got < 3; i++) {
+                    const uint32_t w = pu[i];
+                    if (got == 0) h0 = w; else if (got == 1) h1 = w; else h2 = w;
+                    got++;
+                }
             }
         }
-        s_ctx[0] = h[0];
-        s_ctx[1] = h[1];
-        s_ctx[2] = h[2];
+        uint32_t prev = hp.w;
+        if (t > 0 && (mp & 0x7FFFFFFFu) == 0) {  // rare: previous slot is empty
+            prev = INVALID_WORD;
+            for (uint64_t u = t; u-- > 0;) {
+                const uint32_t mu = meta_in[u];
+                const uint32_t lu = mu & 0x7FFFFFFFu;
+                if (lu) {
+                    prev = (((mu >> 31) ? b1 : b0) + u * TILE)[lu - 1];
+                    break;
+                }
+            }
+        }
+        s_ctx[0] = h0;
+        s_ctx[1] = h1;
+        s_ctx[2] = h2;
         s_ctx[3] = prev;
-        s_ctx[4] = raw.v[0].x;  // my first word (lane 0 of wave 0 holds it; len > 0)
+        s_ctx[4] = hme.x;  // my first word (len > 0)
+        s_ctx[6] = hme.y;
+        s_ctx[7] = hme.z;
+        s_ctx[8] = hme.w;
     }
+    SlotRaw raw;
+    slot_raw_load(raw, src, len);
     __syncthreads();
     const uint32_t halo[3] = {s_ctx[0], s_ctx[1], s_ctx[2]};
     const uint32_t prev = s_ctx[3];
@@ -1510,13 +1522,17 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
     uint32_t kept = 0;
     bool changed = false;
     uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
-    tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed);
+    uint32_t *my_hdr = reinterpret_cast<uint32_t *>(hdr_out + t);
+    tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed, my_hdr);
     if (threadIdx.x == 0) {
         if (changed) {
             meta_out[t] = kept | ((cur ^ 1u) << 31);
             atomicAdd(&st->removed, (unsigned long long)((uint32_t)len - kept));
+            for (uint32_t i = kept; i < 3; i++) my_hdr[i] = INVALID_WORD;  // fewer than 3 ids left
+            if (kept == 0) my_hdr[3] = INVALID_WORD;
         } else {
             meta_out[t] = mi;
+            hdr_out[t] = make_uint4(s_ctx[4], s_ctx[6], s_ctx[7], s_ctx[8]);
         }
     }
 }
