@@ -425,7 +425,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         LAUNCHCHK(c, "k_dp_fold");
     } else if (with_delta) {
         TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-        hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 31) / 32), dim3(256), 0, c->stream,
                            c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
                            c->d_dirty_list, c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
         LAUNCHCHK(c, "k_apply_delta");
@@ -496,7 +496,7 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     LAUNCHCHK(c, "k_merge_slot");
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-    hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 255) / 256), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 31) / 32), dim3(256), 0, c->stream,
                        c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
                        c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, 1);
     LAUNCHCHK(c, "k_apply_delta");
@@ -924,7 +924,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         cur_len = r->new_len;
         c->n = cur_len;  // tighter launch bound for what is enqueued next
         // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
-        c->rep_shift = r->count > 400000 ? 5 : r->count > 50000 ? 3 : r->count > 5000 ? 1 : 0;
+        // few sites -> few same-address atomics -> fewer replicas to fold (measured: going
+        // below 32 while a pass still has tens of thousands of sites slows the merge pass)
+        c->rep_shift = r->count > 12000 ? 5 : r->count > 3000 ? 3 : r->count > 800 ? 1 : 0;
         done = j + 1;
         return BPE_OK;
     };
@@ -1306,7 +1308,7 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t Z = 256u + (uint32_t)iter;
-    hipLaunchKernelGGL(k_apply_delta<true>, dim3((Z + 1 + 255) / 256), dim3(256), 0, c->stream, c->d_mat,
+    hipLaunchKernelGGL(k_apply_delta<true>, dim3((Z + 1 + 31) / 32), dim3(256), 0, c->stream, c->d_mat,
                        c->vcap, c->d_dp_folded, c->vcap, c->d_rowmax, c->d_st, Z, c->d_dirty_list,
                        c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
     LAUNCHCHK(c, "k_apply_delta");

@@ -1588,31 +1588,44 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
         }
     }
     if (st->status) return;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > Z) return;
+    // 8 lanes per token: each folds a quarter of the replicas (all its loads in flight at
+    // once), then a 3-step shuffle sum.  The kernel is latency-bound, so width, not work, counts.
+    const uint32_t g = threadIdx.x & 7u;
+    const uint32_t t = blockIdx.x * (blockDim.x / 8) + (threadIdx.x >> 3);
+    const bool live = t <= Z;
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     uint32_t acc4[4] = {0, 0, 0, 0};
     const uint32_t nrep = 1u << (vcap >> 24);
     vcap &= 0xFFFFFFu;
     if (FOLDED) {
+        if (live && g == 0) {
 #pragma unroll
-        for (int v = 0; v < 4; v++) acc4[v] = delta[(size_t)v * vcap + t];
-    } else {
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-            for (uint32_t r0 = 0; r0 < nrep; r0 += 8) {  // up to 8 loads in flight
-                uint32_t x[8];
-#pragma unroll
-                for (int r = 0; r < 8; r++)
-                    x[r] = (r0 + r < nrep) ? delta[((size_t)(r0 + r) * 4 + v) * vcap + t] : 0u;
-#pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    if (x[r]) delta[((size_t)(r0 + r) * 4 + v) * vcap + t] = 0;
-                    acc4[v] += x[r];
-                }
-            }
+            for (int v = 0; v < 4; v++) acc4[v] = delta[(size_t)v * vcap + t];
         }
+    } else if (live) {
+        uint32_t x[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const uint32_t r = g + 8u * k;
+                x[k][v] = (r < nrep) ? delta[((size_t)r * 4 + v) * vcap + t] : 0u;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if (x[k][v]) delta[((size_t)(g + 8u * k) * 4 + v) * vcap + t] = 0;
+                acc4[v] += x[k][v];
+            }
     }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 1);
+        acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 2);
+        acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 4);
+    }
+    if (!live || g != 0) return;
     const uint32_t dl = acc4[0], dr = acc4[1], il = acc4[2], ir = acc4[3];
     bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
     if (dl) {
