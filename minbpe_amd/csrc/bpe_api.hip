@@ -926,7 +926,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
         // few sites -> few same-address atomics -> fewer replicas to fold (measured: going
         // below 32 while a pass still has tens of thousands of sites slows the merge pass)
-        c->rep_shift = r->count > 12000 ? 5 : r->count > 3000 ? 3 : r->count > 800 ? 1 : 0;
+        c->rep_shift = 5;  // (k_apply_delta folds 32 replicas with 16 loads in flight per lane: no need to shrink)
         done = j + 1;
         return BPE_OK;
     };
@@ -942,8 +942,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 TRY(launch_pair_count(c, false));
                 full_rowmax = true;
             }
-            // slots running low: re-pack (between merges nothing is pending)
-            if (c->slotted && c->slot_T > 64 && c->n * 2 < c->slot_T * (uint64_t)TILE) {
+            // Slots thinning out: re-pack (between merges nothing is pending).  A pass costs
+            // per slot as much as per id, so the slot count should follow the stream length
+            // closely; at 7/8 fill a whole run re-packs only ~log(N0/N)/log(8/7) ~ a dozen times.
+            if (c->slotted && c->slot_T > 64 && c->n * 8 < c->slot_T * (uint64_t)TILE * 7) {
                 TRY(slots_leave(c));
                 TRY(slots_enter(c));
             }

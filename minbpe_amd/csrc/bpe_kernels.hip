@@ -920,13 +920,29 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
             for (int k = 0; k < 4; k++) {
                 if ((kb[j] >> k) & 1u) {
                     const uint32_t w = t.x[j][k];
-                    const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
-                    if (hdr4) {  // the slot's first three and last output words (neighbours read them)
-                        const uint32_t gi = wbase + o;
-                        if (gi < 3) hdr4[gi] = ow;
-                        if (gi + 1 == total) hdr4[3] = ow;
+                    dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                }
+            }
+        }
+        if (hdr4) {
+            // the slot's first three and last output words (the neighbours' context next
+            // pass).  Kept out of the store loop above: only the first and the last writer
+            // of the tile ever get here.
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {
+                const uint32_t lo = wbase + ex[j], hi = lo + __popc(kb[j]);
+                if (kb[j] && (lo < 3 || hi == total)) {
+                    uint32_t gi = lo;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if ((kb[j] >> k) & 1u) {
+                            const uint32_t w = t.x[j][k];
+                            const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                            if (gi < 3) hdr4[gi] = ow;
+                            if (gi + 1 == total) hdr4[3] = ow;
+                            gi++;
+                        }
                     }
-                    dst[o++] = ow;
                 }
             }
         }
@@ -1440,9 +1456,15 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
         s_ctx[7] = hme.z;
         s_ctx[8] = hme.w;
     }
+#ifndef BPE_EXP_LATE_LOAD
     SlotRaw raw;
     slot_raw_load(raw, src, len);
     __syncthreads();
+#else
+    __syncthreads();
+    SlotRaw raw;
+    slot_raw_load(raw, src, len);
+#endif
     const uint32_t halo[3] = {s_ctx[0], s_ctx[1], s_ctx[2]};
     const uint32_t prev = s_ctx[3];
     const uint32_t s_first_word = s_ctx[4];
@@ -1452,6 +1474,7 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
     // carry: the previous slot ended with a site start iff its last id is a and my first word is b
     // (thread 0 stored my first word next to the neighbours' in s_ctx)
     uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (s_first_word == b));
+#ifndef BPE_EXP_NO_AEQB
     if (a == b) {
         // a == b: the carry is the PARITY of the run of a's that ends at the previous slot's
         // last id (F2).  Walk that run backwards, 64 ids per step; only if it swallows the whole
@@ -1519,11 +1542,16 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
         __syncthreads();
         s = s_ctx[5];
     }
+#endif
     uint32_t kept = 0;
     bool changed = false;
     uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
     uint32_t *my_hdr = reinterpret_cast<uint32_t *>(hdr_out + t);
+#ifdef BPE_EXP_NO_HDR4
+    tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed, nullptr);
+#else
     tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed, my_hdr);
+#endif
     if (threadIdx.x == 0) {
         if (changed) {
             meta_out[t] = kept | ((cur ^ 1u) << 31);
