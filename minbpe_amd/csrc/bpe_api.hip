@@ -19,6 +19,10 @@
 
 using namespace bpe;
 
+#ifndef REPACK_DEN
+#define REPACK_DEN 32  // re-pack the slots when their fill drops below (REPACK_DEN-1)/REPACK_DEN
+#endif
+
 namespace {
 thread_local std::string g_create_err;
 
@@ -69,6 +73,8 @@ struct bpe_ctx {
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
     int use_slots = 1;
+    uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
+    unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
     int rep_shift = 5;        // log2(delta-vector replicas in use): shrinks as merges get rarer
     bool rows_in_select = false;  // the next k_select recomputes the queued rows itself
     bool slotted = false;
@@ -286,6 +292,7 @@ int start_from_bytes(bpe_ctx *c) {
     }
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
     LAUNCHCHK(c, "k_init_state");
+    c->apply_target = 0;
     TRY(prof_end(c));
     c->par = 0;
     c->n = n;
@@ -359,16 +366,25 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
     }
     const SlotRef ref = stream_ref(c);
     const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
-    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap,
-                       c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0);
+    const unsigned tie_blocks =
+        space > TIE_WINDOW0 ? grid_for(space - TIE_WINDOW0, 1024, TIE_BLOCKS) : 0u;
+    hipLaunchKernelGGL(k_select, dim3(1 + tie_blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                       c->vcap, c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, ++c->sel_epoch);
     LAUNCHCHK(c, "k_select");
-    if (space > TIE_WINDOW0) {
-        hipLaunchKernelGGL(k_tiebreak, dim3(grid_for(space - TIE_WINDOW0, 256, c->num_cus * 4)),
-                           dim3(256), 0, c->stream, ref, c->d_st, c->par, c->d_mat, c->vcap,
-                           (uint64_t)TIE_WINDOW0);
-        LAUNCHCHK(c, "k_tiebreak");
-    }
     TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// table update: apply blocks + row-maxima blocks in one launch
+template <bool FOLDED>
+int launch_table_update(bpe_ctx *c, uint32_t *delta, uint32_t Z, int par, IterRec *rec, int iter,
+                        int slot_finish) {
+    const uint32_t na = (Z + 1 + 31) / 32;
+    c->apply_target += na;
+    hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na + ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat,
+                       c->vcap, delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
+                       c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na, c->apply_target);
+    LAUNCHCHK(c, "k_apply_delta");
     return BPE_OK;
 }
 
@@ -425,13 +441,7 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
         LAUNCHCHK(c, "k_dp_fold");
     } else if (with_delta) {
         TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-        hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 31) / 32), dim3(256), 0, c->stream,
-                           c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
-                           c->d_dirty_list, c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
-        LAUNCHCHK(c, "k_apply_delta");
-        hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap,
-                           newid + 1, c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
-        LAUNCHCHK(c, "k_rowmax_list");
+        TRY(launch_table_update<false>(c, c->d_delta, newid, 0, nullptr, 0, 0));
         TRY(prof_end(c));
     }
     c->par ^= 1;
@@ -496,13 +506,7 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     LAUNCHCHK(c, "k_merge_slot");
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-    hipLaunchKernelGGL(k_apply_delta<false>, dim3((newid + 1 + 31) / 32), dim3(256), 0, c->stream,
-                       c->d_mat, c->vcap, c->d_delta, vcap_rep(c), c->d_rowmax, c->d_st, newid,
-                       c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, 1);
-    LAUNCHCHK(c, "k_apply_delta");
-    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, newid + 1,
-                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
-    LAUNCHCHK(c, "k_rowmax_list");
+    TRY(launch_table_update<false>(c, c->d_delta, newid, c->par, rec, iter, 1));
     TRY(prof_end(c));
     c->par ^= 1;
     c->mq ^= 1;
@@ -688,6 +692,7 @@ int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chu
     }
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
     LAUNCHCHK(c, "k_init_state");
+    c->apply_target = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_bytes = false;
     c->stream_is_bytes = false;
@@ -945,7 +950,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             // Slots thinning out: re-pack (between merges nothing is pending).  A pass costs
             // per slot as much as per id, so the slot count should follow the stream length
             // closely; at 7/8 fill a whole run re-packs only ~log(N0/N)/log(8/7) ~ a dozen times.
-            if (c->slotted && c->slot_T > 64 && c->n * 8 < c->slot_T * (uint64_t)TILE * 7) {
+            if (c->slotted && c->slot_T > 64 &&
+                c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
                 TRY(slots_leave(c));
                 TRY(slots_enter(c));
             }
@@ -1160,6 +1166,7 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
                            d_src, d_dst, (uint64_t)n_long, c->d_ids[0]);
         LAUNCHCHK(c, "k_long_gather");
         hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, tot);
+        c->apply_target = 0;
         c->par = 0;
         c->n = tot;
         int rc_long = BPE_OK;
@@ -1310,13 +1317,7 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t Z = 256u + (uint32_t)iter;
-    hipLaunchKernelGGL(k_apply_delta<true>, dim3((Z + 1 + 31) / 32), dim3(256), 0, c->stream, c->d_mat,
-                       c->vcap, c->d_dp_folded, c->vcap, c->d_rowmax, c->d_st, Z, c->d_dirty_list,
-                       c->d_dirty_n, 0, (IterRec *)nullptr, 0, 0);
-    LAUNCHCHK(c, "k_apply_delta");
-    hipLaunchKernelGGL(k_rowmax_list, dim3(64), dim3(256), 0, c->stream, c->d_mat, c->vcap, Z + 1,
-                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
-    LAUNCHCHK(c, "k_rowmax_list");
+    TRY(launch_table_update<true>(c, c->d_dp_folded, Z, 0, nullptr, 0, 0));
     return BPE_OK;
 }
 

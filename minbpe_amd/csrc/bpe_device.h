@@ -29,7 +29,9 @@ constexpr int PCB_ROUND = 61440;  // byte-stream kernel: positions between flush
 
 constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
 constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
-constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select itself searches on a tie
+constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select's block 0 searches on a tie
+constexpr int TIE_BLOCKS = 64;      // extra k_select blocks that sweep the rest of the stream
+constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
 
 // encode: one chunk per lane, token lists in lane-private LDS columns
@@ -64,6 +66,9 @@ struct DevState {
     int32_t tied[2 * TIE_CAP];
     int32_t fin_a, fin_b;         // the pair as finalised by the merge pass (read by k_apply_delta)
     unsigned long long removed;   // slotted merge: ids removed by the current pass
+    unsigned long long apply_done;  // k_apply_delta blocks finished (monotonic; row blocks wait on it)
+    uint32_t sel_flag;            // k_select: block 0 publishes its decision to the tie-break blocks
+    uint32_t pad_;
 };
 
 // one per training iteration, written by the device into pinned host memory

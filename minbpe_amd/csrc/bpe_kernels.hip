@@ -294,9 +294,10 @@ __device__ __forceinline__ bool tie_hit(const int32_t *s_tied, uint32_t nt, uint
 // if there is a tie -- search the first TIE_WINDOW0 positions of the stream for
 // the earliest tied pair.  Ties among frequent pairs always resolve there; the
 // rest of the stream is k_tiebreak's job.
-__global__ void __launch_bounds__(1024)
-k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist) {
+__device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
+                                            const uint32_t *__restrict__ mat, uint32_t stride,
+                                            uint32_t vcur, DevState *st, const SlotRef &ref, int par,
+                                            int dist) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt, s_first;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
@@ -411,18 +412,41 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     }
 }
 
-// Tie-break beyond the first window.  The grid sweeps the stream front to back
-// (each sweep step covers gridDim*256 consecutive positions), so a block stops
-// as soon as an earlier position has been reported.  No-op unless a tie is
-// still unresolved.
-__global__ void __launch_bounds__(256)
-k_tiebreak(SlotRef ref, DevState *st, int par, const uint32_t *__restrict__ mat, uint32_t stride,
-           uint64_t lo) {
+// K2 kernel.  Block 0 decides (select_body); blocks 1.. are the tie-break beyond
+// the first window: they wait for block 0's decision (one flag, agent-scope
+// release/acquire -- cdna_hip_programming.md G16) and, only if a tie is still
+// open, sweep the rest of the stream front to back (each sweep step covers
+// (gridDim-1)*1024 consecutive positions, so a block stops as soon as an
+// earlier position has been reported).  One launch instead of two; block 0
+// never waits, so there is no circular dependency whatever the residency.
+__global__ void __launch_bounds__(1024)
+k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
+         uint32_t vcur, DevState *st, SlotRef ref, int par, int dist, uint32_t epoch) {
+    if (blockIdx.x == 0) {
+        select_body(rowmax, mat, stride, vcur, st, ref, par, dist);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&st->sel_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ uint32_t s_go;
-    if (threadIdx.x == 0)
-        s_go = (st->status == 0 && st->found == 0 &&
+    if (threadIdx.x == 0) {
+        bool ok = false;
+        for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
+            if (__hip_atomic_load(&st->sel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+                ok = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_go = (ok && st->status == 0 && st->found == 0 &&
                 __atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) == NOPOS);
+    }
     __syncthreads();
     if (!s_go) return;
     const uint32_t nt = st->ntied;
@@ -431,8 +455,9 @@ k_tiebreak(SlotRef ref, DevState *st, int par, const uint32_t *__restrict__ mat,
     __syncthreads();
     const uint64_t n = st->n[par];
     const uint64_t space = slot_space(ref, n);
-    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t p = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < space; p += total) {
+    const uint64_t total = (uint64_t)(gridDim.x - 1) * blockDim.x;
+    for (uint64_t p = TIE_WINDOW0 + (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x; p < space;
+         p += total) {
         if (__atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) < p) break;
         uint32_t w0, w1;
         if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;
@@ -1591,11 +1616,12 @@ __global__ void k_move_n(DevState *st, int from, int to) { st->n[to] = st->n[fro
 // Rows whose maximum may have dropped are queued for k_rowmax_list; for every
 // other row the only entry that grew is the brand-new column Z.
 template <bool FOLDED>
-__global__ void __launch_bounds__(256)
-k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta,
-              uint32_t vcap, uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
-              uint32_t *__restrict__ dirty_list, uint32_t *__restrict__ dirty_n, int par, IterRec *rec,
-              int iter, int slot_finish) {
+__device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t stride,
+                                           uint32_t *__restrict__ delta, uint32_t vcap,
+                                           uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
+                                           uint32_t *__restrict__ dirty_list,
+                                           uint32_t *__restrict__ dirty_n, int par, IterRec *rec, int iter,
+                                           int slot_finish) {
     if (slot_finish && blockIdx.x == 0 && threadIdx.x == 0) {
         // slotted pass: new stream length and this iteration's record
         const unsigned long long n = st->n[par];
@@ -1672,15 +1698,16 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 
 // Recompute rowmax for the queued rows; also retires the merged pair: after the
 // merge no (a,b) remains (F2), whatever the a == b bookkeeping left there.
-__global__ void __launch_bounds__(256)
-k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
-              uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
-              const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
+__device__ __forceinline__ void rowmax_body(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
+                                            uint32_t *__restrict__ rowmax, const DevState *st,
+                                            const uint32_t *__restrict__ dirty_list,
+                                            const uint32_t *__restrict__ dirty_n, uint32_t first,
+                                            uint32_t step) {
     __shared__ uint32_t s_red[4];
     if (st->status) return;
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     const uint32_t nd = *dirty_n;
-    for (uint32_t i = blockIdx.x; i < nd; i += gridDim.x) {
+    for (uint32_t i = first; i < nd; i += step) {
         const uint32_t x = dirty_list[i];
         uint32_t *row = mat + (size_t)x * stride;
         uint32_t m = 0;
@@ -1698,6 +1725,52 @@ k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
         __syncthreads();
         if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     }
+}
+__global__ void __launch_bounds__(256)
+k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
+              uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
+              const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
+    rowmax_body(mat, stride, vnew, rowmax, st, dirty_list, dirty_n, blockIdx.x, gridDim.x);
+}
+
+// Table update in one launch: blocks [0, na) apply the delta vectors, blocks
+// [na, gridDim) wait until all of them are done (a monotonic counter, agent-scope
+// release/acquire) and recompute the queued row maxima.  The apply blocks never
+// wait and come first in dispatch order, so the wait always ends.
+template <bool FOLDED>
+__global__ void __launch_bounds__(256)
+k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta,
+              uint32_t vcap, uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
+              uint32_t *__restrict__ dirty_list, uint32_t *__restrict__ dirty_n, int par, IterRec *rec,
+              int iter, int slot_finish, uint32_t na, unsigned long long target) {
+    if (blockIdx.x < na) {
+        apply_body<FOLDED>(mat, stride, delta, vcap, rowmax, st, Z, dirty_list, dirty_n, par, rec, iter,
+                           slot_finish);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&st->apply_done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    __shared__ uint32_t s_ok;
+    if (threadIdx.x == 0) {
+        bool ok = false;
+        for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
+            if (__hip_atomic_load(&st->apply_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+                ok = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicExch(&st->status, ST_LOOKBACK);
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    rowmax_body(mat, stride, Z + 1, rowmax, st, dirty_list, dirty_n, blockIdx.x - na, gridDim.x - na);
 }
 
 // ---------------------------------------------------------------------------
@@ -2036,6 +2109,8 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->status = 0;
     st->fin_a = st->fin_b = 0;
     st->removed = 0;
+    st->apply_done = 0;
+    st->sel_flag = 0;
 }
 
 }  // namespace bpe
