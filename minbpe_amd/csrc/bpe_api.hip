@@ -73,6 +73,7 @@ struct bpe_ctx {
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
     int use_slots = 1;
+    int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
     uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
     unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
     int rep_shift = 5;        // log2(delta-vector replicas in use): shrinks as merges get rarer
@@ -380,10 +381,23 @@ template <bool FOLDED>
 int launch_table_update(bpe_ctx *c, uint32_t *delta, uint32_t Z, int par, IterRec *rec, int iter,
                         int slot_finish) {
     const uint32_t na = (Z + 1 + 31) / 32;
-    c->apply_target += na;
-    hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na + ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat,
-                       c->vcap, delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
-                       c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na, c->apply_target);
+    // Measured (cfg2): handing the row maxima to extra blocks of the same launch costs more
+    // (release + acquire fences, polling) than the ~1.5 us kernel boundary it saves -- 58 vs
+    // 45 ms per train -- so by default they are a launch of their own.
+    if (c->fused_rows) {
+        c->apply_target += na;
+        hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na + ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat,
+                           c->vcap, delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
+                           c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na,
+                           c->apply_target);
+    } else {
+        hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
+                           c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na, 0ull);
+        LAUNCHCHK(c, "k_apply_delta");
+        hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           Z + 1, c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    }
     LAUNCHCHK(c, "k_apply_delta");
     return BPE_OK;
 }
@@ -612,6 +626,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->merge_impl = (int)value;
     } else if (!strcmp(name, "lb_tune")) {
         c->lb_tune = (uint32_t)value;
+    } else if (!strcmp(name, "fused_rows")) {
+        c->fused_rows = value != 0;
     } else if (!strcmp(name, "slots")) {
         c->use_slots = value != 0;
     } else if (!strcmp(name, "depth")) {

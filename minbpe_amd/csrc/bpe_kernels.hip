@@ -1746,6 +1746,7 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     if (blockIdx.x < na) {
         apply_body<FOLDED>(mat, stride, delta, vcap, rowmax, st, Z, dirty_list, dirty_n, par, rec, iter,
                            slot_finish);
+        if (target == 0) return;  // row maxima run as their own launch (the default)
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
