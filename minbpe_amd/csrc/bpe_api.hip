@@ -367,9 +367,8 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
     }
     const SlotRef ref = stream_ref(c);
     const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
-    const unsigned tie_blocks =
-        space > TIE_WINDOW0 ? grid_for(space - TIE_WINDOW0, 1024, TIE_BLOCKS) : 0u;
-    hipLaunchKernelGGL(k_select, dim3(1 + tie_blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+    const unsigned blocks = space > TIE_WINDOW0 ? grid_for(space - TIE_WINDOW0, 1024, TIE_BLOCKS) : 1u;
+    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, ++c->sel_epoch);
     LAUNCHCHK(c, "k_select");
     TRY(prof_end(c));

@@ -29,7 +29,7 @@ constexpr int PCB_ROUND = 61440;  // byte-stream kernel: positions between flush
 
 constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
 constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
-constexpr uint32_t TIE_WINDOW0 = 1u << 16;  // positions k_select's block 0 searches on a tie
+constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches alone on a tie (0: all blocks sweep together)
 constexpr int TIE_BLOCKS = 64;      // extra k_select blocks that sweep the rest of the stream
 constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)

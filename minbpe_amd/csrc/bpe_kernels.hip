@@ -412,16 +412,18 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
     }
 }
 
-// K2 kernel.  Block 0 decides (select_body); blocks 1.. are the tie-break beyond
-// the first window: they wait for block 0's decision (one flag, agent-scope
-// release/acquire -- cdna_hip_programming.md G16) and, only if a tie is still
-// open, sweep the rest of the stream front to back (each sweep step covers
-// (gridDim-1)*1024 consecutive positions, so a block stops as soon as an
-// earlier position has been reported).  One launch instead of two; block 0
-// never waits, so there is no circular dependency whatever the residency.
+// K2 kernel.  Block 0 decides (select_body); the other blocks wait for its
+// decision (one flag, agent-scope release/acquire -- cdna_hip_programming.md
+// G16) and, only if a tie is open, ALL blocks sweep the stream front to back
+// for the earliest position holding a tied pair (each sweep step covers
+// gridDim*1024 consecutive positions, so a block stops as soon as an earlier
+// position has been reported).  One launch instead of two; block 0 never waits,
+// so there is no circular dependency whatever the residency.
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
          uint32_t vcur, DevState *st, SlotRef ref, int par, int dist, uint32_t epoch) {
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ uint32_t s_go;
     if (blockIdx.x == 0) {
         select_body(rowmax, mat, stride, vcur, st, ref, par, dist);
         __syncthreads();
@@ -429,12 +431,9 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&st->sel_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_go = (st->status == 0 && st->found == 0 && st->firstpos == NOPOS);
         }
-        return;
-    }
-    __shared__ int32_t s_tied[2 * TIE_CAP];
-    __shared__ uint32_t s_go;
-    if (threadIdx.x == 0) {
+    } else if (threadIdx.x == 0) {
         bool ok = false;
         for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
             if (__hip_atomic_load(&st->sel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
@@ -455,9 +454,9 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     __syncthreads();
     const uint64_t n = st->n[par];
     const uint64_t space = slot_space(ref, n);
-    const uint64_t total = (uint64_t)(gridDim.x - 1) * blockDim.x;
-    for (uint64_t p = TIE_WINDOW0 + (uint64_t)(blockIdx.x - 1) * blockDim.x + threadIdx.x; p < space;
-         p += total) {
+    // every block, block 0 included, sweeps: position order = (sweep step, block, thread)
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = TIE_WINDOW0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < space; p += total) {
         if (__atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) < p) break;
         uint32_t w0, w1;
         if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;

@@ -437,3 +437,16 @@ def test_train_slotted_edge_cases(engine):
         else:
             res = engine.train(nm)
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], (len(data), nm)
+
+
+def test_train_fused_row_maxima_option(engine, native):
+    """option fused_rows=1: row maxima recomputed by extra blocks of the table-update launch."""
+    data = native.synth_text(400_000, 61)
+    exp = oracle.train(data, 200)
+    engine.set_option("fused_rows", 1)
+    try:
+        engine.load_bytes(data)
+        res = engine.train(200)
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+    finally:
+        engine.set_option("fused_rows", 0)
