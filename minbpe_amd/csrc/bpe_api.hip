@@ -890,7 +890,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[0], c->stream));
     const uint64_t n0 = c->n;
     TRY(launch_pair_count(c, false));
-    if (c->profile) c->prof_bytes[BPE_PROF_PAIR_COUNT] += 4 * n0;
 
     int done = 0, rc = BPE_OK, consumed = 0;
     uint64_t cur_len = n0;  // exact length before iteration `consumed`

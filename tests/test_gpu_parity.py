@@ -450,3 +450,20 @@ def test_train_fused_row_maxima_option(engine, native):
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
     finally:
         engine.set_option("fused_rows", 0)
+
+
+def test_train_invariant_at_scale(engine, native):
+    """size-independent property (used at sizes the oracle cannot reach): every a != b merge
+    shortens the stream by exactly the count the pair table reported for it."""
+    data = native.synth_text(20_000_000, 71)
+    engine.load_bytes(data)
+    res = engine.train(300)
+    lens = np.array([len(data)] + res["lens"], dtype=np.int64)
+    cnt = np.array(res["counts"], dtype=np.int64)
+    same = np.array([a == b for a, b in res["pairs"]])
+    removed = lens[:-1] - lens[1:]
+    assert np.all(removed[~same] == cnt[~same])
+    assert np.all(removed[same] <= cnt[same]) and np.all(removed > 0)
+    # and the first merges agree with the oracle on the full 20 MB stream
+    exp = oracle.train(data, 3)
+    assert res["pairs"][:3] == exp[0] and res["counts"][:3] == exp[1] and res["lens"][:3] == exp[2]
