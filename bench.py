@@ -121,11 +121,26 @@ def main():
     hot = max(("pair_count", "merge", "widen"), key=lambda k: breakdown[k]["ms"])
     hp = prof[hot] if prof[hot]["launches"] else breakdown[hot]
     achieved = hp["alg_bytes"] / (hp["ms"] * 1e-3) / 1e9 if hp["ms"] > 0 else 0.0
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this
+    # process; they come from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r1_final_cfg2_pmc_merge_slot.json")
+    if (hot == "merge" and world == 1 and not force_dp and args.bytes == 100_000_000 and args.vocab == 4096
+            and args.mode < 0 and "BPE_MERGE" not in os.environ and os.path.exists(pmc_file)):
+        with open(pmc_file) as f:
+            traffic = int(json.load(f)["hbm_bytes_per_launch"])
+        traffic_src = "profiles/r1_final_cfg2_pmc_merge_slot.json"
     roofline = {
-        "bound": "hbm", "kernel": hot, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+        "bound": "hbm", "kernel": {"merge": "k_merge_slot (merge + pair-table delta)",
+                                   "pair_count": "k_pair_count", "widen": "k_widen"}[hot],
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "traffic_source": traffic_src,
         "launches": hp["launches"], "avg_launch_ms": round(hp["ms"] / max(hp["launches"], 1), 5),
         "alg_bytes_per_launch": hp["alg_bytes"] // max(hp["launches"], 1),
+        "note": "achieved = algorithmic bytes (4 B per id read or written by get_stats+merge, "
+                "SURVEY 8d) / hipEvent time; traffic = measured HBM bytes per launch",
     }
     # the two figures the metric names, over the whole timed region
     pc, mg = breakdown["pair_count"], breakdown["merge"]
