@@ -88,7 +88,7 @@ struct bpe_ctx {
     uint32_t *d_ids2 = nullptr;  // third stream buffer: target of compactions
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
-    int dp_rank = 0, dp_nranks = 1, dp_merges = 0;
+    int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
     bool dp_active = false;  // between bpe_dp_begin and bpe_dp_end
     uint32_t *d_dp_folded = nullptr, *d_dp_table = nullptr;
     long long *d_dp_key = nullptr;
@@ -518,9 +518,16 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
                        c->d_dirty_n, c->d_desc, c->epoch, c->d_hdr[c->mq], c->d_hdr[c->mq ^ 1]);
     LAUNCHCHK(c, "k_merge_slot");
     TRY(prof_end(c));
-    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-    TRY(launch_table_update<false>(c, c->d_delta, newid, c->par, rec, iter, 1));
-    TRY(prof_end(c));
+    if (c->dp_active) {
+        // sharded: fold the replicas into the all-reduce payload; bpe_dp_apply does the rest
+        hipLaunchKernelGGL(k_dp_fold, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta,
+                           vcap_rep(c), newid, c->d_dp_folded);
+        LAUNCHCHK(c, "k_dp_fold");
+    } else {
+        TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+        TRY(launch_table_update<false>(c, c->d_delta, newid, c->par, rec, iter, 1));
+        TRY(prof_end(c));
+    }
     c->par ^= 1;
     c->mq ^= 1;
     c->stats_valid = false;
@@ -1278,6 +1285,9 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     HIPCHK(c, hipMemcpy2DAsync(c->d_dp_table, 256 * 4, c->d_mat, (size_t)c->vcap * 4, 256 * 4, 256,
                                hipMemcpyDeviceToDevice, c->stream));
     c->dp_cur_len = c->n;
+    c->dp_enq = c->dp_done = 0;
+    c->rep_shift = 5;
+    if (c->use_slots) TRY(slots_enter(c));
     return BPE_OK;
 }
 
@@ -1308,8 +1318,13 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     c->vcur = 256u + (uint32_t)iter;
+    if (c->slotted && c->slot_T > 64 &&
+        c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
+        TRY(slots_leave(c));
+        TRY(slots_enter(c));
+    }
     TRY(launch_select(c, false));
-    hipLaunchKernelGGL(k_dp_key, dim3(1), dim3(64), 0, c->stream, c->d_ids[c->par], c->d_st,
+    hipLaunchKernelGGL(k_dp_key, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st,
                        (unsigned long long)c->dp_rank, c->d_dp_key);
     LAUNCHCHK(c, "k_dp_key");
     return BPE_OK;
@@ -1320,6 +1335,8 @@ extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_dp_resolve, dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
     LAUNCHCHK(c, "k_dp_resolve");
+    c->dp_enq = iter + 1;
+    if (c->slotted) return launch_merge_slot(c, 256u + (uint32_t)iter, iter, c->h_rec);
     const int saved = c->merge_impl;
     c->merge_impl = 0;  // the three-pass form finalises the pair before the rewrite
     const int rc = launch_merge(c, 256u + (uint32_t)iter, iter, c->h_rec, true);
@@ -1331,7 +1348,10 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t Z = 256u + (uint32_t)iter;
-    TRY(launch_table_update<true>(c, c->d_dp_folded, Z, 0, nullptr, 0, 0));
+    if (c->slotted)  // the slotted pass leaves length/record bookkeeping to the table update
+        TRY(launch_table_update<true>(c, c->d_dp_folded, Z, c->par ^ 1, c->h_rec, iter, 1));
+    else
+        TRY(launch_table_update<true>(c, c->d_dp_folded, Z, 0, nullptr, 0, 0));
     return BPE_OK;
 }
 
@@ -1356,7 +1376,7 @@ extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uin
         if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
         c->dp_cur_len = r->new_len;
         c->n = r->new_len;  // tighter launch bound
-        c->par = (iter + 1) & 1;
+        c->dp_done = iter + 1;
     }
     return BPE_OK;
 }
@@ -1365,6 +1385,20 @@ extern "C" int bpe_dp_end(bpe_ctx *c) {
     if (!c) return BPE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->slotted) {
+        // iterations enqueued after the last reported one (an early stop) did nothing on the
+        // device: undo their parity flips, then hand back a contiguous stream
+        if ((c->dp_enq - c->dp_done) & 1) {
+            c->par ^= 1;
+            c->mq ^= 1;
+        }
+        hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
+        TRY(slots_leave(c));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n = c->dp_cur_len;
+    } else if ((c->dp_enq - c->dp_done) & 1) {
+        c->par ^= 1;
+    }
     TRY(prof_drain(c));
     c->dp_nranks = 1;
     c->dp_rank = 0;

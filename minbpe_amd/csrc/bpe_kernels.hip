@@ -1784,7 +1784,7 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 // element-wise MIN all-reduce of (w0, w1) returns the pair of the winning rank,
 // because the keys are distinct per rank.  No tie: every rank sends key 0 and
 // the same pair.  No local occurrence: INT64_MAX.
-__global__ void k_dp_key(const uint32_t *__restrict__ ids, const DevState *__restrict__ st,
+__global__ void k_dp_key(SlotRef ref, int par, const DevState *__restrict__ st,
                          unsigned long long rank, long long *__restrict__ key) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long w0 = 0x7FFFFFFFFFFFFFFFll, w1 = 0x7FFFFFFFFFFFFFFFll;
@@ -1793,9 +1793,13 @@ __global__ void k_dp_key(const uint32_t *__restrict__ ids, const DevState *__res
             w0 = (long long)(uint32_t)st->a;
             w1 = (long long)(uint32_t)st->b;
         } else if (st->firstpos != NOPOS) {
+            // (slot-space positions are < 2^32 too: the slot area never exceeds the original stream)
             const unsigned long long k = ((rank << 32) | st->firstpos) + 1;  // > 0: a tie never ties with "no tie"
-            w0 = (long long)((k << 16) | (ids[st->firstpos] & IDMASK));
-            w1 = (long long)((k << 16) | ids[st->firstpos + 1]);
+            uint32_t x0 = 0, x1 = 0;
+            slot_get(ref, st->n[par], st->firstpos, x0);
+            slot_next(ref, st->n[par], st->firstpos, x1);
+            w0 = (long long)((k << 16) | (x0 & IDMASK));
+            w1 = (long long)((k << 16) | x1);
         }
     }
     key[0] = w0;

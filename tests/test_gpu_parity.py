@@ -336,7 +336,7 @@ def _space_chunks(text: bytes):
     return [c for c in re.findall(rb" ?[^ ]+| +", text) if c]
 
 
-def _lockstep(native, chunks, nm, world):
+def _lockstep(native, chunks, nm, world, slots=1):
     """Drive `world` ctxs through the dist.py protocol in lock-step; reductions done by hand."""
     import torch
     from minbpe_amd.dist import GpuShard, shard_chunks
@@ -345,6 +345,7 @@ def _lockstep(native, chunks, nm, world):
         lo, hi = shard_chunks(len(chunks), r, world)
         mine = chunks[lo:hi]
         eng = native.Engine(0)
+        eng.set_option("slots", slots)
         data = b"".join(mine)
         offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
         eng.load_bytes(data, offs)
@@ -386,15 +387,15 @@ def _lockstep(native, chunks, nm, world):
     return pairs, counts, lens
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_dp_lockstep_matches_oracle(native, world):
+@pytest.mark.parametrize("world,slots", [(1, 1), (2, 1), (3, 1), (2, 0)])
+def test_dp_lockstep_matches_oracle(native, world, slots):
     torch = pytest.importorskip("torch")
-    chunks = _space_chunks(native.synth_text(300_000, 51))
-    nm = 200
+    chunks = _space_chunks(native.synth_text(1_500_000, 51))
+    nm = 300
     data = b"".join(chunks)
     offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
     exp = oracle.train(data, nm, offs)
-    got = _lockstep(native, chunks, nm, world)
+    got = _lockstep(native, chunks, nm, world, slots)
     assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2]
 
 
