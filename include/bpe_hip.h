@@ -121,6 +121,15 @@ int bpe_dp_apply(bpe_ctx *ctx, int32_t iter);
 int bpe_dp_poll(bpe_ctx *ctx, int32_t iter, int32_t *a, int32_t *b, uint64_t *count,
                 uint64_t *local_len, int32_t *status);
 int bpe_dp_end(bpe_ctx *ctx);
+/* The same loop driven from inside the library with RCCL called directly (librccl is
+ * dlopen'ed): rank 0 makes a 128-byte id (bpe_comm_unique_id), the application
+ * broadcasts it by whatever means it has, every rank calls bpe_comm_init, then
+ * bpe_dp_train.  Identical results on every rank; len_out holds GLOBAL lengths. */
+int bpe_comm_unique_id(uint8_t *out128);
+int bpe_comm_init(bpe_ctx *ctx, int32_t rank, int32_t nranks, const uint8_t *id128);
+int bpe_comm_destroy(bpe_ctx *ctx);
+int bpe_dp_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
+                 uint64_t *len_out, int32_t *n_done);
 
 /* ---- encode ----------------------------------------------------------------- */
 /* _encode_chunk for a batch of chunks (regex.py:92-121; basic.py:57-74 when

@@ -59,6 +59,10 @@ _SIGS = {
     "bpe_dp_poll": (C.c_int, [_p, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64),
                               C.POINTER(_u64), C.POINTER(_i32)]),
     "bpe_dp_end": (C.c_int, [_p]),
+    "bpe_comm_unique_id": (C.c_int, [_p]),
+    "bpe_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
+    "bpe_comm_destroy": (C.c_int, [_p]),
+    "bpe_dp_train": (C.c_int, [_p, _i32, _p, _p, _p, C.POINTER(_i32)]),
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
@@ -262,6 +266,38 @@ class Engine:
 
     def dp_end(self):
         self._check(_lib.bpe_dp_end(self._h))
+
+    # -- RCCL called from inside the library ---------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = np.zeros(128, np.uint8)
+        rc = _lib.bpe_comm_unique_id(_ptr(buf))
+        if rc != BPE_OK:
+            raise RuntimeError("bpe_comm_unique_id failed: " + (_lib.bpe_last_error(None) or b"").decode())
+        return buf.tobytes()
+
+    def comm_init(self, rank: int, nranks: int, uid: bytes):
+        buf = np.frombuffer(uid, np.uint8)
+        self._check(_lib.bpe_comm_init(self._h, rank, nranks, _ptr(buf)))
+
+    def comm_destroy(self):
+        self._check(_lib.bpe_comm_destroy(self._h))
+
+    def dp_train(self, num_merges: int):
+        """Sharded training with the collectives issued by the library (after comm_init).
+        Same result dict as train(); lens are global."""
+        nm = max(num_merges, 1)
+        pairs = np.zeros(2 * nm, np.int32)
+        counts = np.zeros(nm, np.uint64)
+        lens = np.zeros(nm, np.uint64)
+        done = _i32(0)
+        rc = _lib.bpe_dp_train(self._h, num_merges, _ptr(pairs), _ptr(counts), _ptr(lens), C.byref(done))
+        d = done.value
+        self.last_train = dict(
+            pairs=[(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(d)],
+            counts=[int(x) for x in counts[:d]], lens=[int(x) for x in lens[:d]], iter_ms=None, n_done=d)
+        self._check(rc)
+        return self.last_train
 
     # -- encoding ----------------------------------------------------------------------
     def encode_batch(self, pairs, merge_ids, data, offsets=None):

@@ -159,3 +159,26 @@ def shard_chunks(n_chunks, rank, world):
     base, rem = divmod(n_chunks, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_native_comm(engine, comm):
+    """Create the library's own RCCL communicator for `engine` (one rank per process).
+    The 128-byte id travels over the torch.distributed group `comm` wraps.  Returns True
+    on every rank only if every rank succeeded (so that all ranks take the same path)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(comm.group) == "nccl" else None
+    ok = 1
+    try:
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if comm.rank == 0:
+            uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
+        uid = uid.to(dev) if dev is not None else uid
+        dist.broadcast(uid, src=0, group=comm.group)
+        engine.comm_init(comm.rank, comm.world, bytes(uid.cpu().numpy().tobytes()))
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    flag = flag.to(dev) if dev is not None else flag
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
+    return bool(flag.item())

@@ -468,3 +468,26 @@ def test_train_invariant_at_scale(engine, native):
     # and the first merges agree with the oracle on the full 20 MB stream
     exp = oracle.train(data, 3)
     assert res["pairs"][:3] == exp[0] and res["counts"][:3] == exp[1] and res["lens"][:3] == exp[2]
+
+
+def test_dp_native_rccl_solo(native):
+    """bpe_dp_train: the sharded loop inside the library, RCCL called directly (world of one here)."""
+    eng = native.Engine(0)
+    try:
+        text = native.synth_text(800_000, 81)
+        data, offs = split_chunks(text.decode())
+        exp = oracle.train(data, 250, offs)
+        eng.load_bytes(data, offs)
+        eng.comm_init(0, 1, native.Engine.comm_unique_id())
+        res = eng.dp_train(250)
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+        # exhaustion through the same path
+        eng.load_bytes(b"ab", None)
+        with pytest.raises(ValueError):
+            eng.dp_train(5)
+        assert eng.last_train["pairs"] == [(97, 98)]
+        # and the ctx still trains normally afterwards
+        eng.load_bytes(data, offs)
+        assert eng.train(50)["pairs"] == exp[0][:50]
+    finally:
+        eng.close()
