@@ -58,6 +58,38 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
+// DPP cross-lane moves (VALU speed; __shfl_* lower to ds_bpermute through the LDS crossbar).
+// ctrl: 0x110+n row_shr:n | 0x130 wave_shl:1 | 0x138 wave_shr:1 | 0x142 row_bcast:15 | 0x143 row_bcast:31
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive scans over the 64 lanes: 4 steps inside each row of 16, then two row broadcasts
+__device__ __forceinline__ int wave_iscan_max(int v) {  // identity -1 (values are >= -1)
+    v = max(v, dpp_mov<0x111>(-1, v));
+    v = max(v, dpp_mov<0x112>(-1, v));
+    v = max(v, dpp_mov<0x114>(-1, v));
+    v = max(v, dpp_mov<0x118>(-1, v));
+    v = max(v, dpp_mov<0x142, 0xA>(-1, v));
+    v = max(v, dpp_mov<0x143, 0xC>(-1, v));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_iscan_add(uint32_t x) {
+    int v = (int)x;
+    v += dpp_mov<0x111>(0, v);
+    v += dpp_mov<0x112>(0, v);
+    v += dpp_mov<0x114>(0, v);
+    v += dpp_mov<0x118>(0, v);
+    v += dpp_mov<0x142, 0xA>(0, v);
+    v += dpp_mov<0x143, 0xC>(0, v);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t lane_next(uint32_t x, uint32_t fill) {  // value of lane+1 (lane 63: fill)
+    return (uint32_t)dpp_mov<0x130>((int)fill, (int)x);
+}
+__device__ __forceinline__ uint32_t lane_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 0); }
+__device__ __forceinline__ uint32_t lane_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+
 // ---------------------------------------------------------------------------
 // K0: list(text_bytes)  (basic.py:25-26, regex.py:44)
 // 16 B read -> 64 B written per lane; HBM-bound, 5 B of traffic per id.
@@ -196,17 +228,32 @@ k_pair_count_bytes(const uint32_t *__restrict__ ids, const DevState *__restrict_
     const uint64_t g0 = per_wg * blockIdx.x;
     const uint64_t g1 = min(g0 + per_wg, groups);
     constexpr uint64_t ROUND_GROUPS = PCB_ROUND / 4;
+    constexpr int U = 4;  // 4-id groups per thread in flight: the kernel is latency-bound otherwise
     for (uint64_t r0 = g0; r0 < g1; r0 += ROUND_GROUPS) {
         const uint64_t r1 = min(r0 + ROUND_GROUPS, g1);
-        for (uint64_t g = r0 + threadIdx.x; g < r1; g += PC_THREADS) {
-            const uint64_t p = g * 4;
-            const uint4 v = *reinterpret_cast<const uint4 *>(ids + p);
-            const uint32_t x[5] = {v.x, v.y, v.z, v.w, ids[p + 4]};
+        for (uint64_t gb = r0; gb < r1; gb += (uint64_t)U * PC_THREADS) {
+            uint4 v[U];
+            uint32_t nx[U];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (p + k + 1 < n && !(x[k + 1] & FLAG)) {
-                    const uint32_t idx = ((x[k] & 0xFFu) << 8) | (x[k + 1] & 0xFFu);
-                    atomicAdd(&s_pc[idx >> 1], (idx & 1u) ? 0x10000u : 1u);
+            for (int u = 0; u < U; u++) {
+                const uint64_t g = gb + (uint64_t)u * PC_THREADS + threadIdx.x;
+                if (g < r1) {
+                    v[u] = *reinterpret_cast<const uint4 *>(ids + g * 4);
+                    nx[u] = ids[g * 4 + 4];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t g = gb + (uint64_t)u * PC_THREADS + threadIdx.x;
+                if (g >= r1) continue;
+                const uint64_t p = g * 4;
+                const uint32_t x[5] = {v[u].x, v[u].y, v[u].z, v[u].w, nx[u]};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (p + k + 1 < n && !(x[k + 1] & FLAG)) {
+                        const uint32_t idx = ((x[k] & 0xFFu) << 8) | (x[k + 1] & 0xFFu);
+                        atomicAdd(&s_pc[idx >> 1], (idx & 1u) ? 0x10000u : 1u);
+                    }
                 }
             }
         }
@@ -610,9 +657,8 @@ __device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, in
     const uint32_t tail = t.tail[0];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        const uint32_t nb = (uint32_t)__shfl((int)t.x[j][0], (lane + 1) & 63);
-        const uint32_t up = (j < MJ - 1) ? (uint32_t)__shfl((int)t.x[(j + 1) % MJ][0], 0) : tail;
-        nx[j] = (lane == 63) ? up : nb;
+        const uint32_t up = (j < MJ - 1) ? lane_first(t.x[(j + 1) % MJ][0]) : tail;
+        nx[j] = lane_next(t.x[j][0], up);
     }
     // r bits and the index of the last zero in each group
     int lzg[MJ];
@@ -633,16 +679,10 @@ __device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, in
     int carry = -1;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        int v = lzg[j];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(v, d);
-            if (lane >= d) v = max(v, o);
-        }
-        int ex = __shfl_up(v, 1);
-        if (lane == 0) ex = -1;
+        const int v = wave_iscan_max(lzg[j]);
+        const int ex = dpp_mov<0x138>(-1, v);  // wave_shr:1 -> exclusive
         t.E[j] = max(carry, ex);
-        carry = max(carry, __shfl(v, 63));
+        carry = max(carry, (int)lane_last((uint32_t)v));
     }
     if (lane == 0) s_wave[wave] = carry;
     __syncthreads();
@@ -913,14 +953,9 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         for (int k = 0; k < 4; k++) valid |= (uint32_t)(qw + j * 256 + k < own_len) << k;
         chg |= mb[j] & valid;
         kb[j] = (~((mb[j] << 1) | mp[j])) & valid & 0xFu;
-        uint32_t v = __popc(kb[j]);
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)v, d);
-            if (lane >= d) v += o;
-        }
+        const uint32_t v = wave_iscan_add((uint32_t)__popc(kb[j]));
         ex[j] = carry + v - __popc(kb[j]);
-        carry += (uint32_t)__shfl((int)v, 63);
+        carry += lane_last(v);
     }
     const bool wchg = __any(chg != 0);
     if (lane == 0) s_wsum[wave] = carry | (wchg ? 0x80000000u : 0u);
@@ -987,14 +1022,14 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         delta += (size_t)(blockIdx.x & (nrep - 1)) * 4 * vcap;
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
-            const uint32_t nb_m = (uint32_t)__shfl((int)mb[j], (lane + 1) & 63);
-            const uint32_t nb_x0 = (uint32_t)__shfl((int)t.x[j][0], (lane + 1) & 63);
-            const uint32_t nb_x1 = (uint32_t)__shfl((int)t.x[j][1], (lane + 1) & 63);
+            const uint32_t nb_m = lane_next(mb[j], 0);
+            const uint32_t nb_x0 = lane_next(t.x[j][0], 0);
+            const uint32_t nb_x1 = lane_next(t.x[j][1], 0);
             uint32_t up_m, up_x0, up_x1;
             if (j < MJ - 1) {
-                up_m = (uint32_t)__shfl((int)mb[(j + 1) % MJ], 0);
-                up_x0 = (uint32_t)__shfl((int)t.x[(j + 1) % MJ][0], 0);
-                up_x1 = (uint32_t)__shfl((int)t.x[(j + 1) % MJ][1], 0);
+                up_m = lane_first(mb[(j + 1) % MJ]);
+                up_x0 = lane_first(t.x[(j + 1) % MJ][0]);
+                up_x1 = lane_first(t.x[(j + 1) % MJ][1]);
             } else {
                 const uint32_t m3 = (mb[j] >> 3) & 1u;  // only lane 63's value is used
                 const uint32_t r4 = (uint32_t)(((t0 & IDMASK) == a) & (t1 == b));
