@@ -650,9 +650,8 @@ __device__ __forceinline__ void tile_from_slot(Tile &t, const SlotRaw &r, int le
     }
 }
 
-// r bits, last-zero scan: everything the m bits need (contains one __syncthreads)
-__device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, int *s_wave) {
-    const int lane = lane_id(), wave = wave_id();
+// r bits of my elements: r[p] = 1 iff (word[p], word[p+1]) is the pair
+__device__ __forceinline__ void tile_rbits(Tile &t, uint32_t a, uint32_t b) {
     uint32_t nx[MJ];
     const uint32_t tail = t.tail[0];
 #pragma unroll
@@ -660,9 +659,6 @@ __device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, in
         const uint32_t up = (j < MJ - 1) ? lane_first(t.x[(j + 1) % MJ][0]) : tail;
         nx[j] = lane_next(t.x[j][0], up);
     }
-    // r bits and the index of the last zero in each group
-    int lzg[MJ];
-    const int gb0 = wave * WAVE_SPAN + lane * 4;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         uint32_t rb = 0;
@@ -672,10 +668,19 @@ __device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, in
             rb |= (uint32_t)(((t.x[j][k] & IDMASK) == a) & (nxt == b)) << k;
         }
         t.rb[j] = rb;
-        const uint32_t z = (~rb) & 0xFu;
+    }
+}
+// exclusive max-scan of "index of the last zero of r" in (wave, stripe, lane) order:
+// everything the m bits need (contains one __syncthreads)
+__device__ __forceinline__ void tile_lzscan(Tile &t, int *s_wave) {
+    const int lane = lane_id(), wave = wave_id();
+    int lzg[MJ];
+    const int gb0 = wave * WAVE_SPAN + lane * 4;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const uint32_t z = (~t.rb[j]) & 0xFu;
         lzg[j] = z ? (gb0 + j * 256 + (31 - __clz((int)z))) : -1;
     }
-    // exclusive max-scan of lzg in (wave, stripe, lane) order
     int carry = -1;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
@@ -690,6 +695,10 @@ __device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, in
     for (int w = 0; w < wave; w++) win = max(win, s_wave[w]);
 #pragma unroll
     for (int j = 0; j < MJ; j++) t.E[j] = max(t.E[j], win);
+}
+__device__ __forceinline__ void tile_prepare(Tile &t, uint32_t a, uint32_t b, int *s_wave) {
+    tile_rbits(t, a, b);
+    tile_lzscan(t, s_wave);
 }
 
 __device__ __forceinline__ void tile_load(Tile &t, const uint32_t *__restrict__ ids, uint64_t n,
@@ -1529,7 +1538,7 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
     const uint32_t s_first_word = s_ctx[4];
     Tile tl;
     tile_from_slot(tl, raw, len, halo);
-    tile_prepare(tl, a, b, s_wave);
+    tile_rbits(tl, a, b);
     // carry: the previous slot ended with a site start iff its last id is a and my first word is b
     // (thread 0 stored my first word next to the neighbours' in s_ctx)
     uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (s_first_word == b));
@@ -1602,6 +1611,32 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
         s = s_ctx[5];
     }
 #endif
+    // Fast path: no match at any owned position, none at the first word after the slot, no
+    // carry -> nothing in this slot changes and it owes no pair-table update.  Late in training
+    // this is most slots; they skip the scans and the rewrite altogether.
+    {
+        uint32_t anyr = s;
+        const int qw = wave_id() * WAVE_SPAN + lane_id() * 4;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const int q0 = qw + j * 256;
+            // keep the bits of positions q <= len
+            const int nb = len + 1 - q0;
+            const uint32_t keep = nb >= 4 ? 0xFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+            anyr |= tl.rb[j] & keep;
+        }
+        // a full slot: the word after it is the last wave's tail, not one of my registers
+        if (len == TILE && wave_id() == MT / 64 - 1)
+            anyr |= (uint32_t)(((tl.tail[0] & IDMASK) == a) & (tl.tail[1] == b));
+        if (!__syncthreads_or((int)(anyr != 0))) {
+            if (threadIdx.x == 0) {
+                meta_out[t] = mi;
+                hdr_out[t] = make_uint4(s_ctx[4], s_ctx[6], s_ctx[7], s_ctx[8]);
+            }
+            return;
+        }
+    }
+    tile_lzscan(tl, s_wave);
     uint32_t kept = 0;
     bool changed = false;
     uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
