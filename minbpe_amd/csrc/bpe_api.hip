@@ -74,6 +74,7 @@ struct bpe_ctx {
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
     int use_slots = 1;
+    int slot_wgs_per_cu = 6;             // k_merge_slot grid = CUs x this (workgroups stride over slots)
     int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
     uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
     unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
@@ -515,7 +516,9 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
         HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
         c->epoch++;
     }
-    hipLaunchKernelGGL(k_merge_slot<true>, dim3((unsigned)std::max<uint64_t>(c->slot_T, 1)), dim3(MT), 0,
+    const unsigned slot_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(c->slot_T, 1),
+                                                           (uint64_t)c->num_cus * (uint64_t)c->slot_wgs_per_cu);
+    hipLaunchKernelGGL(k_merge_slot<true>, dim3(slot_grid), dim3(MT), 0,
                        c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
                        c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, vcap_rep(c),
                        c->d_dirty_n, c->d_desc, c->epoch, c->d_hdr[c->mq], c->d_hdr[c->mq ^ 1]);
@@ -638,6 +641,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lb_tune = (uint32_t)value;
     } else if (!strcmp(name, "fused_rows")) {
         c->fused_rows = value != 0;
+    } else if (!strcmp(name, "slot_wgs")) {
+        if (value < 1 || value > 4096) return fail(c, BPE_E_ARG, "slot_wgs must be 1..4096");
+        c->slot_wgs_per_cu = (int)value;
     } else if (!strcmp(name, "slots")) {
         c->use_slots = value != 0;
     } else if (!strcmp(name, "depth")) {

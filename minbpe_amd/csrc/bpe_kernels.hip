@@ -1434,19 +1434,15 @@ k_slot_init(uint32_t *__restrict__ meta, uint4 *__restrict__ hdr, uint64_t T,
 }
 
 template <bool DELTA>
-__global__ void __launch_bounds__(MT)
-k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, uint32_t *__restrict__ w0,
-             uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
-             uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
-             uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n,
-             unsigned long long *__restrict__ sdesc, uint32_t epoch, const uint4 *__restrict__ hdr_in,
-             uint4 *__restrict__ hdr_out) {
+__device__ __forceinline__ void merge_slot_tile(
+    uint64_t t, const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1,
+    uint32_t *__restrict__ w0, uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
+    uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
+    uint32_t *__restrict__ delta, uint32_t vcap, unsigned long long *__restrict__ sdesc, uint32_t epoch,
+    const uint4 *__restrict__ hdr_in, uint4 *__restrict__ hdr_out) {
     __shared__ int s_wave[MT / 64];
     __shared__ uint32_t s_wsum[MT / 64];
     __shared__ uint32_t s_ctx[9];  // halo[0..2], previous last word, my header x, carry (a == b), my header y z w
-    const uint64_t t = blockIdx.x;
-    if (t == 0 && threadIdx.x == 0 && dirty_n) *dirty_n = 0;
-    if (t >= T || st->status) return;
     SlotRef ref;
     ref.b0 = b0;
     ref.b1 = b1;
@@ -1656,6 +1652,26 @@ k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, u
             meta_out[t] = mi;
             hdr_out[t] = make_uint4(s_ctx[4], s_ctx[6], s_ctx[7], s_ctx[8]);
         }
+    }
+}
+
+// Slots have no inter-workgroup dependency (bar the rare a == b chain), so the grid is a
+// fixed number of workgroups striding over the slots: the per-launch state (status, pair) is
+// read once per workgroup instead of once per slot.
+template <bool DELTA>
+__global__ void __launch_bounds__(MT)
+k_merge_slot(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, uint32_t *__restrict__ w0,
+             uint32_t *__restrict__ w1, const uint32_t *__restrict__ meta_in,
+             uint32_t *__restrict__ meta_out, uint64_t T, DevState *st, int par, uint32_t newid,
+             uint32_t *__restrict__ delta, uint32_t vcap, uint32_t *dirty_n,
+             unsigned long long *__restrict__ sdesc, uint32_t epoch, const uint4 *__restrict__ hdr_in,
+             uint4 *__restrict__ hdr_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && dirty_n) *dirty_n = 0;
+    if (st->status) return;
+    for (uint64_t t = blockIdx.x; t < T; t += gridDim.x) {
+        merge_slot_tile<DELTA>(t, b0, b1, w0, w1, meta_in, meta_out, T, st, par, newid, delta, vcap, sdesc,
+                               epoch, hdr_in, hdr_out);
+        __syncthreads();  // the tile's LDS scratch is reused by the next one
     }
 }
 
