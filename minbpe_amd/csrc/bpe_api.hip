@@ -74,10 +74,6 @@ struct bpe_ctx {
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
     int use_slots = 1;
-    // k_merge_slot grid = min(slots, CUs x this).  Measured: one workgroup per slot (let the
-    // dispatcher balance) beats a resident grid striding over slots by 20 % (252 vs 302 ms per
-    // cfg2 train) -- the per-slot barrier serialises each workgroup's load and store phases.
-    int slot_wgs_per_cu = 1 << 20;
     int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
     uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
     unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
@@ -519,8 +515,7 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
         HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
         c->epoch++;
     }
-    const unsigned slot_grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>(c->slot_T, 1),
-                                                           (uint64_t)c->num_cus * (uint64_t)c->slot_wgs_per_cu);
+    const unsigned slot_grid = (unsigned)std::max<uint64_t>(c->slot_T, 1);
     hipLaunchKernelGGL(k_merge_slot<true>, dim3(slot_grid), dim3(MT), 0,
                        c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
                        c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, vcap_rep(c),
@@ -644,9 +639,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lb_tune = (uint32_t)value;
     } else if (!strcmp(name, "fused_rows")) {
         c->fused_rows = value != 0;
-    } else if (!strcmp(name, "slot_wgs")) {
-        if (value < 1 || value > (1 << 20)) return fail(c, BPE_E_ARG, "slot_wgs must be 1..2^20");
-        c->slot_wgs_per_cu = (int)value;
     } else if (!strcmp(name, "slots")) {
         c->use_slots = value != 0;
     } else if (!strcmp(name, "depth")) {
