@@ -906,7 +906,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     int done = 0, rc = BPE_OK, consumed = 0;
     uint64_t cur_len = n0;  // exact length before iteration `consumed`
     bool stop = false;
-    int samepair_at = -1;
     c->rep_shift = 5;
     c->rows_in_select = false;
     const bool slots = delta && c->use_slots && c->merge_impl == 0;
@@ -922,10 +921,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
         }
         __sync_synchronize();
-        if (r->status == ST_SAMEPAIR) {  // slotted pass refused a == b: redo merge j contiguously
-            samepair_at = j;
-            return BPE_OK;
-        }
         if (r->status == ST_EMPTY) {
             stop = true;
             rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
@@ -975,7 +970,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             }
             // Slots thinning out: re-pack (between merges nothing is pending).  A pass costs
             // per slot as much as per id, so the slot count should follow the stream length
-            // closely; at 7/8 fill a whole run re-packs only ~log(N0/N)/log(8/7) ~ a dozen times.
+            // closely; at 31/32 fill a whole cfg2 run re-packs ~45 times, ~60 us each.
             if (c->slotted && c->slot_T > 64 &&
                 c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
                 TRY(slots_leave(c));
@@ -991,31 +986,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         if (consumed < i && (i - consumed > c->depth || i == num_merges)) {
             TRY(consume(consumed));
-            if (samepair_at >= 0) {
-                // Everything enqueued after merge j was a no-op (status is sticky).  Drain,
-                // restore the host's view of iteration j, redo it on the contiguous path.
-                const int j = samepair_at;
-                samepair_at = -1;
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                const int back = i - j;  // iterations whose parity flips must be undone
-                if (back & 1) {
-                    c->par ^= 1;
-                    c->mq ^= 1;
-                }
-                memset(&c->h_rec[j], 0, sizeof(IterRec) * (size_t)(num_merges - j));
-                hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
-                hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par,
-                                   c->d_st);  // pin the pair before positions move
-                LAUNCHCHK(c, "k_finalize");
-                TRY(slots_leave(c));
-                c->vcur = 256u + (uint32_t)j;
-                c->n = cur_len;
-                c->rows_in_select = false;
-                TRY(launch_merge(c, 256u + (uint32_t)j, j, c->h_rec, true));
-                TRY(slots_enter(c));
-                i = j + 1;
-                continue;
-            }
             if (!stop) consumed++;
         }
         if (consumed >= num_merges) break;

@@ -40,7 +40,6 @@ constexpr int ENC_LMAX = 32;  // longer chunks take the stream-wide path
 constexpr int SCAN_TILE = 4096;
 
 constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
-constexpr uint32_t ST_SAMEPAIR = 4;  // slotted merge met a == b: the host redoes this merge on the contiguous path
 constexpr uint32_t EPOCH_MASK = 0xFFFFFu;  // look-back descriptors carry a 20-bit launch tag
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile
 

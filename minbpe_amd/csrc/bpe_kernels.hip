@@ -1520,15 +1520,9 @@ __device__ __forceinline__ void merge_slot_tile(
         s_ctx[7] = hme.z;
         s_ctx[8] = hme.w;
     }
-#ifndef BPE_EXP_LATE_LOAD
     SlotRaw raw;
     slot_raw_load(raw, src, len);
     __syncthreads();
-#else
-    __syncthreads();
-    SlotRaw raw;
-    slot_raw_load(raw, src, len);
-#endif
     const uint32_t halo[3] = {s_ctx[0], s_ctx[1], s_ctx[2]};
     const uint32_t prev = s_ctx[3];
     const uint32_t s_first_word = s_ctx[4];
@@ -1538,7 +1532,6 @@ __device__ __forceinline__ void merge_slot_tile(
     // carry: the previous slot ended with a site start iff its last id is a and my first word is b
     // (thread 0 stored my first word next to the neighbours' in s_ctx)
     uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (s_first_word == b));
-#ifndef BPE_EXP_NO_AEQB
     if (a == b) {
         // a == b: the carry is the PARITY of the run of a's that ends at the previous slot's
         // last id (F2).  Walk that run backwards, 64 ids per step; only if it swallows the whole
@@ -1606,7 +1599,6 @@ __device__ __forceinline__ void merge_slot_tile(
         __syncthreads();
         s = s_ctx[5];
     }
-#endif
     // Fast path: no match at any owned position, none at the first word after the slot, no
     // carry -> nothing in this slot changes and it owes no pair-table update.  Late in training
     // this is most slots; they skip the scans and the rewrite altogether.
@@ -1637,11 +1629,7 @@ __device__ __forceinline__ void merge_slot_tile(
     bool changed = false;
     uint32_t *dst = (cur ? w0 : w1) + t * TILE;  // the OTHER buffer
     uint32_t *my_hdr = reinterpret_cast<uint32_t *>(hdr_out + t);
-#ifdef BPE_EXP_NO_HDR4
-    tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed, nullptr);
-#else
     tile_rewrite<DELTA, true>(tl, s, a, b, newid, dst, s_wsum, delta, vcap, len, &kept, &changed, my_hdr);
-#endif
     if (threadIdx.x == 0) {
         if (changed) {
             meta_out[t] = kept | ((cur ^ 1u) << 31);

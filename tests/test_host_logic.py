@@ -86,3 +86,21 @@ def test_concat_chunks_drops_empty():
 def test_render_token():
     assert render_token(b"a\nb") == "a\\u000ab"
     assert render_token(b"\xff") == "�"
+
+
+def test_gpt4_merge_recovery_from_ranks():
+    """GPT4Tokenizer needs tiktoken's cl100k ranks, which are not available offline; the part
+    that is ours -- rebuilding the merge pairs from a {token bytes: rank} table (gpt4.py:29-46)
+    -- is checked on a rank table made from merges we trained ourselves."""
+    import oracle
+    from minbpe_amd.tokenizer import _recover_merges
+    text = ("the quick brown fox jumps over the lazy dog; " * 40 + "pack my box with five dozen liquor jugs. " * 30).encode()
+    pairs, _, _ = oracle.train(text, 120)
+    vocab = {i: bytes([i]) for i in range(256)}
+    for i, (a, b) in enumerate(pairs):
+        vocab[256 + i] = vocab[a] + vocab[b]
+    if len(set(vocab.values())) != len(vocab):  # a rank table needs distinct byte strings
+        pytest.skip("two merges produced the same byte string")
+    ranks = {tok: idx for idx, tok in vocab.items()}
+    rec = _recover_merges(ranks)
+    assert rec == {p: 256 + i for i, p in enumerate(pairs)}
