@@ -88,13 +88,13 @@ def test_render_token():
     assert render_token(b"\xff") == "�"
 
 
-def test_gpt4_merge_recovery_from_ranks():
+def test_gpt4_merge_recovery_from_ranks(native):
     """GPT4Tokenizer needs tiktoken's cl100k ranks, which are not available offline; the part
     that is ours -- rebuilding the merge pairs from a {token bytes: rank} table (gpt4.py:29-46)
     -- is checked on a rank table made from merges we trained ourselves."""
     import oracle
     from minbpe_amd.tokenizer import _recover_merges
-    text = ("the quick brown fox jumps over the lazy dog; " * 40 + "pack my box with five dozen liquor jugs. " * 30).encode()
+    text = native.synth_text(30_000, 5)
     pairs, _, _ = oracle.train(text, 120)
     vocab = {i: bytes([i]) for i in range(256)}
     for i, (a, b) in enumerate(pairs):
