@@ -250,10 +250,11 @@ k_pair_count_bytes(const uint32_t *__restrict__ ids, const DevState *__restrict_
                 const uint32_t x[5] = {v[u].x, v[u].y, v[u].z, v[u].w, nx[u]};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (p + k + 1 < n && !(x[k + 1] & FLAG)) {
-                        const uint32_t idx = ((x[k] & 0xFFu) << 8) | (x[k + 1] & 0xFFu);
-                        atomicAdd(&s_pc[idx >> 1], (idx & 1u) ? 0x10000u : 1u);
-                    }
+                    // branch-free: a position that is not a pair adds 0 (one ds_add per
+                    // position either way; no exec-mask juggling around every atomic)
+                    const bool ok = (p + k + 1 < n) & !(x[k + 1] & FLAG);
+                    const uint32_t idx = ((x[k] & 0xFFu) << 8) | (x[k + 1] & 0xFFu);
+                    atomicAdd(&s_pc[idx >> 1], ok ? ((idx & 1u) ? 0x10000u : 1u) : 0u);
                 }
             }
         }
