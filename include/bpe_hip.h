@@ -158,6 +158,15 @@ int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_i
 int bpe_prof_reset(bpe_ctx *ctx);
 int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_bytes);
 
+/* ---- native pre-split (host, no GPU needed) ----------------------------- */
+/* regex.findall(pattern, text) for the two GPT split patterns (regex.py:18-19, 41, 114),
+ * as chunk START byte offsets into the UTF-8 text.  which: 2 = GPT-2 pattern, 4 = GPT-4
+ * pattern (any other pattern stays with the `regex` module).  Both patterns match every
+ * character, so the chunks partition the text.  starts_out may be NULL to only count;
+ * returns BPE_E_CAP (with *n_chunks set) if cap is too small.  threads <= 0: all cores. */
+int bpe_split(int which, const uint8_t *utf8, uint64_t n, uint64_t *starts_out, uint64_t cap,
+              uint64_t *n_chunks, int threads);
+
 /* ---- host utilities (no GPU needed) ------------------------------------------ */
 /* Deterministic synthetic UTF-8 text (SURVEY 8d synth_text): explicit
  * splitmix64, integer tables only.  Writes exactly n bytes, valid UTF-8. */

@@ -66,6 +66,7 @@ _SIGS = {
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
+    "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_synth_text": (C.c_int, [_p, _u64, _u64]),
     "bpe_version": (C.c_char_p, []),
 }
@@ -91,6 +92,21 @@ def synth_text(n: int, seed: int) -> bytes:
     if rc != BPE_OK:
         raise RuntimeError(f"bpe_synth_text failed: {rc}")
     return buf.tobytes()
+
+
+def split_offsets(data: bytes, which: int, threads: int = 0):
+    """Chunk start offsets of regex.findall(GPT-2 | GPT-4 split pattern) over UTF-8 `data`
+    (host only).  which: 2 or 4."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    n = _u64(0)
+    out = np.empty(len(buf) // 3 + 16, np.uint64)  # GPT-style chunks average > 4 bytes
+    rc = _lib.bpe_split(which, _ptr(buf) if len(buf) else None, len(buf), _ptr(out), len(out), C.byref(n), threads)
+    if rc == BPE_E_CAP:  # unusually short chunks: now we know the count
+        out = np.empty(n.value, np.uint64)
+        rc = _lib.bpe_split(which, _ptr(buf), len(buf), _ptr(out), len(out), C.byref(n), threads)
+    if rc != BPE_OK:
+        raise RuntimeError(f"bpe_split failed: {rc}")
+    return out[:n.value].copy() if n.value * 2 < len(out) else out[:n.value]
 
 
 def _ptr(a):

@@ -8,8 +8,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", "bpe_api.hip"), os.path.join(HERE, "csrc", "synth.cpp")]
-DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("bpe_kernels.hip", "bpe_device.h")] + [
+SRC = [os.path.join(HERE, "csrc", f) for f in ("bpe_api.hip", "synth.cpp", "split.cpp")]
+DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("bpe_kernels.hip", "bpe_device.h", "unicode_tables.h")] + [
     os.path.join(ROOT, "include", "bpe_hip.h")]
 OUT = os.path.join(HERE, "lib", "libbpe_hip.so")
 
@@ -20,7 +20,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc"),
            *SRC, "-o", OUT]
     if verbose:

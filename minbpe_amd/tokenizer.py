@@ -22,6 +22,9 @@ from . import _native
 GPT2_SPLIT_PATTERN = r"""'(?:[sdmt]|ll|ve|re)| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
 GPT4_SPLIT_PATTERN = r"""'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"""
 
+# compiled_pattern.pattern -> bpe_split's `which` (the scanner knows exactly these two)
+_NATIVE_SPLIT = {GPT2_SPLIT_PATTERN: 2, GPT4_SPLIT_PATTERN: 4}
+
 _engines = {}
 
 
@@ -221,8 +224,19 @@ class RegexTokenizer(Tokenizer):
     def _split(self, text):
         return [piece.encode("utf-8") for piece in re.findall(self.compiled_pattern, text)]
 
+    def _chunked(self, text):
+        """(utf-8 bytes of the chunks back to back, chunk start offsets) -- what
+        re.findall(self.compiled_pattern, text) yields (regex.py:41,114).  The two GPT
+        patterns go through the native scanner (bpe_split, checked against `regex` in
+        tests/test_split.py); any other pattern through the `regex` module itself."""
+        which = _NATIVE_SPLIT.get(self.compiled_pattern.pattern)
+        if which is not None:
+            data = text.encode("utf-8")
+            return data, _native.split_offsets(data, which)
+        return _concat_chunks(self._split(text))
+
     def train(self, text, vocab_size, verbose=False):
-        data, offs = _concat_chunks(self._split(text))
+        data, offs = self._chunked(text)
         self._train_on_device(data, offs, vocab_size, verbose)
 
     def register_special_tokens(self, special_tokens):
@@ -241,15 +255,22 @@ class RegexTokenizer(Tokenizer):
         return b"".join(parts).decode("utf-8", errors="replace")
 
     def _prepare_chunk(self, chunk_bytes):
-        return chunk_bytes  # GPT4Tokenizer permutes bytes here
+        return chunk_bytes  # GPT4Tokenizer permutes bytes here (a per-byte map)
 
     def _encode_chunk(self, text_bytes):
         ids, _ = self._encode_chunks([self._prepare_chunk(text_bytes)])
         return ids.tolist()
 
+    def _encode_flat(self, data, offs):
+        """encode chunks given as one byte string + start offsets (one device batch)"""
+        if not data:
+            return np.empty(0, np.int32), np.zeros(1, np.uint64)
+        pairs, mids = self._merge_table()
+        return engine().encode_batch(pairs, mids, self._prepare_chunk(data), offs)
+
     def encode_ordinary(self, text):
-        ids, _ = self._encode_chunks([self._prepare_chunk(c) for c in self._split(text)])
-        return ids.tolist()
+        data, offs = self._chunked(text)
+        return self._encode_flat(data, offs)[0].tolist()
 
     def encode(self, text, allowed_special="none_raise"):
         if allowed_special == "all":
@@ -268,27 +289,26 @@ class RegexTokenizer(Tokenizer):
         splitter = "(" + "|".join(re.escape(k) for k in special) + ")"
         parts = re.split(splitter, text)
         # one device batch for all ordinary parts; specials spliced back in order
-        chunks, owner = [], []
-        for pi, part in enumerate(parts):
+        datas, offs_list, nchunks, base = [], [], [], 0
+        for part in parts:
             if part in special:
+                nchunks.append(None)
                 continue
-            for c in self._split(part):
-                c = self._prepare_chunk(c)
-                if c:
-                    chunks.append(c)
-                    owner.append(pi)
-        ids, starts = self._encode_chunks(chunks)
-        bounds = np.append(starts, len(ids)).astype(np.int64)
+            d, o = self._chunked(part)
+            datas.append(d)
+            offs_list.append(o + np.uint64(base))
+            nchunks.append(len(o))
+            base += len(d)
+        data = b"".join(datas)
+        offs = np.concatenate(offs_list) if offs_list else np.empty(0, np.uint64)
+        ids, out_off = self._encode_flat(data, offs)
         out, ci = [], 0
-        for pi, part in enumerate(parts):
-            if part in special:
+        for part, k in zip(parts, nchunks):
+            if k is None:
                 out.append(special[part])
-                continue
-            first = ci
-            while ci < len(owner) and owner[ci] == pi:
-                ci += 1
-            if ci > first:
-                out.extend(ids[bounds[first]:bounds[ci]].tolist())
+            elif k:
+                out.extend(ids[int(out_off[ci]):int(out_off[ci + k])].tolist())
+                ci += k
         return out
 
 
