@@ -122,6 +122,39 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1: the ranks must agree, and the sharded result must be the single-GPU result on the
+    # concatenation of all shards (rank 0 re-trains it unsharded, outside the timed region).
+    dp_check = None
+    if world > 1 or force_dp:
+        import hashlib
+        digest = int.from_bytes(hashlib.sha256(repr((res["pairs"], res["counts"], res["lens"])).encode())
+                                .digest()[:7], "big")
+        lo = torch.tensor([digest], dtype=torch.int64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dp_check = {"ranks_agree": bool(lo.item() == hi.item()), "equals_single_gpu": None}
+        if rank == 0 and os.environ.get("BENCH_DP_CHECK", "1") == "1":
+            try:
+                parts, offl, base = [], [], 0
+                for r in range(world):
+                    d = minbpe_amd.synth_text(args.bytes, args.seed + r)
+                    a = np.frombuffer(d, dtype=np.uint8)
+                    cuts = np.flatnonzero((a == 32) | (a == 10)).astype(np.uint64)
+                    o = np.unique(np.concatenate([np.zeros(1, np.uint64), cuts]))
+                    parts.append(d)
+                    offl.append(o + np.uint64(base))
+                    base += len(d)
+                eng2 = Engine(local_rank)
+                eng2.load_bytes(b"".join(parts), np.concatenate(offl))
+                single = eng2.train(num_merges)
+                eng2.close()
+                dp_check["equals_single_gpu"] = bool(
+                    single["pairs"] == res["pairs"] and single["counts"] == res["counts"]
+                    and single["lens"] == res["lens"])
+            except Exception as e:  # the bench line must still come out
+                dp_check["equals_single_gpu"] = f"not checked: {type(e).__name__}: {e}"
+
     # Weak scaling: every rank runs num_merges merge passes over its own `bytes`.  The whole-job
     # aggregate is therefore merge passes summed over ranks (= merges/s at N=1); the plain rate of
     # the one sharded job is reported next to it as job_merges_per_s.
@@ -167,7 +200,7 @@ def main():
     }
 
     cpu_baseline = None
-    if rank == 0 and args.cpu_iters > 0 and world == 1:
+    if rank == 0 and args.cpu_iters > 0 and world == 1 and not force_dp:
         import oracle
         t0 = time.perf_counter()
         cp, _, _ = oracle.train(data, args.cpu_iters)
@@ -196,6 +229,7 @@ def main():
             "job_merges_per_s": round(job_merges_per_s, 2),
             "value_definition": "merge passes per second summed over GPUs (each rank merges its own shard); "
                                 "equals job_merges_per_s x n_gpus",
+            "sharded_check": dp_check,
             "roofline": roofline, "cpu_baseline": cpu_baseline, **extra,
         }))
     eng.close()

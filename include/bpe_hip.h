@@ -144,6 +144,22 @@ int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_i
                      uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
                      uint64_t *n_out);
 
+/* ---- decode -------------------------------------------------------- */
+/* `b"".join(vocab[idx] for idx in ids)` (basic.py:51-55, regex.py:78-90, gpt4.py:87-92)
+ * for a batch of token ids.  The vocab is a table resident in HBM: entry i holds the
+ * bytes vocab_bytes[vocab_offsets[i] .. vocab_offsets[i+1]), i in [0, V).  Sparse ids
+ * (special tokens) are the caller's to map onto table indices.
+ *   bpe_decode_set_vocab   upload the table (kept until replaced)
+ *   bpe_decode_batch       ids -> bytes, left resident; *n_bytes = their number.  An id
+ *                          outside [0, V) fails with BPE_E_ARG and *bad_index = the first
+ *                          such position (the reference raises KeyError / ValueError there)
+ *   bpe_decode_read        copy the bytes out; with doc_token_offsets (k token positions,
+ *                          each <= n) also the byte offset of each of those positions. */
+int bpe_decode_set_vocab(bpe_ctx *ctx, const uint8_t *vocab_bytes, const uint64_t *vocab_offsets, int32_t V);
+int bpe_decode_batch(bpe_ctx *ctx, const int32_t *ids, uint64_t n, uint64_t *n_bytes, uint64_t *bad_index);
+int bpe_decode_read(bpe_ctx *ctx, uint8_t *out, uint64_t cap, const uint64_t *doc_token_offsets,
+                    uint64_t k, uint64_t *doc_byte_offsets_out);
+
 /* ---- measurement ------------------------------------------------------------ */
 #define BPE_PROF_WIDEN 0
 #define BPE_PROF_PAIR_COUNT 1
@@ -151,7 +167,8 @@ int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_i
 #define BPE_PROF_MERGE 3    /* merge pass(es) */
 #define BPE_PROF_TABLE 4    /* delta apply / table clear */
 #define BPE_PROF_ENCODE 5
-#define BPE_PROF_NKINDS 6
+#define BPE_PROF_DECODE 6
+#define BPE_PROF_NKINDS 7
 /* Accumulated since the last bpe_prof_reset: device ms (hipEvents on the ctx's
  * stream), launches, algorithmic bytes (4 B per id read or written,
  * tables and flags not counted). */

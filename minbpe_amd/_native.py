@@ -21,7 +21,7 @@ BPE_E_CAP = -5
 BPE_E_LIMIT = -6
 BPE_E_INTERNAL = -7
 
-PROF_KINDS = ("widen", "pair_count", "argmax", "merge", "table", "encode")
+PROF_KINDS = ("widen", "pair_count", "argmax", "merge", "table", "encode", "decode")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -64,6 +64,9 @@ _SIGS = {
     "bpe_comm_destroy": (C.c_int, [_p]),
     "bpe_dp_train": (C.c_int, [_p, _i32, _p, _p, _p, C.POINTER(_i32)]),
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
+    "bpe_decode_set_vocab": (C.c_int, [_p, _p, _p, _i32]),
+    "bpe_decode_batch": (C.c_int, [_p, _p, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
+    "bpe_decode_read": (C.c_int, [_p, _p, _u64, _p, _u64, _p]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
@@ -107,6 +110,10 @@ def split_offsets(data: bytes, which: int, threads: int = 0):
     if rc != BPE_OK:
         raise RuntimeError(f"bpe_split failed: {rc}")
     return out[:n.value].copy() if n.value * 2 < len(out) else out[:n.value]
+
+
+class InvalidToken(Exception):
+    """bpe_decode_batch met an id outside the vocab table; args[0] = its position."""
 
 
 def _ptr(a):
@@ -332,6 +339,34 @@ class Engine:
                                           _ptr(buf) if len(buf) else None, len(buf), _ptr(off),
                                           n_off, _ptr(out), _ptr(oo), C.byref(n_out)))
         return out[:n_out.value], oo
+
+    # -- decoding ----------------------------------------------------------------------
+    def decode_set_vocab(self, blob: bytes, offsets):
+        """Vocab table: entry i = blob[offsets[i]:offsets[i+1]]; stays resident in HBM."""
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._check(_lib.bpe_decode_set_vocab(self._h, _ptr(buf) if len(buf) else None, _ptr(off),
+                                              len(off) - 1))
+
+    def decode_batch(self, ids, doc_offsets=None):
+        """ids: int32 table indices.  Returns the concatenated bytes, or (bytes, byte offset of
+        each token position in doc_offsets).  An index outside the table raises
+        InvalidToken(position)."""
+        arr = np.ascontiguousarray(ids, dtype=np.int32)
+        nb, bad = _u64(0), _u64(0)
+        rc = _lib.bpe_decode_batch(self._h, _ptr(arr) if len(arr) else None, len(arr), C.byref(nb),
+                                   C.byref(bad))
+        if rc == BPE_E_ARG and bad.value != 0xFFFFFFFFFFFFFFFF:
+            raise InvalidToken(int(bad.value))
+        self._check(rc)
+        out = np.empty(max(nb.value, 1), np.uint8)
+        if doc_offsets is None:
+            self._check(_lib.bpe_decode_read(self._h, _ptr(out), len(out), None, 0, None))
+            return out[:nb.value].tobytes()
+        doff = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+        boff = np.zeros(len(doff), np.uint64)
+        self._check(_lib.bpe_decode_read(self._h, _ptr(out), len(out), _ptr(doff), len(doff), _ptr(boff)))
+        return out[:nb.value].tobytes(), boff
 
     # -- measurement ----------------------------------------------------------------
     def prof_reset(self):

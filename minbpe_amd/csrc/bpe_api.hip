@@ -78,7 +78,6 @@ struct bpe_ctx {
     uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
     unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
     int rep_shift = 5;        // log2(delta-vector replicas in use): shrinks as merges get rarer
-    bool rows_in_select = false;  // the next k_select recomputes the queued rows itself
     bool slotted = false;
     uint64_t slot_T = 0;
     int mq = 0;
@@ -111,6 +110,16 @@ struct bpe_ctx {
     uint32_t *d_ht_vals = nullptr;
     int32_t *d_merge_ids = nullptr;
     uint64_t cap_enc_n = 0, cap_enc_chunks = 0, cap_ht = 0, cap_merge_ids = 0;
+
+    // decode (grow-only): vocab table, then ids / lengths / offsets / bytes of the last batch
+    uint8_t *d_dec_blob = nullptr, *d_dec_out = nullptr;
+    unsigned long long *d_dec_voff = nullptr, *d_dec_off = nullptr, *d_dec_bsum = nullptr;
+    int32_t *d_dec_ids = nullptr;
+    uint32_t *d_dec_len = nullptr;
+    uint64_t cap_dec_blob = 0, cap_dec_voff = 0, cap_dec_n = 0, cap_dec_out = 0;
+    uint32_t dec_V = 0;
+    bool dec_have_vocab = false, dec_have_result = false;
+    uint64_t dec_n = 0, dec_total = 0;
 
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
@@ -157,6 +166,28 @@ int fail(bpe_ctx *c, int code, const char *fmt, ...) {
         int rc_ = (expr);      \
         if (rc_ != BPE_OK) return rc_; \
     } while (0)
+
+// scratch device allocation of one call, released on every exit path
+struct DevTmp {
+    void *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+struct EventList {
+    std::vector<hipEvent_t> v;
+    ~EventList() {
+        for (hipEvent_t e : v)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
 
 template <typename T>
 int dev_realloc(bpe_ctx *c, T *&p, size_t count) {
@@ -604,7 +635,9 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc, c->d_enc_tmp, c->d_enc_len, c->d_enc_out,
                     c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids,
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
-                    c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1]};
+                    c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1],
+                    c->d_dec_blob, c->d_dec_out, c->d_dec_voff, c->d_dec_off, c->d_dec_bsum, c->d_dec_ids,
+                    c->d_dec_len};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -756,13 +789,14 @@ int bpe_read_stats(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *cnt, uint64_t *
     if (!c) return BPE_E_ARG;
     if (!c->stats_valid) return fail(c, BPE_E_STATE, "bpe_get_stats has not been run on the current ids");
     HIPCHK(c, hipSetDevice(c->device));
-    int32_t *da = nullptr, *db = nullptr;
-    unsigned long long *dc = nullptr, *df = nullptr;
+    DevTmp ta, tb, tc, tf;
     const size_t capn = cap ? cap : 1;
-    HIPCHK(c, hipMalloc((void **)&da, capn * 4));
-    HIPCHK(c, hipMalloc((void **)&db, capn * 4));
-    HIPCHK(c, hipMalloc((void **)&dc, capn * 8));
-    HIPCHK(c, hipMalloc((void **)&df, capn * 8));
+    HIPCHK(c, ta.alloc(capn * 4));
+    HIPCHK(c, tb.alloc(capn * 4));
+    HIPCHK(c, tc.alloc(capn * 8));
+    HIPCHK(c, tf.alloc(capn * 8));
+    int32_t *da = ta.as<int32_t>(), *db = tb.as<int32_t>();
+    unsigned long long *dc = tc.as<unsigned long long>(), *df = tf.as<unsigned long long>();
     HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_dump_stats, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->d_first,
                        c->vcap, c->vcur, da, db, dc, df, (unsigned long long)cap, c->d_scratch);
@@ -779,10 +813,6 @@ int bpe_read_stats(bpe_ctx *c, int32_t *a, int32_t *b, uint64_t *cnt, uint64_t *
         HIPCHK(c, hipMemcpy(cnt, dc, np * 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(first_pos, df, np * 8, hipMemcpyDeviceToHost));
     }
-    (void)hipFree(da);
-    (void)hipFree(db);
-    (void)hipFree(dc);
-    (void)hipFree(df);
     if (n_out) *n_out = np;
     return rc;
 }
@@ -854,8 +884,9 @@ int bpe_read_chunk_starts(bpe_ctx *c, uint64_t *out, uint64_t cap, uint64_t *n_o
     if (!c) return BPE_E_ARG;
     if (!c->have_ids) return fail(c, BPE_E_STATE, "no ids loaded");
     HIPCHK(c, hipSetDevice(c->device));
-    unsigned long long *d_out = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_out, (cap ? cap : 1) * 8));
+    DevTmp t_out;
+    HIPCHK(c, t_out.alloc((cap ? cap : 1) * 8));
+    unsigned long long *d_out = t_out.as<unsigned long long>();
     HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long), c->stream));
     if (c->n) {
         hipLaunchKernelGGL(k_collect_starts, dim3(grid_for(c->n, 256, c->num_cus * 8)), dim3(256), 0,
@@ -873,7 +904,6 @@ int bpe_read_chunk_starts(bpe_ctx *c, uint64_t *out, uint64_t cap, uint64_t *n_o
         HIPCHK(c, hipMemcpy(out, d_out, ns * 8, hipMemcpyDeviceToHost));
         std::sort(out, out + ns);
     }
-    (void)hipFree(d_out);
     if (n_out) *n_out = ns;
     return rc;
 }
@@ -890,9 +920,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
     TRY(start_from_bytes(c));
     const bool delta = (c->mode == 1);
-    std::vector<hipEvent_t> evs;
+    EventList ev_list;  // destroyed on every exit path
+    std::vector<hipEvent_t> &evs = ev_list.v;
     if (iter_ms_out) {
-        evs.resize((size_t)num_merges + 1);
+        evs.assign((size_t)num_merges + 1, nullptr);
         for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
     }
     // statistics of the initial byte stream (iteration 0 of both modes)
@@ -907,7 +938,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     uint64_t cur_len = n0;  // exact length before iteration `consumed`
     bool stop = false;
     c->rep_shift = 5;
-    c->rows_in_select = false;
     const bool slots = delta && c->use_slots && c->merge_impl == 0;
     if (slots) TRY(slots_enter(c));
     // The device writes one IterRec per iteration into pinned host memory; the
@@ -1017,7 +1047,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             HIPCHK(c, hipEventElapsedTime(&ms, evs[(size_t)i], evs[(size_t)i + 1]));
             iter_ms_out[i] = ms;
         }
-        for (auto &e : evs) (void)hipEventDestroy(e);
     }
     TRY(prof_drain(c));
     if (n_done) *n_done = done;
@@ -1150,11 +1179,13 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         dst[n_long] = tot;
         TRY(ensure_table(c, 256));
         TRY(ensure_ids(c, tot));
-        unsigned long long *d_src = nullptr, *d_dst = nullptr, *d_cid = nullptr, *d_starts = nullptr;
-        HIPCHK(c, hipMalloc((void **)&d_src, n_long * 8));
-        HIPCHK(c, hipMalloc((void **)&d_dst, (n_long + 1) * 8));
-        HIPCHK(c, hipMalloc((void **)&d_cid, n_long * 8));
-        HIPCHK(c, hipMalloc((void **)&d_starts, (n_long + 1) * 8));
+        DevTmp t_src, t_dst, t_cid, t_starts;
+        HIPCHK(c, t_src.alloc(n_long * 8));
+        HIPCHK(c, t_dst.alloc((n_long + 1) * 8));
+        HIPCHK(c, t_cid.alloc(n_long * 8));
+        HIPCHK(c, t_starts.alloc((n_long + 1) * 8));
+        unsigned long long *d_src = t_src.as<unsigned long long>(), *d_dst = t_dst.as<unsigned long long>(),
+                           *d_cid = t_cid.as<unsigned long long>(), *d_starts = t_starts.as<unsigned long long>();
         HIPCHK(c, hipMemcpyAsync(d_src, src.data(), n_long * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (n_long + 1) * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(d_cid, ids_l.data(), n_long * 8, hipMemcpyHostToDevice, c->stream));
@@ -1202,10 +1233,6 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
                                c->d_enc_len);
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        (void)hipFree(d_src);
-        (void)hipFree(d_dst);
-        (void)hipFree(d_cid);
-        (void)hipFree(d_starts);
         if (rc_long != BPE_OK) return rc_long;
     }
     // 6. output offsets = exclusive scan of the per-chunk lengths
@@ -1230,6 +1257,132 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     }
     if (n_out) *n_out = total;
     TRY(prof_drain(c));
+    return BPE_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decode (N4)
+
+extern "C" int bpe_decode_set_vocab(bpe_ctx *c, const uint8_t *vocab_bytes, const uint64_t *vocab_offsets,
+                                    int32_t V) {
+    if (!c || V < 0 || !vocab_offsets) return fail(c, BPE_E_ARG, "bad arguments");
+    if (vocab_offsets[0] != 0) return fail(c, BPE_E_ARG, "vocab_offsets[0] must be 0");
+    for (int32_t i = 0; i < V; i++)
+        if (vocab_offsets[i + 1] < vocab_offsets[i])
+            return fail(c, BPE_E_ARG, "vocab_offsets must not decrease (entry %d)", i);
+    const uint64_t nb = vocab_offsets[V];
+    if (nb && !vocab_bytes) return fail(c, BPE_E_ARG, "vocab_bytes is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->dec_have_vocab = false;
+    c->dec_have_result = false;
+    if (nb + 16 > c->cap_dec_blob) {
+        TRY(dev_realloc(c, c->d_dec_blob, (size_t)nb + 16));
+        c->cap_dec_blob = nb + 16;
+    }
+    if ((uint64_t)V + 1 > c->cap_dec_voff) {
+        TRY(dev_realloc(c, c->d_dec_voff, (size_t)V + 1));
+        c->cap_dec_voff = (uint64_t)V + 1;
+    }
+    if (nb) HIPCHK(c, hipMemcpyAsync(c->d_dec_blob, vocab_bytes, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_dec_voff, vocab_offsets, ((size_t)V + 1) * sizeof(uint64_t),
+                             hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free its buffers on return
+    c->dec_V = (uint32_t)V;
+    c->dec_have_vocab = true;
+    return BPE_OK;
+}
+
+extern "C" int bpe_decode_batch(bpe_ctx *c, const int32_t *ids, uint64_t n, uint64_t *n_bytes,
+                                uint64_t *bad_index) {
+    if (!c || (!ids && n)) return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->dec_have_vocab) return fail(c, BPE_E_STATE, "bpe_decode_set_vocab first");
+    if (n_bytes) *n_bytes = 0;
+    if (bad_index) *bad_index = ~0ull;
+    c->dec_have_result = false;
+    c->dec_n = n;
+    c->dec_total = 0;
+    if (n == 0) {
+        c->dec_have_result = true;
+        return BPE_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (n > c->cap_dec_n) {
+        TRY(dev_realloc(c, c->d_dec_ids, (size_t)n));
+        TRY(dev_realloc(c, c->d_dec_len, (size_t)n));
+        TRY(dev_realloc(c, c->d_dec_off, (size_t)n + 1));
+        TRY(dev_realloc(c, c->d_dec_bsum, (size_t)nb + 1));
+        c->cap_dec_n = n;
+    }
+    unsigned long long *d_bad = c->d_scratch, *d_total = c->d_scratch + 1;
+    HIPCHK(c, hipMemcpyAsync(c->d_dec_ids, ids, n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_bad, 0xFF, sizeof(unsigned long long), c->stream));
+    TRY(prof_begin(c, BPE_PROF_DECODE, 4 * n));
+    hipLaunchKernelGGL(k_decode_len, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                       c->d_dec_ids, n, c->d_dec_voff, c->dec_V, c->d_dec_len, d_bad);
+    LAUNCHCHK(c, "k_decode_len");
+    hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_dec_len, n,
+                       c->d_dec_bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_dec_bsum, nb, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_dec_len, n,
+                       c->d_dec_bsum, c->d_dec_off);
+    LAUNCHCHK(c, "k_scan_*");
+    TRY(prof_end(c));
+    unsigned long long hb[2] = {0, 0};  // {first bad position, total bytes}
+    HIPCHK(c, hipMemcpyAsync(hb, c->d_scratch, sizeof hb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (hb[0] != ~0ull) {
+        if (bad_index) *bad_index = hb[0];
+        TRY(prof_drain(c));
+        return fail(c, BPE_E_ARG, "invalid token id: %d (position %llu)", ids[hb[0]], hb[0]);
+    }
+    const uint64_t total = hb[1];
+    if (total + 16 > c->cap_dec_out) {
+        TRY(dev_realloc(c, c->d_dec_out, (size_t)total + 16));
+        c->cap_dec_out = total + 16;
+    }
+    TRY(prof_begin(c, BPE_PROF_DECODE, total));
+    hipLaunchKernelGGL(k_decode_copy, dim3(grid_for(n, 256, c->num_cus * 8)), dim3(256), 0, c->stream,
+                       c->d_dec_ids, n, c->d_dec_voff, c->dec_V, c->d_dec_blob, c->d_dec_off, c->d_dec_out);
+    LAUNCHCHK(c, "k_decode_copy");
+    TRY(prof_end(c));
+    TRY(prof_drain(c));
+    c->dec_total = total;
+    c->dec_have_result = true;
+    if (n_bytes) *n_bytes = total;
+    return BPE_OK;
+}
+
+extern "C" int bpe_decode_read(bpe_ctx *c, uint8_t *out, uint64_t cap, const uint64_t *doc_token_offsets,
+                               uint64_t k, uint64_t *doc_byte_offsets_out) {
+    if (!c) return BPE_E_ARG;
+    if (!c->dec_have_result) return fail(c, BPE_E_STATE, "bpe_decode_batch first");
+    if (c->dec_total && (!out || cap < c->dec_total))
+        return fail(c, BPE_E_CAP, "need %llu bytes", (unsigned long long)c->dec_total);
+    if (k && (!doc_token_offsets || !doc_byte_offsets_out)) return fail(c, BPE_E_ARG, "offset arrays are NULL");
+    for (uint64_t j = 0; j < k; j++)
+        if (doc_token_offsets[j] > c->dec_n)
+            return fail(c, BPE_E_ARG, "doc_token_offsets[%llu] is past the last token", (unsigned long long)j);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->dec_total)
+        HIPCHK(c, hipMemcpyAsync(out, c->d_dec_out, c->dec_total, hipMemcpyDeviceToHost, c->stream));
+    if (k) {
+        if (c->dec_n == 0) {  // nothing was decoded: every offset is 0
+            for (uint64_t j = 0; j < k; j++) doc_byte_offsets_out[j] = 0;
+        } else {
+            DevTmp t_idx, t_dst;
+            HIPCHK(c, t_idx.alloc(k * 8));
+            HIPCHK(c, t_dst.alloc(k * 8));
+            HIPCHK(c, hipMemcpyAsync(t_idx.p, doc_token_offsets, k * 8, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_decode_doc_offsets, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, c->stream,
+                               c->d_dec_off, c->dec_n, (unsigned long long)c->dec_total, t_idx.as<unsigned long long>(), k,
+                               t_dst.as<unsigned long long>());
+            LAUNCHCHK(c, "k_decode_doc_offsets");
+            HIPCHK(c, hipMemcpyAsync(doc_byte_offsets_out, t_dst.p, k * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return BPE_OK;
 }
 
@@ -1521,13 +1674,13 @@ extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, 
     TRY(bpe_dp_end(c));
     // global lengths: one SUM over the per-shard lengths
     if (num_merges > 0) {
-        long long *d_l = nullptr;
-        HIPCHK(c, hipMalloc((void **)&d_l, (size_t)num_merges * 8));
+        DevTmp t_l;
+        HIPCHK(c, t_l.alloc((size_t)num_merges * 8));
+        long long *d_l = t_l.as<long long>();
         HIPCHK(c, hipMemcpyAsync(d_l, lens.data(), (size_t)num_merges * 8, hipMemcpyHostToDevice, c->stream));
         RCCLCHK(c, r->AllReduce(d_l, d_l, (size_t)num_merges, RCCL_INT64, RCCL_SUM, c->comm, c->stream));
         HIPCHK(c, hipMemcpyAsync(lens.data(), d_l, (size_t)num_merges * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(d_l);
         if (len_out)
             for (int i = 0; i < done; i++) len_out[i] = (uint64_t)lens[(size_t)i];
     }

@@ -169,14 +169,21 @@ def init_native_comm(engine, comm):
     import torch.distributed as dist
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(comm.group) == "nccl" else None
     ok = 1
-    try:
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if comm.rank == 0:
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if comm.rank == 0:
+        try:
             uid = torch.frombuffer(bytearray(engine.comm_unique_id()), dtype=torch.uint8).clone()
-        uid = uid.to(dev) if dev is not None else uid
-        dist.broadcast(uid, src=0, group=comm.group)
-        engine.comm_init(comm.rank, comm.world, bytes(uid.cpu().numpy().tobytes()))
-    except Exception:
+        except Exception:
+            ok = 0  # the zeros still go out, so that no rank is left waiting in the broadcast
+    uid = uid.to(dev) if dev is not None else uid
+    dist.broadcast(uid, src=0, group=comm.group)
+    raw = bytes(uid.cpu().numpy().tobytes())
+    if any(raw):
+        try:
+            engine.comm_init(comm.rank, comm.world, raw)
+        except Exception:
+            ok = 0
+    else:
         ok = 0
     flag = torch.tensor([ok], dtype=torch.int32)
     flag = flag.to(dev) if dev is not None else flag

@@ -158,6 +158,73 @@ class Tokenizer:
             self._mt_cache = (key, pairs, mids)
         return self._mt_cache[1], self._mt_cache[2]
 
+    # -- device decoding of a batch of token ids ---------------------------
+    def _decode_extra(self):
+        """ids decode() accepts besides self.vocab: {id: str}"""
+        return {}
+
+    def _invalid_token(self, idx):
+        return KeyError(idx)  # what `self.vocab[idx]` raises (basic.py:53, gpt4.py:89)
+
+    def _finish_bytes(self, raw):
+        return raw
+
+    def _decode_table(self):
+        """vocab (+ special tokens) as one dense table for the device: (blob, offsets, V,
+        sparse) where ids 0..V-1 are table indices as they are and `sparse` maps every
+        other known id to its index."""
+        extra = self._decode_extra()
+        key = (id(self.vocab), len(self.vocab), id(extra), len(extra))
+        cached = getattr(self, "_dt_cache", None)
+        if cached is None or cached[0] != key:
+            vocab = self.vocab
+            V = 0
+            while V in vocab:
+                V += 1
+            table = [vocab[i] for i in range(V)]
+            sparse = {}
+            for idx, tok in vocab.items():
+                if not 0 <= idx < V:
+                    sparse[idx] = len(table)
+                    table.append(tok)
+            for idx, tok in extra.items():
+                if idx not in vocab:
+                    sparse[idx] = len(table)
+                    table.append(tok.encode("utf-8"))
+            offs = np.zeros(len(table) + 1, dtype=np.uint64)
+            np.cumsum(np.fromiter((len(t) for t in table), dtype=np.uint64, count=len(table)), out=offs[1:])
+            self._dt_cache = (key, b"".join(table), offs, V, sparse)
+        return self._dt_cache[1:]
+
+    def decode_batch(self, ids, doc_offsets=None):
+        """The bytes decode() joins (`b"".join(vocab[idx] for idx in ids)`), produced on the
+        device for a whole batch of token ids at once; not in the reference (its decode is
+        a per-token Python loop).  With doc_offsets -- token positions, e.g. the start of
+        every document plus len(ids) -- also returns the byte offset of each position, so
+        document d is out[b[d]:b[d+1]].  Unknown ids raise what decode() raises, for the
+        first such id.  Returns bytes (no UTF-8 decoding: documents are cut on bytes)."""
+        arr = np.asarray(ids)
+        if arr.size and arr.dtype.kind not in "iu":
+            raise TypeError("token ids must be integers")
+        arr = arr.astype(np.int64, copy=False).reshape(-1)
+        blob, offs, V, sparse = self._decode_table()
+        outside = np.flatnonzero((arr < 0) | (arr >= V))
+        if len(outside):
+            arr = arr.copy()
+            for p in outside.tolist():
+                j = sparse.get(int(arr[p]))
+                if j is None:
+                    raise self._invalid_token(int(arr[p]))
+                arr[p] = j
+        eng = engine()
+        if getattr(eng, "_decode_owner", None) is not blob:  # the table stays resident per engine
+            eng.decode_set_vocab(blob, offs)
+            eng._decode_owner = blob
+        res = eng.decode_batch(arr.astype(np.int32), doc_offsets)
+        if doc_offsets is None:
+            return self._finish_bytes(res)
+        return self._finish_bytes(res[0]), res[1]
+
     # -- persistence (file formats of base.py:97-165, byte for byte) -----------------
     def save(self, file_prefix):
         lines = ["minbpe v1", f"{self.pattern}", f"{len(self.special_tokens)}"]
@@ -254,6 +321,12 @@ class RegexTokenizer(Tokenizer):
                 raise ValueError(f"invalid token id: {idx}")
         return b"".join(parts).decode("utf-8", errors="replace")
 
+    def _decode_extra(self):
+        return self.inverse_special_tokens
+
+    def _invalid_token(self, idx):
+        return ValueError(f"invalid token id: {idx}")  # regex.py:87
+
     def _prepare_chunk(self, chunk_bytes):
         return chunk_bytes  # GPT4Tokenizer permutes bytes here (a per-byte map)
 
@@ -345,6 +418,15 @@ class GPT4Tokenizer(RegexTokenizer):
     def decode(self, ids):
         raw = b"".join(self.vocab[i] for i in ids).translate(self._unshuffle_lut)
         return raw.decode("utf-8", errors="replace")
+
+    def _decode_extra(self):
+        return {}  # gpt4.py:89 looks ids up in self.vocab only
+
+    def _invalid_token(self, idx):
+        return KeyError(idx)
+
+    def _finish_bytes(self, raw):
+        return raw.translate(self._unshuffle_lut)
 
     def train(self, text, vocab_size, verbose=False):
         raise NotImplementedError

@@ -491,3 +491,85 @@ def test_dp_native_rccl_solo(native):
         assert eng.train(50)["pairs"] == exp[0][:50]
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------
+# batch decode (N4): b"".join(vocab[idx] for idx in ids) on the device
+
+def test_decode_batch_engine_level(engine, native):
+    rng = np.random.default_rng(5)
+    V = 1000
+    toks = [bytes(rng.integers(0, 256, size=int(L), dtype=np.uint8)) for L in rng.integers(0, 12, size=V)]
+    toks[3] = b""
+    toks[V - 1] = b"\xff" * 40
+    lens = np.array([len(t) for t in toks], dtype=np.int64)
+    offs = np.zeros(V + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    engine.decode_set_vocab(b"".join(toks), offs)
+    for n in (0, 1, 63, 64, 4096, 4097, 300_000):
+        ids = rng.integers(0, V, size=n, dtype=np.int32)
+        want = b"".join(toks[i] for i in ids)
+        assert engine.decode_batch(ids) == want
+        pos = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, size=50)])).astype(np.uint64)
+        got, boff = engine.decode_batch(ids, pos)
+        cum = np.concatenate([[0], np.cumsum(lens[ids])]).astype(np.int64)
+        assert got == want
+        assert boff.tolist() == cum[pos.astype(np.int64)].tolist()
+    # ids outside the table: the FIRST offending position is reported, nothing is returned
+    ids = rng.integers(0, V, size=10_000, dtype=np.int32)
+    ids[7000] = V
+    ids[400] = -1
+    with pytest.raises(native.InvalidToken) as ei:
+        engine.decode_batch(ids)
+    assert ei.value.args[0] == 400
+    ids[400] = 0
+    with pytest.raises(native.InvalidToken) as ei:
+        engine.decode_batch(ids)
+    assert ei.value.args[0] == 7000
+    # an empty table decodes nothing but the empty batch
+    engine.decode_set_vocab(b"", np.zeros(1, np.uint64))
+    assert engine.decode_batch(np.empty(0, np.int32)) == b""
+    with pytest.raises(native.InvalidToken):
+        engine.decode_batch(np.zeros(3, np.int32))
+
+
+def test_decode_batch_tokenizers(native):
+    from minbpe_amd import BasicTokenizer, RegexTokenizer
+    text = native.synth_text(2_000_000, 77).decode()
+    tok = RegexTokenizer()
+    tok.train(text[:300_000], 256 + 300)
+    tok.register_special_tokens({"<|endoftext|>": 100257})
+    doc = text + "<|endoftext|>" + text[:1000]
+    ids = tok.encode(doc, allowed_special="all")
+    raw = tok.decode_batch(ids)
+    assert raw == doc.encode("utf-8")
+    assert raw.decode("utf-8", errors="replace") == tok.decode(ids)
+    cut = ids.index(100257)
+    raw2, boff = tok.decode_batch(ids, [0, cut, cut + 1, len(ids)])
+    assert raw2 == raw
+    assert boff.tolist() == [0, len(text.encode()), len(text.encode()) + len("<|endoftext|>"), len(raw)]
+    with pytest.raises(ValueError, match="invalid token id: 90000"):
+        tok.decode_batch([65, 90000, 90001])
+    assert tok.decode_batch([]) == b""
+    b = BasicTokenizer()
+    b.train(text[:100_000], 256 + 50)
+    part = text[:200_000]
+    assert b.decode_batch(np.array(b.encode(part))) == part.encode("utf-8")
+    with pytest.raises(KeyError):
+        b.decode_batch([1, 4000])
+    # the two tokenizers share one engine: each call re-installs its own table when needed
+    assert tok.decode_batch(ids[:100]) == b"".join(tok.vocab[i] for i in ids[:100])
+
+
+def test_encode_decode_round_trip_20mb(native):
+    """size-independent property at a bench-sized batch: decode(encode(x)) == x"""
+    from minbpe_amd import RegexTokenizer
+    text = native.synth_text(20_000_000, 78).decode()
+    tok = RegexTokenizer()
+    tok.train(text[:1_000_000], 256 + 1000)
+    data, offs = tok._chunked(text)
+    ids, out_off = tok._encode_flat(data, offs)
+    assert len(out_off) == len(offs) + 1 and int(out_off[-1]) == len(ids) < len(data)
+    raw, boff = tok.decode_batch(ids, out_off)
+    assert raw == data
+    assert np.array_equal(boff[:-1], offs) and int(boff[-1]) == len(data)

@@ -17,6 +17,12 @@ for cls in (RegexTokenizer, BasicTokenizer):
     t0 = time.time(); ids = tok.encode(sample); t_enc = time.time() - t0
     t0 = time.time(); back = tok.decode(ids); t_dec = time.time() - t0
     assert back == sample
+    import numpy as np
+    arr = np.asarray(ids, dtype=np.int32)
+    tok.decode_batch(arr[:1000])  # installs the vocab table
+    t0 = time.time(); raw = tok.decode_batch(arr); t_decb = time.time() - t0
+    assert raw == sample.encode("utf-8")
     out[cls.__name__] = dict(train_s=round(t_train, 3), merges=len(tok.merges), encode_20MB_s=round(t_enc, 3),
-                             tokens=len(ids), decode_s=round(t_dec, 3))
+                             tokens=len(ids), decode_s=round(t_dec, 3),
+                             decode_batch_s=round(t_decb, 4))
 print(json.dumps(out))
