@@ -54,6 +54,15 @@ int bpe_set_option(bpe_ctx *ctx, const char *name, int64_t value);
  * Uploads the bytes; they stay resident so bpe_train can be re-run. */
 int bpe_load_bytes(bpe_ctx *ctx, const uint8_t *bytes, uint64_t n,
                    const uint64_t *chunk_offsets, uint64_t n_chunks);
+/* The same with a weight per chunk: every pair inside chunk c counts
+ * 2^weight_exp[c] times (weight_exp[c] <= 31).  A chunk that occurs w times in the text
+ * (regex.py:41-44 keeps all w copies) can be loaded once per set bit of w -- see
+ * bpe_dedup_chunks, which builds exactly that list in first-appearance order, so that
+ * counts AND the first-occurrence tie-break are those of the full list.  Stream lengths
+ * reported by bpe_train then refer to the de-duplicated stream. */
+int bpe_load_bytes_weighted(bpe_ctx *ctx, const uint8_t *bytes, uint64_t n,
+                            const uint64_t *chunk_offsets, uint64_t n_chunks,
+                            const uint8_t *weight_exp);
 /* Arbitrary id lists, for the module-level get_stats()/merge() drop-ins
  * (base.py:13-41 called on user lists). */
 int bpe_load_ids(bpe_ctx *ctx, const int32_t *ids, uint64_t n,
@@ -183,6 +192,17 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
  * returns BPE_E_CAP (with *n_chunks set) if cap is too small.  threads <= 0: all cores. */
 int bpe_split(int which, const uint8_t *utf8, uint64_t n, uint64_t *starts_out, uint64_t cap,
               uint64_t *n_chunks, int threads);
+
+/* ---- chunk de-duplication (host, no GPU needed) ---------------------------- */
+/* In: the chunk list of regex.py:41-44 as bytes + chunk START offsets (chunk c ends where
+ * chunk c+1 starts, the last one at n).  Out: the distinct chunks in order of first
+ * appearance, each emitted once per set bit k of its multiplicity with weight_exp = k (so
+ * the emitted weights 2^k sum to the multiplicity).  The output never exceeds the input:
+ * out_bytes needs n bytes, out_offsets and out_weight_exp need n_chunks entries.
+ * threads <= 0: all cores. */
+int bpe_dedup_chunks(const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets, uint64_t n_chunks,
+                     uint8_t *out_bytes, uint64_t *out_offsets, uint8_t *out_weight_exp,
+                     uint64_t *n_out_bytes, uint64_t *n_out_chunks, uint64_t *n_distinct, int threads);
 
 /* ---- host utilities (no GPU needed) ------------------------------------------ */
 /* Deterministic synthetic UTF-8 text (SURVEY 8d synth_text): explicit

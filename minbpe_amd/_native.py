@@ -6,6 +6,7 @@ build command; if no GPU is present, Engine() raises RuntimeError.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -28,7 +29,27 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -m minbpe_amd.build` "
         "(hipcc --offload-arch=gfx950). minbpe_amd has no CPU fallback.")
 
-_lib = C.CDLL(LIB_PATH)
+
+
+def _load_library():
+    """PyTorch ships private copies of libamdhip64 / libhsa-runtime64.  Two HIP runtimes cannot
+    both bring up the same GPU in one process (the second one reports "No HIP GPUs are
+    available"; measured, tools/gpu_probe.sh), and which copy a process ends up with is decided
+    by load order: with torch imported first, this library binds to torch's copy (same SONAME)
+    and the process has one runtime.  So when torch is installed it is imported before the
+    library is loaded -- the order bench.py and the GPU tests run in.  MINBPE_AMD_NO_TORCH=1
+    skips this (for processes that will never import torch)."""
+    if "torch" not in sys.modules and not os.environ.get("MINBPE_AMD_NO_TORCH"):
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:
+            pass
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load_library()
 _p = C.c_void_p
 _u64 = C.c_uint64
 _i32 = C.c_int32
@@ -40,6 +61,7 @@ _SIGS = {
     "bpe_set_stream": (C.c_int, [_p, _p]),
     "bpe_set_option": (C.c_int, [_p, C.c_char_p, C.c_int64]),
     "bpe_load_bytes": (C.c_int, [_p, _p, _u64, _p, _u64]),
+    "bpe_load_bytes_weighted": (C.c_int, [_p, _p, _u64, _p, _u64, _p]),
     "bpe_load_ids": (C.c_int, [_p, _p, _u64, _p, _u64]),
     "bpe_get_stats": (C.c_int, [_p, C.POINTER(_u64)]),
     "bpe_read_stats": (C.c_int, [_p, _p, _p, _p, _p, _u64, C.POINTER(_u64)]),
@@ -70,6 +92,8 @@ _SIGS = {
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
+    "bpe_dedup_chunks": (C.c_int, [_p, _u64, _p, _u64, _p, _p, _p, C.POINTER(_u64), C.POINTER(_u64),
+                                  C.POINTER(_u64), C.c_int]),
     "bpe_synth_text": (C.c_int, [_p, _u64, _u64]),
     "bpe_version": (C.c_char_p, []),
 }
@@ -110,6 +134,24 @@ def split_offsets(data: bytes, which: int, threads: int = 0):
     if rc != BPE_OK:
         raise RuntimeError(f"bpe_split failed: {rc}")
     return out[:n.value].copy() if n.value * 2 < len(out) else out[:n.value]
+
+
+def dedup_chunks(data: bytes, offsets, threads: int = 0):
+    """Distinct chunks of (data, chunk start offsets) in order of first appearance, one copy
+    per set bit of the multiplicity (host only).  Returns (data2, offsets2, weight_exp uint8,
+    n_distinct)."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.empty(max(len(buf), 1), np.uint8)
+    ooff = np.empty(max(len(off), 1), np.uint64)
+    wexp = np.empty(max(len(off), 1), np.uint8)
+    nb, nc, nd = _u64(0), _u64(0), _u64(0)
+    rc = _lib.bpe_dedup_chunks(_ptr(buf) if len(buf) else None, len(buf), _ptr(off) if len(off) else None,
+                               len(off), _ptr(out), _ptr(ooff), _ptr(wexp), C.byref(nb), C.byref(nc),
+                               C.byref(nd), threads)
+    if rc != BPE_OK:
+        raise RuntimeError(f"bpe_dedup_chunks failed: {rc}")
+    return out[:nb.value].tobytes(), ooff[:nc.value].copy(), wexp[:nc.value].copy(), int(nd.value)
 
 
 class InvalidToken(Exception):
@@ -176,12 +218,20 @@ class Engine:
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         return off, len(off)
 
-    def load_bytes(self, data, offsets=None):
+    def load_bytes(self, data, offsets=None, weight_exp=None):
+        """weight_exp (uint8 per chunk): pairs inside chunk c count 2**weight_exp[c] times."""
         buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
         off, n_off = self._offsets(offsets)
         self._keep = (buf, off)
-        self._check(_lib.bpe_load_bytes(self._h, _ptr(buf) if len(buf) else None, len(buf),
-                                        _ptr(off), n_off))
+        if weight_exp is None:
+            self._check(_lib.bpe_load_bytes(self._h, _ptr(buf) if len(buf) else None, len(buf),
+                                            _ptr(off), n_off))
+            return
+        w = np.ascontiguousarray(weight_exp, dtype=np.uint8)
+        if off is None or len(w) != n_off:
+            raise ValueError("weight_exp needs one entry per chunk offset")
+        self._check(_lib.bpe_load_bytes_weighted(self._h, _ptr(buf) if len(buf) else None, len(buf),
+                                                 _ptr(off), n_off, _ptr(w)))
 
     def load_ids(self, ids, offsets=None):
         arr = np.ascontiguousarray(ids, dtype=np.int32)

@@ -47,6 +47,9 @@ struct bpe_ctx {
     uint64_t *d_offsets = nullptr;
     uint64_t n_chunks = 0, cap_offsets = 0;
     bool have_bytes = false;
+    uint8_t *d_wexp = nullptr;  // per chunk: weight exponent (bpe_load_bytes_weighted)
+    uint64_t cap_wexp = 0;
+    bool weighted = false;
 
     // id stream
     uint32_t *d_ids[2] = {nullptr, nullptr};
@@ -323,6 +326,11 @@ int start_from_bytes(bpe_ctx *c) {
             hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)),
                                dim3(256), 0, c->stream, c->d_ids[0], c->d_offsets, c->n_chunks, n);
             LAUNCHCHK(c, "k_mark_starts");
+            if (c->weighted) {
+                hipLaunchKernelGGL(k_mark_weights, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)), dim3(256),
+                                   0, c->stream, c->d_ids[0], c->d_offsets, c->d_wexp, c->n_chunks, n);
+                LAUNCHCHK(c, "k_mark_weights");
+            }
         }
     }
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
@@ -358,7 +366,8 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
             hipLaunchKernelGGL(k_pair_count_simple<false>, dim3(grid_for(n, 1024, c->num_cus * 8)),
                                dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
                                c->vcap, (uint32_t *)nullptr);
-        } else if (c->k1 == 2 && c->vcur <= 256 && c->stream_is_bytes) {
+        } else if (c->k1 == 2 && c->vcur <= 256 && c->stream_is_bytes && !c->weighted) {
+            // (16-bit LDS counters: unit increments only)
             hipLaunchKernelGGL(k_pair_count_bytes, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
                                dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
                                c->par, c->d_mat, c->vcap);
@@ -637,7 +646,7 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
                     c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1],
                     c->d_dec_blob, c->d_dec_out, c->d_dec_voff, c->d_dec_off, c->d_dec_bsum, c->d_dec_ids,
-                    c->d_dec_len};
+                    c->d_dec_len, c->d_wexp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -683,11 +692,12 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     return BPE_OK;
 }
 
-int bpe_load_bytes(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
-                   uint64_t n_chunks) {
+static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                           uint64_t n_chunks, const uint8_t *wexp) {
     if (!c || (!bytes && n)) return fail(c, BPE_E_ARG, "bytes is NULL");
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream of %llu bytes exceeds 2^32-1 per GPU",
                                        (unsigned long long)n);
+    if (wexp && !chunk_offsets) return fail(c, BPE_E_ARG, "weights need chunk offsets");
     HIPCHK(c, hipSetDevice(c->device));
     if (n + 16 > c->cap_bytes) {
         TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
@@ -706,6 +716,18 @@ int bpe_load_bytes(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t 
     if (n_chunks)
         HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
                                  hipMemcpyHostToDevice, c->stream));
+    c->weighted = false;
+    if (wexp && n_chunks) {
+        for (uint64_t i = 0; i < n_chunks; i++)
+            if (wexp[i] > 31) return fail(c, BPE_E_ARG, "weight exponent %u of chunk %llu exceeds 31", wexp[i],
+                                          (unsigned long long)i);
+        if (n_chunks > c->cap_wexp) {
+            TRY(dev_realloc(c, c->d_wexp, (size_t)n_chunks));
+            c->cap_wexp = n_chunks;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_wexp, wexp, n_chunks, hipMemcpyHostToDevice, c->stream));
+        c->weighted = true;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free its buffers on return
     c->nbytes = n;
     c->n_chunks = n_chunks;
@@ -713,6 +735,17 @@ int bpe_load_bytes(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t 
     TRY(ensure_table(c, 256));
     TRY(start_from_bytes(c));
     return BPE_OK;
+}
+
+int bpe_load_bytes(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                   uint64_t n_chunks) {
+    return load_bytes_impl(c, bytes, n, chunk_offsets, n_chunks, nullptr);
+}
+
+int bpe_load_bytes_weighted(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                            uint64_t n_chunks, const uint8_t *weight_exp) {
+    if (!weight_exp) return fail(c, BPE_E_ARG, "weight_exp is NULL");
+    return load_bytes_impl(c, bytes, n, chunk_offsets, n_chunks, weight_exp);
 }
 
 int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chunk_offsets,
@@ -755,6 +788,7 @@ int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chu
     c->apply_target = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_bytes = false;
+    c->weighted = false;
     c->stream_is_bytes = false;
     c->par = 0;
     c->n = n;
@@ -1093,6 +1127,7 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     HIPCHK(c, hipSetDevice(c->device));
     // this call reuses the ctx's input and id-stream buffers
     c->have_bytes = false;
+    c->weighted = false;
     c->have_ids = false;
     c->stats_valid = false;
 

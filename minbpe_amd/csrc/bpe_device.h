@@ -7,7 +7,12 @@ namespace bpe {
 
 // id-stream word format
 constexpr uint32_t FLAG = 0x80000000u;          // bit 31: token starts a chunk
-constexpr uint32_t IDMASK = 0x7FFFFFFFu;        // bits 0..30: token id
+constexpr uint32_t IDMASK = 0x03FFFFFFu;        // bits 0..25: token id
+// bits 26..30: weight exponent e of the token's chunk -- every pair inside the chunk counts
+// 2^e times (chunk de-duplication; 0 everywhere for an unweighted stream)
+constexpr int WSHIFT = 26;
+constexpr uint32_t WMASK = 0x7C000000u;
+constexpr uint32_t NWMASK = ~WMASK;             // flag + id: what a pair comparison looks at
 constexpr uint32_t INVALID_WORD = 0xFFFFFFFFu;  // positions >= n inside a tile
 constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;     // LDS cache: free slot
 constexpr unsigned long long NOPOS = ~0ull;

@@ -32,6 +32,8 @@ namespace bpe {
 // small wave / block helpers (wave = 64 lanes, hard-coded: gfx950 only)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// what one pair inside the chunk of word w adds to a count: 2^(weight exponent)
+__device__ __forceinline__ uint32_t word_weight(uint32_t w) { return 1u << ((w >> WSHIFT) & 31u); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -126,6 +128,18 @@ __global__ void k_mark_starts(uint32_t *ids, const uint64_t *__restrict__ off, u
     }
 }
 
+// weighted chunks (N1): every word of chunk c carries the chunk's weight exponent
+__global__ void k_mark_weights(uint32_t *ids, const uint64_t *__restrict__ off, const uint8_t *__restrict__ wexp,
+                               uint64_t n_chunks, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
+        const uint32_t e = (uint32_t)(wexp[c] & 31u) << WSHIFT;
+        if (!e) continue;
+        const uint64_t p0 = off[c], p1 = (c + 1 < n_chunks) ? off[c + 1] : n;
+        for (uint64_t p = p0; p < p1 && p < n; p++) ids[p] |= e;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1: get_stats  (base.py:13-22; shared dict over chunks regex.py:51-54)
 //
@@ -144,8 +158,8 @@ k_pair_count_simple(const uint32_t *__restrict__ ids, const DevState *__restrict
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (p + k + 1 < n && !(x[k + 1] & FLAG)) {
-                const size_t idx = (size_t)(x[k] & IDMASK) * stride + x[k + 1];
-                atomicAdd(&mat[idx], 1u);
+                const size_t idx = (size_t)(x[k] & IDMASK) * stride + (x[k + 1] & IDMASK);
+                atomicAdd(&mat[idx], word_weight(x[k]));
                 if (FIRST) atomicMin(&first[idx], (uint32_t)(p + k));
             }
         }
@@ -201,7 +215,7 @@ k_pair_count_lds(const uint32_t *__restrict__ ids, const DevState *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (p + k + 1 < n && !(x[k + 1] & FLAG))
-                cache_add(s_keys, s_vals, mat, (x[k] & IDMASK) * stride + x[k + 1], 1u);
+                cache_add(s_keys, s_vals, mat, (x[k] & IDMASK) * stride + (x[k + 1] & IDMASK), word_weight(x[k]));
         }
     }
     __syncthreads();
@@ -417,7 +431,7 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
                     if (q + 1 < len) w1 = src[q + 1];
                     else if (!slot_next(ref, n, (uint64_t)u * TILE + q, w1)) continue;
                     if (w1 & FLAG) continue;
-                    if (tie_hit(s_tied, nt, M, mat, stride, src[q] & IDMASK, w1)) {
+                    if (tie_hit(s_tied, nt, M, mat, stride, src[q] & IDMASK, w1 & IDMASK)) {
                         atomicMin(&s_first, u * TILE + q);
                         break;
                     }
@@ -429,7 +443,7 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
             if (__atomic_load_n(&s_first, __ATOMIC_RELAXED) < p) break;  // an earlier hit exists
             uint32_t w0, w1;
             if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;
-            if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1)) {
+            if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1 & IDMASK)) {
                 atomicMin(&s_first, p);
                 break;
             }
@@ -453,7 +467,7 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
             slot_next(ref, st->n[par], s_first, w1);
             st->found = 1;
             st->a = (int32_t)(w0 & IDMASK);
-            st->b = (int32_t)w1;
+            st->b = (int32_t)(w1 & IDMASK);
         } else {
             st->found = 0;
         }
@@ -508,7 +522,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
         if (__atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) < p) break;
         uint32_t w0, w1;
         if (!slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1) || (w1 & FLAG)) continue;
-        if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1)) {
+        if (tie_hit(s_tied, nt, M, mat, stride, w0 & IDMASK, w1 & IDMASK)) {
             atomicMin(&st->firstpos, (unsigned long long)p);
             break;  // later positions of this thread cannot be earlier
         }
@@ -527,7 +541,7 @@ __device__ __forceinline__ bool resolved_pair(const DevState *st, const uint32_t
     const unsigned long long p = st->firstpos;
     if (p == NOPOS) return false;
     a = ids[p] & IDMASK;
-    b = ids[p + 1];
+    b = ids[p + 1] & IDMASK;
     return true;
 }
 
@@ -542,7 +556,7 @@ __device__ __forceinline__ bool resolved_pair(const DevState *st, const SlotRef 
     uint32_t w0, w1;
     if (p == NOPOS || !slot_get(ref, n, p, w0) || !slot_next(ref, n, p, w1)) return false;
     a = w0 & IDMASK;
-    b = w1;
+    b = w1 & IDMASK;
     return true;
 }
 
@@ -666,7 +680,7 @@ __device__ __forceinline__ void tile_rbits(Tile &t, uint32_t a, uint32_t b) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t nxt = (k < 3) ? t.x[j][k + 1] : nx[j];
-            rb |= (uint32_t)(((t.x[j][k] & IDMASK) == a) & (nxt == b)) << k;
+            rb |= (uint32_t)(((t.x[j][k] & IDMASK) == a) & ((nxt & NWMASK) == b)) << k;
         }
         t.rb[j] = rb;
     }
@@ -989,7 +1003,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
             for (int k = 0; k < 4; k++) {
                 if ((kb[j] >> k) & 1u) {
                     const uint32_t w = t.x[j][k];
-                    dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                    dst[o++] = ((mb[j] >> k) & 1u) ? (newid | (w & (FLAG | WMASK))) : w;
                 }
             }
         }
@@ -1006,7 +1020,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                     for (int k = 0; k < 4; k++) {
                         if ((kb[j] >> k) & 1u) {
                             const uint32_t w = t.x[j][k];
-                            const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & FLAG)) : w;
+                            const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & (FLAG | WMASK))) : w;
                             if (gi < 3) hdr4[gi] = ow;
                             if (gi + 1 == total) hdr4[3] = ow;
                             gi++;
@@ -1024,7 +1038,8 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         uint32_t near = 0;
 #pragma unroll
         for (int j = 0; j < MJ; j++) near |= mb[j] | mp[j];
-        near |= (uint32_t)((((t0 & IDMASK) == a) & (t1 == b)) | (((t1 & IDMASK) == a) & (t2 == b)));
+        near |= (uint32_t)((((t0 & IDMASK) == a) & ((t1 & NWMASK) == b)) |
+                           (((t1 & IDMASK) == a) & ((t2 & NWMASK) == b)));
         if (!__any(near != 0)) return;
         // same-address atomics serialise (~11 ns each): spread them over replicas
         const uint32_t nrep = 1u << (vcap >> 24);  // host packs log2(replicas) above the stride
@@ -1042,9 +1057,9 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                 up_x1 = lane_first(t.x[(j + 1) % MJ][1]);
             } else {
                 const uint32_t m3 = (mb[j] >> 3) & 1u;  // only lane 63's value is used
-                const uint32_t r4 = (uint32_t)(((t0 & IDMASK) == a) & (t1 == b));
+                const uint32_t r4 = (uint32_t)(((t0 & IDMASK) == a) & ((t1 & NWMASK) == b));
                 const uint32_t m4 = r4 & (m3 ^ 1u);
-                const uint32_t r5 = (uint32_t)(((t1 & IDMASK) == a) & (t2 == b));
+                const uint32_t r5 = (uint32_t)(((t1 & IDMASK) == a) & ((t2 & NWMASK) == b));
                 const uint32_t m5 = r5 & (m4 ^ 1u);
                 up_m = m4 | (m5 << 1);
                 up_x0 = t0;
@@ -1061,16 +1076,17 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                     const uint32_t Mk = (Mx >> (k + 1)) & 1u, Mkm1 = (Mx >> k) & 1u,
                                    Mkp1 = (Mx >> (k + 2)) & 1u;
                     if (qw + j * 256 + k >= own_len) continue;  // context word, not mine
+                    const uint32_t wt = word_weight(X[k]);  // every word involved shares X[k]'s chunk
                     if (!(X[k + 1] & FLAG) && !Mk) {  // an old pair that is not the site itself
-                        if (Mkm1) atomicAdd(&delta[1 * (size_t)vcap + X[k + 1]], 1u);
-                        else if (Mkp1) atomicAdd(&delta[0 * (size_t)vcap + (X[k] & IDMASK)], 1u);
+                        if (Mkm1) atomicAdd(&delta[1 * (size_t)vcap + (X[k + 1] & IDMASK)], wt);
+                        else if (Mkp1) atomicAdd(&delta[0 * (size_t)vcap + (X[k] & IDMASK)], wt);
                     }
                     if (!Mkm1) {  // output element
                         const uint32_t Xq = Mk ? X[k + 2] : X[k + 1];
                         const uint32_t Mq = Mk ? ((Mx >> (k + 3)) & 1u) : Mkp1;
                         if (!(Xq & FLAG)) {
-                            if (Mk) atomicAdd(&delta[3 * (size_t)vcap + (Mq ? newid : Xq)], 1u);
-                            else if (Mq) atomicAdd(&delta[2 * (size_t)vcap + (X[k] & IDMASK)], 1u);
+                            if (Mk) atomicAdd(&delta[3 * (size_t)vcap + (Mq ? newid : (Xq & IDMASK))], wt);
+                            else if (Mq) atomicAdd(&delta[2 * (size_t)vcap + (X[k] & IDMASK)], wt);
                         }
                     }
                 }
@@ -1532,7 +1548,7 @@ __device__ __forceinline__ void merge_slot_tile(
     tile_rbits(tl, a, b);
     // carry: the previous slot ended with a site start iff its last id is a and my first word is b
     // (thread 0 stored my first word next to the neighbours' in s_ctx)
-    uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & (s_first_word == b));
+    uint32_t s = (uint32_t)((prev != INVALID_WORD) & ((prev & IDMASK) == a) & ((s_first_word & NWMASK) == b));
     if (a == b) {
         // a == b: the carry is the PARITY of the run of a's that ends at the previous slot's
         // last id (F2).  Walk that run backwards, 64 ids per step; only if it swallows the whole
@@ -1560,7 +1576,7 @@ __device__ __forceinline__ void merge_slot_tile(
                     const uint32_t xq = (q >= 0) ? pu[q] : INVALID_WORD;
                     uint32_t nx = (uint32_t)__shfl_up((int)xq, 1);
                     if (lane == 0) nx = nextw;
-                    const bool r = (q >= 0) && ((xq & IDMASK) == a) && (nx == a);
+                    const bool r = (q >= 0) && ((xq & IDMASK) == a) && ((nx & NWMASK) == a);
                     const unsigned long long zeros = __ballot(!r);
                     if (zeros) {
                         ones += __ffsll((long long)zeros) - 1;
@@ -1616,7 +1632,7 @@ __device__ __forceinline__ void merge_slot_tile(
         }
         // a full slot: the word after it is the last wave's tail, not one of my registers
         if (len == TILE && wave_id() == MT / 64 - 1)
-            anyr |= (uint32_t)(((tl.tail[0] & IDMASK) == a) & (tl.tail[1] == b));
+            anyr |= (uint32_t)(((tl.tail[0] & IDMASK) == a) & ((tl.tail[1] & NWMASK) == b));
         if (!__syncthreads_or((int)(anyr != 0))) {
             if (threadIdx.x == 0) {
                 meta_out[t] = mi;
@@ -1870,7 +1886,7 @@ __global__ void k_dp_key(SlotRef ref, int par, const DevState *__restrict__ st,
             slot_get(ref, st->n[par], st->firstpos, x0);
             slot_next(ref, st->n[par], st->firstpos, x1);
             w0 = (long long)((k << 16) | (x0 & IDMASK));
-            w1 = (long long)((k << 16) | x1);
+            w1 = (long long)((k << 16) | (x1 & IDMASK));
         }
     }
     key[0] = w0;

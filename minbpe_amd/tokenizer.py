@@ -112,11 +112,11 @@ class Tokenizer:
         return vocab
 
     # -- device training shared by Basic/Regex ------------------------------------
-    def _train_on_device(self, data: bytes, offsets, vocab_size: int, verbose: bool):
+    def _train_on_device(self, data: bytes, offsets, vocab_size: int, verbose: bool, weight_exp=None):
         assert vocab_size >= 256
         num_merges = vocab_size - 256
         eng = engine()
-        eng.load_bytes(data, offsets)
+        eng.load_bytes(data, offsets, weight_exp)
         failure = None
         try:
             res = eng.train(num_merges)
@@ -302,9 +302,20 @@ class RegexTokenizer(Tokenizer):
             return data, _native.split_offsets(data, which)
         return _concat_chunks(self._split(text))
 
+    # Train on the DISTINCT chunks, each weighted by how often it occurs (bpe_dedup_chunks):
+    # same merges, counts and tie-breaks as over the full chunk list, a fraction
+    # of the stream.  The host pass costs about as much as ~6000 device merges over the full
+    # list (profiles/r1_notes.md), so "auto" turns it on from there; True / False force it.
+    dedup = "auto"
+    DEDUP_AUTO_MERGES = 6000
+
     def train(self, text, vocab_size, verbose=False):
         data, offs = self._chunked(text)
-        self._train_on_device(data, offs, vocab_size, verbose)
+        wexp = None
+        want = (vocab_size - 256 >= self.DEDUP_AUTO_MERGES) if self.dedup == "auto" else bool(self.dedup)
+        if want and len(offs) > 1:
+            data, offs, wexp, _ = _native.dedup_chunks(data, offs)
+        self._train_on_device(data, offs, vocab_size, verbose, wexp)
 
     def register_special_tokens(self, special_tokens):
         self.special_tokens = special_tokens

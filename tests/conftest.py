@@ -11,6 +11,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # GPU session: bring torch's HIP runtime up BEFORE libbpe_hip.so loads its own copy, the order
+    # bench.py uses (torch ships a private libamdhip64 / libhsa-runtime64; initialising it second,
+    # late in a long-lived process, was seen to fail with "No HIP GPUs are available").
+    markexpr = config.getoption("markexpr", "") or ""
+    if "gpu" in markexpr and "not gpu" not in markexpr and not os.environ.get("MINBPE_TEST_TORCH_LATE"):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:  # torch is optional for everything but the torch.distributed-driven tests
+            pass
 
 
 @pytest.fixture(scope="session")

@@ -188,11 +188,15 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots):
 # ---------------------------------------------------------------------------
 # the drop-in classes
 
-def test_classes_golden(golden, native):
+@pytest.mark.parametrize("dedup", [True, False])
+def test_classes_golden(golden, native, dedup):
     from minbpe_amd import BasicTokenizer, RegexTokenizer
     for case in golden["train"]:
+        if case["kind"] == "basic" and not dedup:
+            continue  # BasicTokenizer has one chunk: nothing to de-duplicate either way
         cls = BasicTokenizer if case["kind"] == "basic" else RegexTokenizer
         tok = cls()
+        tok.dedup = dedup
         text = case_text(case, native)
         if case["raises_value_error"]:
             with pytest.raises(ValueError):
@@ -336,7 +340,7 @@ def _space_chunks(text: bytes):
     return [c for c in re.findall(rb" ?[^ ]+| +", text) if c]
 
 
-def _lockstep(native, chunks, nm, world, slots=1):
+def _lockstep(native, chunks, nm, world, slots=1, dedup=False):
     """Drive `world` ctxs through the dist.py protocol in lock-step; reductions done by hand."""
     import torch
     from minbpe_amd.dist import GpuShard, shard_chunks
@@ -348,7 +352,11 @@ def _lockstep(native, chunks, nm, world, slots=1):
         eng.set_option("slots", slots)
         data = b"".join(mine)
         offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
-        eng.load_bytes(data, offs)
+        if dedup:  # every rank de-duplicates its own shard
+            d2, o2, w, _ = native.dedup_chunks(data, offs)
+            eng.load_bytes(d2, o2, w)
+        else:
+            eng.load_bytes(data, offs)
         sh = GpuShard(eng, 0)
         sh.begin(nm, r, world)
         shards.append(sh)
@@ -573,3 +581,68 @@ def test_encode_decode_round_trip_20mb(native):
     raw, boff = tok.decode_batch(ids, out_off)
     assert raw == data
     assert np.array_equal(boff[:-1], offs) and int(boff[-1]) == len(data)
+
+
+# ---------------------------------------------------------------------------
+# weighted chunks (N1): the distinct chunks, weighted, train like the full chunk list
+
+def _weighted_cases(native):
+    rng = np.random.default_rng(12)
+    yield native.synth_text(600_000, 71).decode(), 300
+    # tiny alphabet: ties at the maximum, a == b runs, multiplicities with many set bits; runs empty
+    words = ["".join("ab"[int(x)] for x in rng.integers(0, 2, size=int(L))) for L in rng.integers(1, 9, size=60)]
+    yield " ".join(words[int(i)] for i in rng.integers(0, len(words), size=150_000)), 120
+    # runs of one symbol longer than a slot (4096 ids), repeated so that they carry weight
+    yield ("a" * 9001 + " ") * 3 + "aaaaaaa " * 5000 + "aaaa bbbb abab " * 3000 + ("b" * 4097 + " ") * 6, 40
+
+
+def _train_or_partial(eng, nm):
+    try:
+        return eng.train(nm)
+    except ValueError:
+        return eng.last_train
+
+
+@pytest.mark.parametrize("opts", [{}, {"slots": 0}, {"mode": 0}, {"merge": 1}])
+def test_weighted_training_matches_full_list(native, opts):
+    eng = native.Engine(0)
+    for name, value in opts.items():
+        eng.set_option(name, value)
+    for text, nm in _weighted_cases(native):
+        data, offs = split_chunks(text)
+        exp_pairs, exp_counts, _ = oracle.train(data, nm, offs, raise_on_empty=False)
+        d2, o2, w, nd = native.dedup_chunks(data, offs)
+        assert len(o2) < len(offs) and int(w.max()) >= 2
+        eng.load_bytes(d2, o2, w)
+        got = _train_or_partial(eng, nm)
+        assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
+        # same engine, unweighted again: no state leaks from the weighted run
+        eng.load_bytes(data, offs)
+        got = _train_or_partial(eng, nm)
+        assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
+    eng.close()
+
+
+def test_weighted_single_steps(engine, native):
+    # bpe_get_stats / bpe_argmax on a weighted stream: weighted counts, first-appearance order
+    text = "the cat the dog the end of the cat and the dog " * 7
+    data, offs = split_chunks(text)
+    d2, o2, w, _ = native.dedup_chunks(data, offs)
+    engine.load_bytes(data, offs)
+    full = engine.get_stats()
+    full_arg = engine.argmax()
+    engine.load_bytes(d2, o2, w)
+    got = engine.get_stats()
+    assert [(p, c) for p, c, _ in got] == [(p, c) for p, c, _ in full]
+    assert engine.argmax() == full_arg
+
+
+def test_weighted_sharded_lockstep(native):
+    pytest.importorskip("torch")
+    chunks = _space_chunks(native.synth_text(1_200_000, 53))
+    nm = 200
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, nm, offs)
+    got = _lockstep(native, chunks, nm, 3, dedup=True)
+    assert got[0] == exp[0] and got[1] == exp[1]
