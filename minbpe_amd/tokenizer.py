@@ -304,10 +304,10 @@ class RegexTokenizer(Tokenizer):
 
     # Train on the DISTINCT chunks, each weighted by how often it occurs (bpe_dedup_chunks):
     # same merges, counts and tie-breaks as over the full chunk list, a fraction
-    # of the stream.  The host pass costs about as much as ~6000 device merges over the full
-    # list (profiles/r1_notes.md), so "auto" turns it on from there; True / False force it.
+    # of the stream.  The host pass costs about as much as ~1500 device merges over the full
+    # list (profiles/r1_notes.md), so "auto" turns it on from 2000; True / False force it.
     dedup = "auto"
-    DEDUP_AUTO_MERGES = 6000
+    DEDUP_AUTO_MERGES = 2000
 
     def train(self, text, vocab_size, verbose=False):
         data, offs = self._chunked(text)
