@@ -134,7 +134,10 @@ extern "C" int bpe_dedup_chunks(const uint8_t *bytes, uint64_t n, const uint64_t
         const uint64_t b = chunk_offsets[c], e = c + 1 < n_chunks ? chunk_offsets[c + 1] : n;
         if (b > e || e > n) return BPE_E_ARG;  // offsets must ascend and stay inside the text
     }
-    if (threads < 1) threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (threads < 1) {  // one per million chunks, at most 32
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n_chunks >> 20));
+    }
     if (n_chunks < (1u << 16)) threads = 1;
     const Span sp{bytes, chunk_offsets, n, n_chunks};
     const unsigned T = (unsigned)threads;

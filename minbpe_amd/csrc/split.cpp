@@ -250,9 +250,11 @@ int split_impl(const uint8_t *s, uint64_t n, uint64_t *out, uint64_t cap, uint64
 extern "C" int bpe_split(int which, const uint8_t *utf8, uint64_t n, uint64_t *starts_out, uint64_t cap,
                          uint64_t *n_chunks, int threads) {
     if ((!utf8 && n) || (which != 2 && which != 4)) return BPE_E_ARG;
-    // (one thread scans ~180 MB/s; threads only pay on long texts)
-    if (threads < 1)
-        threads = n < (64u << 20) ? 1 : (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    // (one thread scans ~180 MB/s; threads only pay on long texts: one per 8 MB, at most 32)
+    if (threads < 1) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n >> 23));
+    }
     if (n == 0) {
         if (n_chunks) *n_chunks = 0;
         return BPE_OK;

@@ -100,3 +100,54 @@ def test_sharded_exhaustion_stops_all_ranks_together():
     assert len(exp[0]) < 6
     for rank, status, pairs, counts, lens in _run(chunks, 6):
         assert status == "empty" and pairs == exp[0] and lens == exp[2]
+
+
+# ---------------------------------------------------------------------------
+# init_native_comm: every rank must come back with the same answer, and none may be left
+# waiting in a collective, whichever rank fails to set the library's communicator up
+
+class _FakeEngine:
+    def __init__(self, rank, fail_uid=False, fail_init_on=None):
+        self.rank, self.fail_uid, self.fail_init_on = rank, fail_uid, fail_init_on
+        self.inited = None
+
+    def comm_unique_id(self):
+        if self.fail_uid:
+            raise RuntimeError("librccl not found")
+        return bytes(range(1, 129))
+
+    def comm_init(self, rank, world, uid):
+        if self.fail_init_on == rank:
+            raise RuntimeError("ncclCommInitRank failed")
+        self.inited = (rank, world, uid)
+
+
+def _comm_worker(rank, world, port, mode, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from minbpe_amd.dist import TorchComm, init_native_comm
+        eng = _FakeEngine(rank, fail_uid=(mode == "uid"), fail_init_on=(1 if mode == "init" else None))
+        ok = init_native_comm(eng, TorchComm())
+        out_q.put((rank, ok, eng.inited))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["ok", "uid", "init"])
+def test_native_comm_setup_is_all_or_nothing(mode):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [o[1] for o in outs] == [mode == "ok"] * world
+    if mode == "ok":  # every rank got rank 0's id
+        assert all(o[2] == (o[0], world, bytes(range(1, 129))) for o in outs)
