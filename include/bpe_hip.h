@@ -193,6 +193,14 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
 int bpe_split(int which, const uint8_t *utf8, uint64_t n, uint64_t *starts_out, uint64_t cap,
               uint64_t *n_chunks, int threads);
 
+/* The same for a batch of documents laid out back to back (document d starts at doc_offsets[d];
+ * the last one ends at n): every document is split on its own, as a loop of encode() calls over
+ * the documents would (regex.py:111-121).  doc_first_chunk (n_docs + 1 entries, may be NULL)
+ * receives the index of each document's first chunk in starts_out. */
+int bpe_split_docs(int which, const uint8_t *utf8, uint64_t n, const uint64_t *doc_offsets,
+                   uint64_t n_docs, uint64_t *starts_out, uint64_t cap, uint64_t *n_chunks,
+                   uint64_t *doc_first_chunk, int threads);
+
 /* ---- chunk de-duplication (host, no GPU needed) ---------------------------- */
 /* In: the chunk list of regex.py:41-44 as bytes + chunk START offsets (chunk c ends where
  * chunk c+1 starts, the last one at n).  Out: the distinct chunks in order of first

@@ -94,6 +94,7 @@ _SIGS = {
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_dedup_chunks": (C.c_int, [_p, _u64, _p, _u64, _p, _p, _p, C.POINTER(_u64), C.POINTER(_u64),
                                   C.POINTER(_u64), C.c_int]),
+    "bpe_split_docs": (C.c_int, [C.c_int, _p, _u64, _p, _u64, _p, _u64, C.POINTER(_u64), _p, C.c_int]),
     "bpe_synth_text": (C.c_int, [_p, _u64, _u64]),
     "bpe_version": (C.c_char_p, []),
 }
@@ -134,6 +135,24 @@ def split_offsets(data: bytes, which: int, threads: int = 0):
     if rc != BPE_OK:
         raise RuntimeError(f"bpe_split failed: {rc}")
     return out[:n.value].copy() if n.value * 2 < len(out) else out[:n.value]
+
+
+def split_docs(data: bytes, doc_offsets, which: int, threads: int = 0):
+    """split_offsets for documents laid out back to back: every document is split on its own.
+    Returns (chunk start offsets, index of each document's first chunk [n_docs + 1])."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    doff = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+    first = np.zeros(len(doff) + 1, np.uint64)
+    n = _u64(0)
+    out = np.empty(len(buf) // 3 + len(doff) + 16, np.uint64)
+    args = (which, _ptr(buf) if len(buf) else None, len(buf), _ptr(doff) if len(doff) else None, len(doff))
+    rc = _lib.bpe_split_docs(*args, _ptr(out), len(out), C.byref(n), _ptr(first), threads)
+    if rc == BPE_E_CAP:
+        out = np.empty(n.value, np.uint64)
+        rc = _lib.bpe_split_docs(*args, _ptr(out), len(out), C.byref(n), _ptr(first), threads)
+    if rc != BPE_OK:
+        raise RuntimeError(f"bpe_split_docs failed: {rc}")
+    return out[:n.value].copy(), first
 
 
 def dedup_chunks(data: bytes, offsets, threads: int = 0):

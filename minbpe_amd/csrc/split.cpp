@@ -245,7 +245,80 @@ int split_impl(const uint8_t *s, uint64_t n, uint64_t *out, uint64_t cap, uint64
     return BPE_OK;
 }
 
+// documents: every document is split on its own (a match never crosses a document boundary)
+template <bool GPT4>
+int split_docs_impl(const uint8_t *s, uint64_t n, const uint64_t *doc_off, uint64_t n_docs, uint64_t *out,
+                    uint64_t cap, uint64_t *n_chunks, uint64_t *doc_first_chunk, int threads) {
+    auto doc_begin = [&](uint64_t d) { return doc_off[d]; };
+    auto doc_end = [&](uint64_t d) { return d + 1 < n_docs ? doc_off[d + 1] : n; };
+    // contiguous groups of documents with about the same number of bytes
+    const unsigned T = (unsigned)std::max(1, threads);
+    std::vector<uint64_t> cut(T + 1, n_docs);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {
+        const uint64_t target = n / T * t;
+        cut[t] = (uint64_t)(std::lower_bound(doc_off, doc_off + n_docs, target) - doc_off);
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    std::vector<Sink> sinks(T);
+    std::vector<uint64_t> per_doc(n_docs, 0);
+    auto work = [&](unsigned t) {
+        Sink &sk = sinks[t];
+        for (uint64_t d = cut[t]; d < cut[t + 1]; d++) {
+            const size_t before = sk.v.size();
+            const uint64_t b = doc_begin(d), e = doc_end(d);
+            if (e > b) scan<GPT4>(s, s + b, s + e, s + e, sk);
+            per_doc[d] = sk.v.size() - before;
+        }
+    };
+    if (T == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    uint64_t total = 0;
+    for (uint64_t d = 0; d < n_docs; d++) {
+        if (doc_first_chunk) doc_first_chunk[d] = total;
+        total += per_doc[d];
+    }
+    if (doc_first_chunk) doc_first_chunk[n_docs] = total;
+    if (n_chunks) *n_chunks = total;
+    if (!out) return BPE_OK;
+    if (cap < total) return BPE_E_CAP;
+    uint64_t w = 0;
+    for (auto &sk : sinks) {
+        if (!sk.v.empty()) memcpy(out + w, sk.v.data(), sk.v.size() * sizeof(uint64_t));
+        w += sk.v.size();
+    }
+    return BPE_OK;
+}
+
 }  // namespace
+
+extern "C" int bpe_split_docs(int which, const uint8_t *utf8, uint64_t n, const uint64_t *doc_offsets,
+                              uint64_t n_docs, uint64_t *starts_out, uint64_t cap, uint64_t *n_chunks,
+                              uint64_t *doc_first_chunk, int threads) {
+    if ((!utf8 && n) || (which != 2 && which != 4) || (!doc_offsets && n_docs)) return BPE_E_ARG;
+    for (uint64_t d = 0; d < n_docs; d++) {
+        const uint64_t b = doc_offsets[d], e = d + 1 < n_docs ? doc_offsets[d + 1] : n;
+        if (b > e || e > n) return BPE_E_ARG;  // offsets must ascend and stay inside the text
+    }
+    if (threads < 1) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n >> 23));
+    }
+    if (n_docs == 0) {
+        if (n_chunks) *n_chunks = 0;
+        if (doc_first_chunk) doc_first_chunk[0] = 0;
+        return BPE_OK;
+    }
+    return which == 4 ? split_docs_impl<true>(utf8, n, doc_offsets, n_docs, starts_out, cap, n_chunks,
+                                              doc_first_chunk, threads)
+                      : split_docs_impl<false>(utf8, n, doc_offsets, n_docs, starts_out, cap, n_chunks,
+                                               doc_first_chunk, threads);
+}
 
 extern "C" int bpe_split(int which, const uint8_t *utf8, uint64_t n, uint64_t *starts_out, uint64_t cap,
                          uint64_t *n_chunks, int threads) {

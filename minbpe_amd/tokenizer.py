@@ -356,6 +356,30 @@ class RegexTokenizer(Tokenizer):
         data, offs = self._chunked(text)
         return self._encode_flat(data, offs)[0].tolist()
 
+    def encode_ordinary_batch(self, texts):
+        """encode_ordinary() of every text, as one device batch (not in the reference, whose
+        encode takes one string).  Returns (ids, doc_offsets): int32 ids of all texts back to
+        back and len(texts) + 1 offsets, text d being ids[doc_offsets[d]:doc_offsets[d + 1]].
+        Every text is split on its own, so the ids are those of a loop over encode_ordinary."""
+        enc = [t.encode("utf-8") for t in texts]
+        if not enc:
+            return np.empty(0, np.int32), np.zeros(1, np.uint64)
+        which = _NATIVE_SPLIT.get(self.compiled_pattern.pattern)
+        if which is not None:
+            data = b"".join(enc)
+            doff = np.zeros(len(enc), dtype=np.uint64)
+            np.cumsum(np.fromiter((len(e) for e in enc[:-1]), dtype=np.uint64, count=len(enc) - 1), out=doff[1:])
+            offs, first = _native.split_docs(data, doff, which)
+        else:  # any other pattern: the regex module, one text at a time
+            pieces, first = [], [0]
+            for t in texts:
+                pieces += [p for p in self._split(t) if p]
+                first.append(len(pieces))
+            data, offs = _concat_chunks(pieces)
+            first = np.array(first, dtype=np.uint64)
+        ids, out_off = self._encode_flat(data, offs)
+        return ids, out_off[first.astype(np.int64)]
+
     def encode(self, text, allowed_special="none_raise"):
         if allowed_special == "all":
             special = self.special_tokens

@@ -646,3 +646,24 @@ def test_weighted_sharded_lockstep(native):
     exp = oracle.train(data, nm, offs)
     got = _lockstep(native, chunks, nm, 3, dedup=True)
     assert got[0] == exp[0] and got[1] == exp[1]
+
+
+def test_encode_ordinary_batch_and_back(native):
+    """cfg5 at the drop-in level: many documents -> one encode batch -> one decode batch."""
+    from minbpe_amd import RegexTokenizer
+    from minbpe_amd.tokenizer import GPT2_SPLIT_PATTERN
+    text = native.synth_text(1_500_000, 91).decode()
+    docs = [d for d in text.split("\n\n")] + ["", " ", "don't  stop\r\n", "x"]
+    for pattern in (None, GPT2_SPLIT_PATTERN, r"\p{L}+|\p{N}+|[^\p{L}\p{N}]+"):
+        tok = RegexTokenizer(pattern)
+        tok.train(text[:300_000], 256 + 400)
+        ids, doff = tok.encode_ordinary_batch(docs)
+        assert len(doff) == len(docs) + 1 and int(doff[-1]) == len(ids)
+        for d in list(range(0, len(docs), 97)) + list(range(len(docs) - 4, len(docs))):
+            assert ids[int(doff[d]):int(doff[d + 1])].tolist() == tok.encode_ordinary(docs[d]), d
+        raw, boff = tok.decode_batch(ids, doff)
+        assert [raw[int(boff[d]):int(boff[d + 1])] for d in range(len(docs))] == [d.encode() for d in docs]
+    ids, doff = tok.encode_ordinary_batch([])
+    assert len(ids) == 0 and doff.tolist() == [0]
+    ids, doff = tok.encode_ordinary_batch(["", ""])
+    assert len(ids) == 0 and doff.tolist() == [0, 0, 0]
