@@ -10,9 +10,10 @@ I64MAX = 0x7FFFFFFFFFFFFFFF
 
 
 class CpuShard:
-    def __init__(self, data: bytes, offsets):
+    def __init__(self, data: bytes, offsets, weight_exp=None):
         self.data = data
         self.offsets = offsets
+        self.weight_exp = weight_exp  # per chunk: pairs inside it count 2**e times (bpe_load_bytes_weighted)
         self.device = None
 
     # -- protocol ---------------------------------------------------------------
@@ -26,11 +27,17 @@ class CpuShard:
         for o in offs:
             if o < n:
                 self.start[o] = True
+        self.w = [1] * n  # weight of the chunk each token belongs to
+        if self.weight_exp is not None:
+            ends = offs[1:] + [n]
+            for o, e, k in zip(offs, ends, self.weight_exp):
+                for p in range(o, e):
+                    self.w[p] = 1 << int(k)
         self.tab = np.zeros((self.V, self.V), dtype=np.int64)
         t256 = np.zeros((256, 256), dtype=np.int32)
         for p in range(n - 1):
             if not self.start[p + 1]:
-                t256[self.ids[p], self.ids[p + 1]] += 1
+                t256[self.ids[p], self.ids[p + 1]] += self.w[p]
         self.table = torch.from_numpy(t256.reshape(-1))
         self.delta = torch.zeros(4 * self.V, dtype=torch.int32)
         self.key = torch.zeros(2, dtype=torch.int64)
@@ -68,30 +75,30 @@ class CpuShard:
             return
         a, b = int(self.key[0]) & 0xFFFF, int(self.key[1]) & 0xFFFF
         self._pair = (a, b)
-        ids, st = self.ids, self.start
+        ids, st, wt = self.ids, self.start, self.w
         n = len(ids)
         m = [0] * n
         for p in range(n):
             if ids[p] == a and p + 1 < n and ids[p + 1] == b and not st[p + 1] and not (p and m[p - 1]):
                 m[p] = 1
         d = self.delta.numpy()
-        out, ost = [], []
+        out, ost, ow = [], [], []
         # old pairs that lose an element / new pairs that gain the new token
         before = {}
         for p in range(n - 1):
             if not st[p + 1] and (m[p] or (p and m[p - 1]) or m[p + 1] or m[p]):
-                before[(ids[p], ids[p + 1])] = before.get((ids[p], ids[p + 1]), 0) + 1
+                before[(ids[p], ids[p + 1])] = before.get((ids[p], ids[p + 1]), 0) + wt[p]
         p = 0
         touched = []
         while p < n:
             if m[p]:
-                out.append(Z); ost.append(st[p]); touched.append(True); p += 2
+                out.append(Z); ost.append(st[p]); ow.append(wt[p]); touched.append(True); p += 2
             else:
-                out.append(ids[p]); ost.append(st[p]); touched.append(False); p += 1
+                out.append(ids[p]); ost.append(st[p]); ow.append(wt[p]); touched.append(False); p += 1
         after = {}
         for q in range(len(out) - 1):
             if not ost[q + 1] and (touched[q] or touched[q + 1]):
-                after[(out[q], out[q + 1])] = after.get((out[q], out[q + 1]), 0) + 1
+                after[(out[q], out[q + 1])] = after.get((out[q], out[q + 1]), 0) + ow[q]
         for (x, y), c in before.items():
             if (x, y) == (a, b):
                 continue
@@ -110,7 +117,7 @@ class CpuShard:
             else:
                 assert y == Z
                 d[2 * V + x] += c
-        self.ids, self.start = out, ost
+        self.ids, self.start, self.w = out, ost, ow
         self.rec[i] = ((a, b), self._count, len(out), 0)
 
     def apply(self, i):

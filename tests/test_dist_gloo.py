@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, chunks, num_merges, out_q):
+def _worker(rank, world, port, chunks, num_merges, out_q, dedup=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,8 +37,12 @@ def _worker(rank, world, port, chunks, num_merges, out_q):
         mine = chunks[lo:hi]
         data = b"".join(mine)
         offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
+        wexp = None
+        if dedup and mine:  # every rank folds the repeats of ITS shard into weights
+            from minbpe_amd import _native
+            data, offs, wexp, _ = _native.dedup_chunks(data, offs)
         try:
-            res = train_sharded(CpuShard(data, offs), TorchComm(), num_merges, depth=3)
+            res = train_sharded(CpuShard(data, offs, wexp), TorchComm(), num_merges, depth=3)
             out_q.put((rank, "ok", res["pairs"], res["counts"], res["lens"]))
         except ValueError as e:
             out_q.put((rank, "empty", e.partial["pairs"], e.partial["counts"], e.partial["lens"]))
@@ -46,11 +50,11 @@ def _worker(rank, world, port, chunks, num_merges, out_q):
         dist.destroy_process_group()
 
 
-def _run(chunks, num_merges, world=2):
+def _run(chunks, num_merges, world=2, dedup=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, num_merges, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, num_merges, q, dedup)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=240) for _ in procs]
@@ -92,6 +96,16 @@ def test_sharded_ties_prefer_lowest_rank_then_position(native):
     exp = _oracle(chunks, 25)
     for rank, status, pairs, counts, lens in _run(chunks, 25):
         assert status == "ok" and pairs == exp[0] and counts == exp[1] and lens == exp[2]
+
+
+def test_sharded_training_with_per_rank_dedup(native):
+    # tie-heavy and repetitive: weights with several set bits on every rank
+    rng = np.random.default_rng(10)
+    words = [bytes(97 + rng.integers(0, 3, size=rng.integers(1, 5))) for _ in range(30)]
+    chunks = [b" " + words[int(i)] for i in rng.integers(0, len(words), size=1500)]
+    exp = _oracle(chunks, 30)
+    for rank, status, pairs, counts, lens in _run(chunks, 30, world=3, dedup=True):
+        assert pairs == exp[0] and counts == exp[1]  # lens refer to the de-duplicated shards
 
 
 def test_sharded_exhaustion_stops_all_ranks_together():
