@@ -55,13 +55,15 @@ def main():
     cases = []
 
     def add_train(name, text=None, synth=None, vocab_size=256, kinds=("basic", "regex"),
-                  encode_texts=()):
+                  encode_texts=(), pattern=None):
         src = text if synth is None else synth_text(*synth).decode("utf-8")
         for kind in kinds:
             cls = BasicTokenizer if kind == "basic" else RegexTokenizer
-            tok, merges, err = run_train(cls, src, vocab_size)
+            tok, merges, err = run_train(cls, src, vocab_size, pattern if kind == "regex" else None)
             case = dict(name=f"{name}-{kind}", kind=kind, vocab_size=vocab_size, merges=merges,
                         raises_value_error=err)
+            if pattern is not None and kind == "regex":
+                case["pattern"] = pattern  # RegexTokenizer(pattern) (regex.py:24-32)
             if synth is None:
                 case["text"] = text
             else:
@@ -96,6 +98,16 @@ def main():
         add_train(f"alpha{k}-spaces", text=s2, vocab_size=256 + 60, encode_texts=[s2[:500]])
     add_train("synth-60k", synth=(60_000, 7), vocab_size=256 + 160,
               encode_texts=[synth_text(4000, 8).decode()])
+    # other split patterns: the GPT-2 one (regex.py:18; native scanner) and a custom one (regex module)
+    from minbpe.regex import GPT2_SPLIT_PATTERN
+    add_train("prose-gpt2", text=PROSE, vocab_size=256 + 64, kinds=("regex",), pattern=GPT2_SPLIT_PATTERN,
+              encode_texts=[PROSE[:300], "don't  stop\r\n  now"])
+    add_train("synth-gpt2", synth=(50_000, 9), vocab_size=256 + 120, kinds=("regex",), pattern=GPT2_SPLIT_PATTERN,
+              encode_texts=[synth_text(3000, 10).decode()])
+    add_train("prose-custom", text=PROSE, vocab_size=256 + 48, kinds=("regex",),
+              pattern=r"\p{L}+|\p{N}+|[^\p{L}\p{N}]+", encode_texts=[PROSE[:300]])
+    add_train("synth-150k", synth=(150_000, 11), vocab_size=256 + 300, kinds=("regex",),
+              encode_texts=[synth_text(5000, 12).decode()])
 
     # get_stats / merge primitives on random lists (dict order matters)
     prims = []

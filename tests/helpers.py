@@ -24,8 +24,13 @@ def split_chunks(text, pattern=_PAT):
     return b"".join(chunks), offs
 
 
+def pattern_of(case):
+    """compiled split pattern of a golden case (default: the GPT-4 pattern, regex.py:29)"""
+    return re.compile(case["pattern"]) if case.get("pattern") else _PAT
+
+
 def data_for(case, native):
     text = case_text(case, native)
     if case["kind"] == "basic":
         return text.encode("utf-8"), None
-    return split_chunks(text)
+    return split_chunks(text, pattern_of(case))

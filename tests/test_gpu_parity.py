@@ -195,7 +195,7 @@ def test_classes_golden(golden, native, dedup):
         if case["kind"] == "basic" and not dedup:
             continue  # BasicTokenizer has one chunk: nothing to de-duplicate either way
         cls = BasicTokenizer if case["kind"] == "basic" else RegexTokenizer
-        tok = cls()
+        tok = cls(case["pattern"]) if case.get("pattern") else cls()
         tok.dedup = dedup
         text = case_text(case, native)
         if case["raises_value_error"]:

@@ -22,7 +22,7 @@ def classes(native, monkeypatch):
 def test_golden_cases_through_the_classes(golden, native, classes, dedup):
     for case in golden["train"]:
         cls = classes.BasicTokenizer if case["kind"] == "basic" else classes.RegexTokenizer
-        tok = cls()
+        tok = cls(case["pattern"]) if case.get("pattern") else cls()
         tok.dedup = dedup
         text = case_text(case, native)
         if len(text) > 300_000:

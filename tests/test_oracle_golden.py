@@ -29,14 +29,14 @@ def test_train_cases(golden, native):
 
 
 def test_encode_cases(golden, native):
-    from helpers import split_chunks
+    from helpers import pattern_of, split_chunks
     for case in golden["train"]:
         for enc in case.get("encode", []):
             merges = [tuple(m) for m in case["merges"]]
             if case["kind"] == "basic":
                 data, offs = enc["text"].encode(), None
             else:
-                data, offs = split_chunks(enc["text"])
+                data, offs = split_chunks(enc["text"], pattern_of(case))
             ids, _ = oracle.encode(merges, data, offs)
             assert ids.tolist() == enc["ids"], case["name"]
 
