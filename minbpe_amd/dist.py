@@ -189,3 +189,58 @@ def init_native_comm(engine, comm):
     flag = flag.to(dev) if dev is not None else flag
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
     return bool(flag.item())
+
+
+def train_tokenizer(tok, text, vocab_size, comm=None, verbose=False, make_shard=None, device_index=None):
+    """RegexTokenizer.train (regex.py:36-70) over a corpus that is spread across ranks.
+
+    `text` is THIS rank's part of the corpus; the corpus is the parts in rank order, and the parts
+    must be cut where the split pattern cuts anyway (e.g. between documents) -- a chunk never spans
+    two ranks.  Every rank ends with the same `tok.merges` / `tok.vocab`, equal to what the single
+    process `tok.train(whole_text, vocab_size)` produces; exhaustion raises ValueError on every rank
+    at the same merge and, like the reference, leaves the tokenizer untouched.
+
+    comm: a TorchComm (default: the default process group).  make_shard(data, offsets, weight_exp)
+    overrides the per-rank engine (tests run the protocol on CPU with it); by default the rank's GPU
+    is used, with the collectives issued by the library itself when librccl can be set up."""
+    assert vocab_size >= 256
+    num_merges = vocab_size - 256
+    comm = comm or TorchComm()
+    data, offs = tok._chunked(text)
+    wexp = None
+    want = (num_merges >= tok.DEDUP_AUTO_MERGES) if tok.dedup == "auto" else bool(tok.dedup)
+    if want and len(offs) > 1:
+        from . import _native
+        data, offs, wexp, _ = _native.dedup_chunks(data, offs)
+    failure = None
+    try:
+        if make_shard is not None:
+            res = train_sharded(make_shard(data, offs, wexp), comm, num_merges)
+        else:
+            import torch
+            from .tokenizer import engine
+            if device_index is None:
+                device_index = torch.cuda.current_device()
+            eng = engine(device_index)
+            eng.load_bytes(data, offs, wexp)
+            if init_native_comm(eng, comm):
+                try:
+                    res = eng.dp_train(num_merges)
+                except ValueError as e:
+                    e.partial = eng.last_train
+                    raise
+            else:
+                res = train_sharded(GpuShard(eng, device_index), comm, num_merges)
+    except ValueError as e:
+        res, failure = e.partial, e
+    merges, vocab = {}, {i: bytes([i]) for i in range(256)}
+    for i, pair in enumerate(res["pairs"]):
+        idx = 256 + i
+        merges[pair] = idx
+        vocab[idx] = vocab[pair[0]] + vocab[pair[1]]
+        if verbose and comm.rank == 0:
+            print(f"merge {i+1}/{num_merges}: {pair} -> {idx} ({vocab[idx]}) had {res['counts'][i]} occurrences")
+    if failure is not None:
+        raise ValueError("max() arg is an empty sequence") from failure
+    tok.merges = merges
+    tok.vocab = vocab

@@ -165,3 +165,54 @@ def test_native_comm_setup_is_all_or_nothing(mode):
     assert [o[1] for o in outs] == [mode == "ok"] * world
     if mode == "ok":  # every rank got rank 0's id
         assert all(o[2] == (o[0], world, bytes(range(1, 129))) for o in outs)
+
+
+# ---------------------------------------------------------------------------
+# train_tokenizer: the drop-in class trained over a corpus spread across ranks
+
+def _tok_worker(rank, world, port, parts, vocab_size, dedup, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from minbpe_amd import RegexTokenizer
+        from minbpe_amd.dist import train_tokenizer
+        from cpu_shard import CpuShard
+        tok = RegexTokenizer()
+        tok.dedup = dedup
+        try:
+            train_tokenizer(tok, parts[rank], vocab_size, make_shard=CpuShard)
+            out_q.put((rank, "ok", list(tok.merges.items()), tok.vocab[max(tok.vocab)]))
+        except ValueError:
+            out_q.put((rank, "empty", list(tok.merges.items()), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dedup", [True, False])
+def test_train_tokenizer_over_ranks_equals_single_process(native, dedup):
+    import regex as re
+    from minbpe_amd.tokenizer import GPT4_SPLIT_PATTERN
+    text = native.synth_text(9000, 43).decode()
+    docs = text.split("\n\n")
+    cut = len(docs) // 2
+    parts = ["\n\n".join(docs[:cut]) + "\n\n", "\n\n".join(docs[cut:])]  # a document boundary is a chunk boundary
+    whole = parts[0] + parts[1]
+    chunks = [c.encode() for c in re.findall(GPT4_SPLIT_PATTERN, whole)]
+    assert chunks == [c.encode() for p in parts for c in re.findall(GPT4_SPLIT_PATTERN, p)]
+    exp = _oracle(chunks, 50)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tok_worker, args=(r, world, port, parts, 256 + 50, dedup, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, status, merges, last_tok in outs:
+        assert status == "ok"
+        assert [m[0] for m in merges] == exp[0] and [m[1] for m in merges] == list(range(256, 306))
+    assert outs[0][3] == outs[1][3]
