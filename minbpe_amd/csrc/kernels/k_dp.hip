@@ -1,0 +1,76 @@
+// k_dp.hip -- data-parallel (sharded chunks) helpers.
+// Part of bpe_kernels.hip, which includes the parts in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../bpe_device.h"
+#include "k_select.hip"
+
+namespace bpe {
+
+// ---------------------------------------------------------------------------
+// Data-parallel training over sharded chunks: every rank holds a
+// contiguous range of chunks and a replica of the GLOBAL pair table.  Per
+// iteration the ranks exchange (1) two 64-bit words that decide the tie-break
+// and (2) the four delta vectors -- never ids, never the table.
+//
+// Tie-break across ranks: global first occurrence = lowest (rank, local
+// position).  w0 = key<<16 | a, w1 = key<<16 | b with key = rank<<32 | pos: the
+// element-wise MIN all-reduce of (w0, w1) returns the pair of the winning rank,
+// because the keys are distinct per rank.  No tie: every rank sends key 0 and
+// the same pair.  No local occurrence: INT64_MAX.
+__global__ void k_dp_key(SlotRef ref, int par, const DevState *__restrict__ st,
+                         unsigned long long rank, long long *__restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    long long w0 = 0x7FFFFFFFFFFFFFFFll, w1 = 0x7FFFFFFFFFFFFFFFll;
+    if (st->status == 0) {
+        if (st->found) {
+            w0 = (long long)(uint32_t)st->a;
+            w1 = (long long)(uint32_t)st->b;
+        } else if (st->firstpos != NOPOS) {
+            // (slot-space positions are < 2^32 too: the slot area never exceeds the original stream)
+            const unsigned long long k = ((rank << 32) | st->firstpos) + 1;  // > 0: a tie never ties with "no tie"
+            uint32_t x0 = 0, x1 = 0;
+            slot_get(ref, st->n[par], st->firstpos, x0);
+            slot_next(ref, st->n[par], st->firstpos, x1);
+            w0 = (long long)((k << 16) | (x0 & IDMASK));
+            w1 = (long long)((k << 16) | (x1 & IDMASK));
+        }
+    }
+    key[0] = w0;
+    key[1] = w1;
+}
+__global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->status) return;
+    if (key[0] == 0x7FFFFFFFFFFFFFFFll) {
+        st->status = ST_INTERNAL;  // a tie at the maximum, yet no rank holds a tied pair
+        return;
+    }
+    st->a = (int32_t)(key[0] & 0xFFFF);
+    st->b = (int32_t)(key[1] & 0xFFFF);
+    st->found = 1;
+}
+// fold the replicated delta vectors into one compact 4 x vcap buffer (the SUM all-reduce payload)
+__global__ void __launch_bounds__(256)
+k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__restrict__ folded) {
+    const uint32_t nrep = 1u << (vcap >> 24);
+    vcap &= 0xFFFFFFu;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= vcap) return;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        uint32_t acc = 0;
+        if (t <= Z) {
+            for (uint32_t r = 0; r < nrep; r++) {
+                const uint32_t x = delta[((size_t)r * 4 + v) * vcap + t];
+                if (x) delta[((size_t)r * 4 + v) * vcap + t] = 0;
+                acc += x;
+            }
+        }
+        folded[(size_t)v * vcap + t] = acc;
+    }
+}
+
+}  // namespace bpe

@@ -1,0 +1,220 @@
+// k_encode.hip -- K4: batch encode.
+// Part of bpe_kernels.hip, which includes the parts in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../bpe_device.h"
+#include "k_common.hip"
+
+namespace bpe {
+
+// ---------------------------------------------------------------------------
+// K4: encode  (_encode_chunk regex.py:92-109 == basic.py:57-74, batched)
+//
+// The reference repeatedly merges the lowest-rank pair present in a chunk.
+// Merging the LEFTMOST lowest-rank pair, one occurrence at a time, is the same
+// computation (pairs created by a merge of rank r involve token 256+r and so
+// have rank > r; left-to-right order reproduces the greedy a==b pairing).
+//
+// Ranks live in an open-addressing hash table (key = a<<32|b, value = rank),
+// a few hundred KB, L2-resident.  Short chunks -- virtually all of them under a
+// GPT-style split pattern (mean ~4 bytes) -- are encoded one chunk per lane
+// with the token list in lane-private LDS columns.  Chunks longer than
+// ENC_LMAX tokens are queued and encoded by stream-wide rounds (bpe_api.hip).
+
+__device__ __forceinline__ uint32_t rank_lookup(const unsigned long long *__restrict__ keys,
+                                                const uint32_t *__restrict__ vals, uint32_t mask,
+                                                uint32_t a, uint32_t b) {
+    const unsigned long long key = ((unsigned long long)a << 32) | b;
+    uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+    for (;;) {
+        const unsigned long long k = keys[h];
+        if (k == key) return vals[h];
+        if (k == ~0ull) return 0xFFFFFFFFu;
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ void __launch_bounds__(ENC_THREADS)
+k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks,
+               uint64_t n, const unsigned long long *__restrict__ keys,
+               const uint32_t *__restrict__ vals, uint32_t mask, const int32_t *__restrict__ merge_ids,
+               uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
+               unsigned long long *__restrict__ long_list, unsigned long long *__restrict__ n_long) {
+    __shared__ uint32_t s_tok[ENC_LMAX * ENC_THREADS];
+    __shared__ uint32_t s_rk[ENC_LMAX * ENC_THREADS];
+    const uint64_t c = (uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t s0 = off[c];
+    const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
+    uint32_t L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
+    if (L == 0) {
+        outlen[c] = 0;
+        return;
+    }
+    if (L > ENC_LMAX) {
+        outlen[c] = 0;
+        long_list[atomicAdd(n_long, 1ull)] = c;
+        return;
+    }
+    uint32_t *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
+    uint32_t *rk = s_rk + threadIdx.x;
+    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = bytes[s0 + i];
+    for (uint32_t i = 0; i + 1 < L; i++)
+        rk[i * ENC_THREADS] = rank_lookup(keys, vals, mask, tok[i * ENC_THREADS], tok[(i + 1) * ENC_THREADS]);
+    while (L >= 2) {
+        uint32_t best = 0xFFFFFFFFu, bi = 0;
+        for (uint32_t i = 0; i + 1 < L; i++) {
+            const uint32_t r = rk[i * ENC_THREADS];
+            if (r < best) {  // strict: leftmost occurrence of the lowest rank
+                best = r;
+                bi = i;
+            }
+        }
+        if (best == 0xFFFFFFFFu) break;  // nothing else can be merged
+        tok[bi * ENC_THREADS] = merge_ids ? (uint32_t)merge_ids[best] : 256u + best;
+        for (uint32_t i = bi + 1; i + 1 < L; i++) {
+            tok[i * ENC_THREADS] = tok[(i + 1) * ENC_THREADS];
+            rk[i * ENC_THREADS] = rk[(i + 1) * ENC_THREADS];
+        }
+        L--;
+        if (bi > 0)
+            rk[(bi - 1) * ENC_THREADS] =
+                rank_lookup(keys, vals, mask, tok[(bi - 1) * ENC_THREADS], tok[bi * ENC_THREADS]);
+        if (bi + 1 < L)
+            rk[bi * ENC_THREADS] =
+                rank_lookup(keys, vals, mask, tok[bi * ENC_THREADS], tok[(bi + 1) * ENC_THREADS]);
+    }
+    for (uint32_t i = 0; i < L; i++) tmp[s0 + i] = tok[i * ENC_THREADS];
+    outlen[c] = L;
+}
+
+// long chunks: lowest rank present anywhere in the (flagged) stream
+__global__ void __launch_bounds__(256)
+k_min_rank(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+           const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals,
+           uint32_t mask, uint32_t *__restrict__ out_min) {
+    const uint64_t n = st->n[par];
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p + 1 < n; p += total) {
+        const uint32_t w1 = ids[p + 1];
+        if (w1 & FLAG) continue;
+        best = min(best, rank_lookup(keys, vals, mask, ids[p] & IDMASK, w1));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
+    if (lane_id() == 0 && best != 0xFFFFFFFFu) atomicMin(out_min, best);
+}
+
+// gather the bytes of the queued long chunks into one flagged id stream
+__global__ void __launch_bounds__(256)
+k_long_gather(const uint8_t *__restrict__ bytes, const unsigned long long *__restrict__ src_off,
+              const unsigned long long *__restrict__ dst_off, uint64_t n_long,
+              uint32_t *__restrict__ ids) {
+    const uint64_t k = blockIdx.x;
+    if (k >= n_long) return;
+    const unsigned long long s0 = src_off[k], d0 = dst_off[k], len = dst_off[k + 1] - d0;
+    for (unsigned long long i = threadIdx.x; i < len; i += 256)
+        ids[d0 + i] = (uint32_t)bytes[s0 + i] | (i == 0 ? FLAG : 0u);
+}
+
+// ... and put their encoded tokens back into the per-chunk staging area
+__global__ void __launch_bounds__(256)
+k_long_scatter(const uint32_t *__restrict__ ids, const unsigned long long *__restrict__ starts,
+               const unsigned long long *__restrict__ chunk_id, const unsigned long long *__restrict__ src_off,
+               uint64_t n_long, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen) {
+    const uint64_t k = blockIdx.x;
+    if (k >= n_long) return;
+    const unsigned long long p0 = starts[k], len = starts[k + 1] - p0, d0 = src_off[k];
+    for (unsigned long long i = threadIdx.x; i < len; i += 256) tmp[d0 + i] = ids[p0 + i] & IDMASK;
+    if (threadIdx.x == 0) outlen[chunk_id[k]] = (uint32_t)len;
+}
+
+// exclusive scan of the per-chunk output lengths (u32 -> u64), three small kernels
+__global__ void __launch_bounds__(256)
+k_scan_blocksum(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long s_red[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE;
+    unsigned long long acc = 0;
+    for (uint32_t i = threadIdx.x; i < SCAN_TILE; i += 256)
+        if (base + i < n) acc += v[base + i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane_id() == 0) s_red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+__global__ void __launch_bounds__(1024)
+k_scan_top(unsigned long long *__restrict__ bsum, uint64_t nb, unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long s_part[1024];
+    const uint64_t R = (nb + 1023) / 1024;
+    const uint64_t b0 = min((uint64_t)threadIdx.x * R, nb), b1 = min(b0 + R, nb);
+    unsigned long long acc = 0;
+    for (uint64_t b = b0; b < b1; b++) acc += bsum[b];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const unsigned long long t = s_part[i];
+            s_part[i] = run;
+            run += t;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = s_part[threadIdx.x];
+    for (uint64_t b = b0; b < b1; b++) {
+        const unsigned long long t = bsum[b];
+        bsum[b] = run;
+        run += t;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_scan_apply(const uint32_t *__restrict__ v, uint64_t n, const unsigned long long *__restrict__ bsum,
+             unsigned long long *__restrict__ out) {
+    // thread t owns SCAN_TILE/256 consecutive values of its block
+    __shared__ unsigned long long s_w[4];
+    constexpr int PER = SCAN_TILE / 256;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * PER;
+    uint32_t x[PER];
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        x[i] = (base + i < n) ? v[base + i] : 0u;
+        acc += x[i];
+    }
+    unsigned long long inc = acc;
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    unsigned long long run = bsum[blockIdx.x] + inc - acc;
+    for (int w = 0; w < wave_id(); w++) run += s_w[w];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += x[i];
+    }
+}
+
+// final placement: chunk c's tokens go to out[out_off[c] ...]
+__global__ void __launch_bounds__(256)
+k_encode_place(const uint32_t *__restrict__ tmp, const uint64_t *__restrict__ off,
+               const uint32_t *__restrict__ outlen, const unsigned long long *__restrict__ out_off,
+               uint64_t n_chunks, int32_t *__restrict__ out) {
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t L = outlen[c];
+    const uint64_t s0 = off[c];
+    const unsigned long long d0 = out_off[c];
+    for (uint32_t i = 0; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
+}
+
+}  // namespace bpe
