@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = [os.path.join(HERE, "csrc", f) for f in ("bpe_api.hip", "synth.cpp", "split.cpp", "dedup.cpp")]
 DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("bpe_kernels.hip", "bpe_device.h", "unicode_tables.h")] + [
-    os.path.join(HERE, "csrc", "kernels", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc", "kernels")))] + [
+    os.path.join(HERE, "csrc", sub, f) for sub in ("kernels", "api")
+    for f in sorted(os.listdir(os.path.join(HERE, "csrc", sub)))] + [
     os.path.join(ROOT, "include", "bpe_hip.h")]
 OUT = os.path.join(HERE, "lib", "libbpe_hip.so")
 

@@ -1,0 +1,555 @@
+// api_ctx.hip -- the ctx, error / allocation helpers, profiling events, kernel-launch helpers.
+// Part of bpe_api.hip, which includes the parts in order (one translation unit).
+
+struct bpe_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // resident input (bpe_load_bytes)
+    uint8_t *d_bytes = nullptr;
+    uint64_t nbytes = 0, cap_bytes = 0;
+    uint64_t *d_offsets = nullptr;
+    uint64_t n_chunks = 0, cap_offsets = 0;
+    bool have_bytes = false;
+    uint8_t *d_wexp = nullptr;  // per chunk: weight exponent (bpe_load_bytes_weighted)
+    uint64_t cap_wexp = 0;
+    bool weighted = false;
+
+    // id stream
+    uint32_t *d_ids[2] = {nullptr, nullptr};
+    uint64_t cap_ids = 0;
+    int par = 0;
+    uint64_t n = 0;
+    bool have_ids = false;
+
+    // pair table
+    uint32_t *d_mat = nullptr, *d_first = nullptr, *d_rowmax = nullptr;
+    uint32_t vcap = 0;  // matrix dimension == row stride
+    uint32_t vcur = 0;  // ids in use: [0, vcur)
+    bool stats_valid = false;
+
+    DevState *d_st = nullptr;
+    uint64_t *d_tsum = nullptr, *d_tile_off = nullptr;
+    uint8_t *d_tile_sin = nullptr;
+    uint64_t cap_tiles = 0;
+    IterRec *h_rec = nullptr;  // pinned, device-visible
+    int rec_cap = 0;
+    unsigned long long *d_scratch = nullptr;  // 2 x u64 cursor/counter
+    uint32_t *d_delta = nullptr;       // 4 x vcap: decL | decR | incL | incR
+    uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
+    uint32_t *d_dirty_n = nullptr;
+    int depth = 8;  // iterations the host may run ahead of the device
+    // slotted stream (training loop, a != b merges)
+    int use_slots = 1;
+    int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
+    uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
+    unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
+    int rep_shift = 5;        // log2(delta-vector replicas in use): shrinks as merges get rarer
+    bool slotted = false;
+    uint64_t slot_T = 0;
+    int mq = 0;
+    uint32_t *d_meta[2] = {nullptr, nullptr};
+    uint4 *d_hdr[2] = {nullptr, nullptr};  // per slot: first three words, last word
+    uint32_t *d_slot_lens = nullptr;
+    unsigned long long *d_slot_off = nullptr, *d_slot_bsum = nullptr;
+    uint32_t *d_ids2 = nullptr;  // third stream buffer: target of compactions
+    uint64_t cap_slots = 0;
+    // data-parallel stepping (bpe_dp_*)
+    int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
+    bool dp_active = false;  // between bpe_dp_begin and bpe_dp_end
+    void *comm = nullptr;    // RCCL communicator (bpe_comm_init), one rank per ctx
+    int comm_rank = 0, comm_nranks = 1;
+    uint32_t *d_dp_folded = nullptr, *d_dp_table = nullptr;
+    long long *d_dp_key = nullptr;
+    uint64_t dp_cur_len = 0;
+    int merge_impl = 0;  // 0 three-pass | 1 single-pass (two-level decoupled look-back)
+    unsigned long long *d_desc = nullptr;   // look-back descriptors, one per tile
+    unsigned long long *d_gdesc = nullptr;  // ... and one per group of 64 tiles
+    uint64_t cap_desc = 0;
+    uint32_t epoch = 0;
+    uint32_t lb_tune = 1;  // bits 0..7: s_sleep(8) units between polls; bit 8: measurement-only 'no wait'
+
+    // encode scratch (grow-only)
+    uint32_t *d_enc_tmp = nullptr, *d_enc_len = nullptr;
+    int32_t *d_enc_out = nullptr;
+    unsigned long long *d_enc_off = nullptr, *d_enc_bsum = nullptr, *d_enc_long = nullptr;
+    unsigned long long *d_ht_keys = nullptr;
+    uint32_t *d_ht_vals = nullptr;
+    int32_t *d_merge_ids = nullptr;
+    uint64_t cap_enc_n = 0, cap_enc_chunks = 0, cap_ht = 0, cap_merge_ids = 0;
+
+    // decode (grow-only): vocab table, then ids / lengths / offsets / bytes of the last batch
+    uint8_t *d_dec_blob = nullptr, *d_dec_out = nullptr;
+    unsigned long long *d_dec_voff = nullptr, *d_dec_off = nullptr, *d_dec_bsum = nullptr;
+    int32_t *d_dec_ids = nullptr;
+    uint32_t *d_dec_len = nullptr;
+    uint64_t cap_dec_blob = 0, cap_dec_voff = 0, cap_dec_n = 0, cap_dec_out = 0;
+    uint32_t dec_V = 0;
+    bool dec_have_vocab = false, dec_have_result = false;
+    uint64_t dec_n = 0, dec_total = 0;
+
+    int mode = 1;     // 0 recount | 1 delta
+    int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
+    bool prof_active = false;
+    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache | 2 = 1 + dense 16-bit LDS table for byte streams
+    bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
+
+    std::vector<ProfEv> prof_open;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[BPE_PROF_NKINDS] = {0};
+    uint64_t prof_launches[BPE_PROF_NKINDS] = {0};
+    uint64_t prof_bytes[BPE_PROF_NKINDS] = {0};
+};
+
+namespace {
+
+int fail(bpe_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail((c), BPE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+#define LAUNCHCHK(c, name)                                                                \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return fail((c), BPE_E_HIP, "launch %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+#define TRY(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != BPE_OK) return rc_; \
+    } while (0)
+
+// scratch device allocation of one call, released on every exit path
+struct DevTmp {
+    void *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T>
+    T *as() const { return (T *)p; }
+};
+
+struct EventList {
+    std::vector<hipEvent_t> v;
+    ~EventList() {
+        for (hipEvent_t e : v)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+template <typename T>
+int dev_realloc(bpe_ctx *c, T *&p, size_t count) {
+    if (p) HIPCHK(c, hipFree(p));
+    p = nullptr;
+    if (count) HIPCHK(c, hipMalloc((void **)&p, count * sizeof(T)));
+    return BPE_OK;
+}
+
+inline uint64_t ntiles_of(uint64_t n) { return (n + TILE - 1) / TILE; }
+
+int ensure_ids(bpe_ctx *c, uint64_t n) {
+    // capacity padded so every tile load (and the +1 halo word) is in bounds
+    const uint64_t need = (ntiles_of(n) + 2) * TILE;
+    if (need > c->cap_ids) {
+        TRY(dev_realloc(c, c->d_ids[0], need));
+        TRY(dev_realloc(c, c->d_ids[1], need));
+        TRY(dev_realloc(c, c->d_ids2, need));
+        c->cap_ids = need;
+    }
+    const uint64_t nt = ntiles_of(n) + 1;
+    if (nt > c->cap_tiles) {
+        TRY(dev_realloc(c, c->d_tsum, nt));
+        TRY(dev_realloc(c, c->d_tile_off, nt));
+        TRY(dev_realloc(c, c->d_tile_sin, nt));
+        TRY(dev_realloc(c, c->d_meta[0], nt));
+        TRY(dev_realloc(c, c->d_meta[1], nt));
+        TRY(dev_realloc(c, c->d_hdr[0], nt));
+        TRY(dev_realloc(c, c->d_hdr[1], nt));
+        TRY(dev_realloc(c, c->d_slot_lens, nt));
+        TRY(dev_realloc(c, c->d_slot_off, nt + 1));
+        TRY(dev_realloc(c, c->d_slot_bsum, nt / SCAN_TILE + 2));
+        TRY(dev_realloc(c, c->d_desc, nt));
+        TRY(dev_realloc(c, c->d_gdesc, nt / 64 + 2));
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (nt / 64 + 2) * sizeof(unsigned long long), c->stream));
+        c->cap_tiles = nt;
+    }
+    return BPE_OK;
+}
+
+int ensure_table(bpe_ctx *c, uint32_t v) {
+    if (v > 65535) return fail(c, BPE_E_LIMIT, "vocab %u exceeds this build's 65535 limit", v);
+    if (v <= c->vcap) return BPE_OK;
+    uint32_t nv = std::max<uint32_t>(v, 256);
+    nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
+    TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
+    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv));
+    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL));
+    TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
+    if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * DELTA_REPL * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
+    if (c->d_first) {
+        HIPCHK(c, hipFree(c->d_first));
+        c->d_first = nullptr;
+    }
+    c->vcap = nv;
+    c->stats_valid = false;
+    return BPE_OK;
+}
+
+int ensure_rec(bpe_ctx *c, int n) {
+    if (n <= c->rec_cap) return BPE_OK;
+    if (c->h_rec) HIPCHK(c, hipHostFree(c->h_rec));
+    c->h_rec = nullptr;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_rec, sizeof(IterRec) * (size_t)n, hipHostMallocMapped));
+    c->rec_cap = n;
+    return BPE_OK;
+}
+
+// ---- profiling --------------------------------------------------------------
+int prof_begin(bpe_ctx *c, int kind, uint64_t bytes) {
+    // level 1: only the dominant kernel class (merge) -- two event records per
+    // iteration; level 2: every class (adds marker packets between all kernels)
+    c->prof_active = c->profile >= 2 || (c->profile == 1 && kind == BPE_PROF_MERGE);
+    if (!c->prof_active) return BPE_OK;
+    ProfEv ev;
+    ev.kind = kind;
+    ev.bytes = bytes;
+    for (hipEvent_t *e : {&ev.e0, &ev.e1}) {
+        if (!c->ev_pool.empty()) {
+            *e = c->ev_pool.back();
+            c->ev_pool.pop_back();
+        } else {
+            HIPCHK(c, hipEventCreate(e));
+        }
+    }
+    HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+    c->prof_open.push_back(ev);
+    return BPE_OK;
+}
+int prof_end(bpe_ctx *c) {
+    if (!c->prof_active) return BPE_OK;
+    c->prof_active = false;
+    HIPCHK(c, hipEventRecord(c->prof_open.back().e1, c->stream));
+    return BPE_OK;
+}
+int prof_drain(bpe_ctx *c) {
+    if (c->prof_open.empty()) return BPE_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (ProfEv &ev : c->prof_open) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+        c->prof_ms[ev.kind] += ms;
+        c->prof_launches[ev.kind] += 1;
+        c->prof_bytes[ev.kind] += ev.bytes;
+        c->ev_pool.push_back(ev.e0);
+        c->ev_pool.push_back(ev.e1);
+    }
+    c->prof_open.clear();
+    return BPE_OK;
+}
+
+// ---- launch helpers -----------------------------------------------------------
+inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap) {
+    uint64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// widen resident bytes into ids[0], mark chunk starts, reset state
+int start_from_bytes(bpe_ctx *c) {
+    const uint64_t n = c->nbytes;
+    TRY(ensure_ids(c, n));
+    TRY(prof_begin(c, BPE_PROF_WIDEN, 5 * n));
+    if (n) {
+        hipLaunchKernelGGL(k_widen, dim3(grid_for(n, 256 * 16, c->num_cus * 8)), dim3(256), 0,
+                           c->stream, c->d_bytes, c->d_ids[0], n);
+        LAUNCHCHK(c, "k_widen");
+        if (c->n_chunks) {
+            hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[0], c->d_offsets, c->n_chunks, n);
+            LAUNCHCHK(c, "k_mark_starts");
+            if (c->weighted) {
+                hipLaunchKernelGGL(k_mark_weights, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)), dim3(256),
+                                   0, c->stream, c->d_ids[0], c->d_offsets, c->d_wexp, c->n_chunks, n);
+                LAUNCHCHK(c, "k_mark_weights");
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
+    LAUNCHCHK(c, "k_init_state");
+    c->apply_target = 0;
+    TRY(prof_end(c));
+    c->par = 0;
+    c->n = n;
+    c->vcur = 256;
+    c->have_ids = true;
+    c->stats_valid = false;
+    c->stream_is_bytes = true;
+    return BPE_OK;
+}
+
+int clear_table(bpe_ctx *c) {
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcur * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// K1 on the current stream into the (cleared) table
+int launch_pair_count(bpe_ctx *c, bool with_first) {
+    const uint64_t n = c->n;
+    TRY(prof_begin(c, BPE_PROF_PAIR_COUNT, 4 * n));
+    if (n >= 2) {
+        if (with_first) {
+            hipLaunchKernelGGL(k_pair_count_simple<true>, dim3(grid_for(n, 1024, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
+                               c->vcap, c->d_first);
+        } else if (c->k1 == 0) {
+            hipLaunchKernelGGL(k_pair_count_simple<false>, dim3(grid_for(n, 1024, c->num_cus * 8)),
+                               dim3(256), 0, c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_mat,
+                               c->vcap, (uint32_t *)nullptr);
+        } else if (c->k1 == 2 && c->vcur <= 256 && c->stream_is_bytes && !c->weighted) {
+            // (16-bit LDS counters: unit increments only)
+            hipLaunchKernelGGL(k_pair_count_bytes, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
+                               dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
+                               c->par, c->d_mat, c->vcap);
+        } else {
+            hipLaunchKernelGGL(k_pair_count_lds, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
+                               dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
+                               c->par, c->d_mat, c->vcap);
+        }
+        LAUNCHCHK(c, "k_pair_count");
+    }
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+inline uint32_t vcap_rep(const bpe_ctx *c) { return c->vcap | ((uint32_t)c->rep_shift << 24); }
+
+SlotRef stream_ref(const bpe_ctx *c) {
+    SlotRef r;
+    if (c->slotted) {
+        r.b0 = c->d_ids[0];
+        r.b1 = c->d_ids[1];
+        r.meta = c->d_meta[c->mq];
+        r.T = c->slot_T;
+    } else {
+        r.b0 = c->d_ids[c->par];
+        r.b1 = nullptr;
+        r.meta = nullptr;
+        r.T = 0;
+    }
+    return r;
+}
+
+// K2 + tie-break: after these, resolved_pair() gives the pair on the device
+int launch_select(bpe_ctx *c, bool rowmax_all) {
+    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    if (rowmax_all) {
+        hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           c->vcur, c->d_rowmax);
+        LAUNCHCHK(c, "k_rowmax_all");
+    }
+    const SlotRef ref = stream_ref(c);
+    const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
+    const unsigned blocks = space > TIE_WINDOW0 ? grid_for(space - TIE_WINDOW0, 1024, TIE_BLOCKS) : 1u;
+    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                       c->vcap, c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, ++c->sel_epoch);
+    LAUNCHCHK(c, "k_select");
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// table update: apply blocks + row-maxima blocks in one launch
+template <bool FOLDED>
+int launch_table_update(bpe_ctx *c, uint32_t *delta, uint32_t Z, int par, IterRec *rec, int iter,
+                        int slot_finish) {
+    const uint32_t na = (Z + 1 + 31) / 32;
+    // Measured (cfg2): handing the row maxima to extra blocks of the same launch costs more
+    // (release + acquire fences, polling) than the ~1.5 us kernel boundary it saves -- 58 vs
+    // 45 ms per train -- so by default they are a launch of their own.
+    if (c->fused_rows) {
+        c->apply_target += na;
+        hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na + ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat,
+                           c->vcap, delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
+                           c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na,
+                           c->apply_target);
+    } else {
+        hipLaunchKernelGGL(k_apply_delta<FOLDED>, dim3(na), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           delta, FOLDED ? c->vcap : vcap_rep(c), c->d_rowmax, c->d_st, Z,
+                           c->d_dirty_list, c->d_dirty_n, par, rec, iter, slot_finish, na, 0ull);
+        LAUNCHCHK(c, "k_apply_delta");
+        hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(256), 0, c->stream, c->d_mat, c->vcap,
+                           Z + 1, c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    }
+    LAUNCHCHK(c, "k_apply_delta");
+    return BPE_OK;
+}
+
+// K3: three passes (summary, tile scan, rewrite); flips the ping-pong parity.
+// with_delta: the rewrite pass also accumulates the pair-table delta vectors,
+// which k_apply_delta / k_rowmax_list then fold into the table.
+int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_delta) {
+    const uint64_t n = c->n;  // upper bound of the device-side length
+    const uint64_t nt = ntiles_of(n);
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if (c->merge_impl == 1) {
+        if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
+            HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
+            c->epoch++;
+        }
+        const unsigned grid = (unsigned)std::max<uint64_t>(nt, 1);
+        if (with_delta)
+            hipLaunchKernelGGL(k_merge_lookback<true>, dim3(grid), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
+                               c->d_gdesc, c->epoch, newid, c->d_delta, vcap_rep(c), rec, iter, c->d_dirty_n, c->lb_tune);
+        else
+            hipLaunchKernelGGL(k_merge_lookback<false>, dim3(grid), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par, c->d_desc,
+                               c->d_gdesc, c->epoch, newid, (uint32_t *)nullptr, c->vcap, rec, iter, c->d_dirty_n,
+                               c->lb_tune);
+        LAUNCHCHK(c, "k_merge_lookback");
+    } else {
+    if (nt) {
+        hipLaunchKernelGGL(k_merge_count, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                           c->d_ids[c->par], c->d_st, c->par, c->d_tsum);
+        LAUNCHCHK(c, "k_merge_count");
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tsum, nt, c->d_tile_off,
+                       c->d_tile_sin, c->d_st, c->par, rec, iter, c->d_ids[c->par], c->d_dirty_n);
+    LAUNCHCHK(c, "k_tile_scan");
+    if (nt) {
+        if (with_delta)
+            hipLaunchKernelGGL(k_merge_scatter<true>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
+                               c->d_tile_off, c->d_tile_sin, newid, c->d_delta, vcap_rep(c));
+        else
+            hipLaunchKernelGGL(k_merge_scatter<false>, dim3((unsigned)nt), dim3(MT), 0, c->stream,
+                               c->d_ids[c->par], c->d_ids[c->par ^ 1], c->d_st, c->par,
+                               c->d_tile_off, c->d_tile_sin, newid, (uint32_t *)nullptr, c->vcap);
+        LAUNCHCHK(c, "k_merge_scatter");
+    }
+    }
+    TRY(prof_end(c));
+    if (with_delta && c->dp_active) {
+        // sharded: fold the replicas into the all-reduce payload; bpe_dp_apply does the rest
+        hipLaunchKernelGGL(k_dp_fold, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta,
+                           vcap_rep(c), newid, c->d_dp_folded);
+        LAUNCHCHK(c, "k_dp_fold");
+    } else if (with_delta) {
+        TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+        TRY(launch_table_update<false>(c, c->d_delta, newid, 0, nullptr, 0, 0));
+        TRY(prof_end(c));
+    }
+    c->par ^= 1;
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    return BPE_OK;
+}
+
+
+// ---- slotted stream ---------------------------------------------------------------
+// contiguous (d_ids[par], st->n[par]) -> slots of TILE ids, all full but the last
+int slots_enter(bpe_ctx *c) {
+    c->slot_T = ntiles_of(c->n);
+    c->mq = 0;
+    hipLaunchKernelGGL(k_slot_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
+                       dim3(256), 0, c->stream, c->d_meta[0], c->d_hdr[0], c->slot_T, c->d_st, c->par,
+                       (uint32_t)c->par, c->d_ids[c->par]);
+    LAUNCHCHK(c, "k_slot_init");
+    c->slotted = true;
+    return BPE_OK;
+}
+
+// slots -> contiguous in d_ids[0] (par 0); st->n[0] = the stream length
+int slots_leave(bpe_ctx *c) {
+    const uint64_t T = c->slot_T;
+    if (T) {
+        const uint64_t nb = (T + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_slot_lens, dim3(grid_for(T, 256, c->num_cus * 4)), dim3(256), 0, c->stream,
+                           c->d_meta[c->mq], T, c->d_slot_lens);
+        hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_slot_bsum, nb,
+                           c->d_scratch + 3);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum, c->d_slot_off);
+        hipLaunchKernelGGL(k_slot_compact, dim3((unsigned)T), dim3(256), 0, c->stream, c->d_ids[0],
+                           c->d_ids[1], c->d_meta[c->mq], c->d_slot_off, c->d_ids2);
+        LAUNCHCHK(c, "k_slot_compact");
+    }
+    std::swap(c->d_ids[0], c->d_ids2);
+    if (c->par != 0) {
+        hipLaunchKernelGGL(k_move_n, dim3(1), dim3(1), 0, c->stream, c->d_st, c->par, 0);
+        LAUNCHCHK(c, "k_move_n");
+    }
+    c->par = 0;
+    c->slotted = false;
+    return BPE_OK;
+}
+
+// one slotted merge pass + table update (delta mode only)
+int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (c->cap_tiles / 64 + 2) * sizeof(unsigned long long), c->stream));
+        c->epoch++;
+    }
+    const unsigned slot_grid = (unsigned)std::max<uint64_t>(c->slot_T, 1);
+    hipLaunchKernelGGL(k_merge_slot<true>, dim3(slot_grid), dim3(MT), 0,
+                       c->stream, c->d_ids[0], c->d_ids[1], c->d_ids[0], c->d_ids[1], c->d_meta[c->mq],
+                       c->d_meta[c->mq ^ 1], c->slot_T, c->d_st, c->par, newid, c->d_delta, vcap_rep(c),
+                       c->d_dirty_n, c->d_desc, c->epoch, c->d_hdr[c->mq], c->d_hdr[c->mq ^ 1]);
+    LAUNCHCHK(c, "k_merge_slot");
+    TRY(prof_end(c));
+    if (c->dp_active) {
+        // sharded: fold the replicas into the all-reduce payload; bpe_dp_apply does the rest
+        hipLaunchKernelGGL(k_dp_fold, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta,
+                           vcap_rep(c), newid, c->d_dp_folded);
+        LAUNCHCHK(c, "k_dp_fold");
+    } else {
+        TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+        TRY(launch_table_update<false>(c, c->d_delta, newid, c->par, rec, iter, 1));
+        TRY(prof_end(c));
+    }
+    c->par ^= 1;
+    c->mq ^= 1;
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    return BPE_OK;
+}
+
+int read_state(bpe_ctx *c, DevState *out) {
+    HIPCHK(c, hipMemcpyAsync(out, c->d_st, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BPE_OK;
+}
+
+}  // namespace

@@ -1,0 +1,150 @@
+// api_dp.hip -- bpe_dp_*: data-parallel stepping.
+// Part of bpe_api.hip, which includes the parts in order (one translation unit).
+
+// ---------------------------------------------------------------------------
+// data-parallel stepping: one ctx per rank, the host runs the two all-reduces
+
+extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_t nranks) {
+    if (!c || num_merges < 0 || rank < 0 || nranks < 1 || rank >= nranks || nranks > 1024)
+        return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->dp_rank = rank;
+    c->dp_nranks = nranks;
+    c->dp_merges = num_merges;
+    c->dp_active = true;
+    TRY(ensure_table(c, 256u + (uint32_t)num_merges));
+    TRY(ensure_rec(c, std::max(num_merges, 1)));
+    memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
+    if (c->d_dp_folded) (void)hipFree(c->d_dp_folded);
+    c->d_dp_folded = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, (size_t)c->vcap * 4 * sizeof(uint32_t)));
+    if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
+    if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 2 * sizeof(long long)));
+    TRY(start_from_bytes(c));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(launch_pair_count(c, false));
+    // the byte-pair block of the table, packed, is the first all-reduce payload
+    HIPCHK(c, hipMemcpy2DAsync(c->d_dp_table, 256 * 4, c->d_mat, (size_t)c->vcap * 4, 256 * 4, 256,
+                               hipMemcpyDeviceToDevice, c->stream));
+    c->dp_cur_len = c->n;
+    c->dp_enq = c->dp_done = 0;
+    c->rep_shift = 5;
+    if (c->use_slots) TRY(slots_enter(c));
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_buffers(bpe_ctx *c, void **table, uint64_t *table_count, void **delta,
+                              uint64_t *delta_count, void **tiekey) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    if (table) *table = c->d_dp_table;
+    if (table_count) *table_count = 256 * 256;
+    if (delta) *delta = c->d_dp_folded;
+    if (delta_count) *delta_count = (uint64_t)c->vcap * 4;
+    if (tiekey) *tiekey = c->d_dp_key;
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_table_ready(bpe_ctx *c) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy2DAsync(c->d_mat, (size_t)c->vcap * 4, c->d_dp_table, 256 * 4, 256 * 4, 256,
+                               hipMemcpyDeviceToDevice, c->stream));
+    c->vcur = 256;
+    hipLaunchKernelGGL(k_rowmax_all, dim3(256), dim3(256), 0, c->stream, c->d_mat, c->vcap, 256u,
+                       c->d_rowmax);
+    LAUNCHCHK(c, "k_rowmax_all");
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->vcur = 256u + (uint32_t)iter;
+    if (c->slotted && c->slot_T > 64 &&
+        c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
+        TRY(slots_leave(c));
+        TRY(slots_enter(c));
+    }
+    TRY(launch_select(c, false));
+    hipLaunchKernelGGL(k_dp_key, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st,
+                       (unsigned long long)c->dp_rank, c->d_dp_key);
+    LAUNCHCHK(c, "k_dp_key");
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_dp_resolve, dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
+    LAUNCHCHK(c, "k_dp_resolve");
+    c->dp_enq = iter + 1;
+    if (c->slotted) return launch_merge_slot(c, 256u + (uint32_t)iter, iter, c->h_rec);
+    const int saved = c->merge_impl;
+    c->merge_impl = 0;  // the three-pass form finalises the pair before the rewrite
+    const int rc = launch_merge(c, 256u + (uint32_t)iter, iter, c->h_rec, true);
+    c->merge_impl = saved;
+    return rc;
+}
+
+extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
+    if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t Z = 256u + (uint32_t)iter;
+    if (c->slotted)  // the slotted pass leaves length/record bookkeeping to the table update
+        TRY(launch_table_update<true>(c, c->d_dp_folded, Z, c->par ^ 1, c->h_rec, iter, 1));
+    else
+        TRY(launch_table_update<true>(c, c->d_dp_folded, Z, 0, nullptr, 0, 0));
+    return BPE_OK;
+}
+
+// Wait for iteration `iter`'s record (written by the device into pinned memory).
+extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uint64_t *count,
+                           uint64_t *local_len, int32_t *status) {
+    if (!c || !c->d_dp_folded || iter < 0 || iter >= std::max(c->dp_merges, 1))
+        return fail(c, BPE_E_ARG, "bad iteration");
+    volatile IterRec *r = &c->h_rec[iter];
+    for (uint64_t spins = 1; r->seq != (unsigned long long)iter + 1; spins++) {
+        if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
+            r->seq != (unsigned long long)iter + 1)
+            return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", iter);
+    }
+    __sync_synchronize();
+    if (a) *a = r->a;
+    if (b) *b = r->b;
+    if (count) *count = r->count;
+    if (local_len) *local_len = r->new_len;
+    if (status) *status = (r->status == ST_OK) ? BPE_OK : (r->status == ST_EMPTY ? BPE_E_EMPTY_STATS : BPE_E_INTERNAL);
+    if (r->status == ST_OK) {
+        if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
+        c->dp_cur_len = r->new_len;
+        c->n = r->new_len;  // tighter launch bound
+        c->dp_done = iter + 1;
+    }
+    return BPE_OK;
+}
+
+extern "C" int bpe_dp_end(bpe_ctx *c) {
+    if (!c) return BPE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->slotted) {
+        // iterations enqueued after the last reported one (an early stop) did nothing on the
+        // device: undo their parity flips, then hand back a contiguous stream
+        if ((c->dp_enq - c->dp_done) & 1) {
+            c->par ^= 1;
+            c->mq ^= 1;
+        }
+        hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
+        TRY(slots_leave(c));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n = c->dp_cur_len;
+    } else if ((c->dp_enq - c->dp_done) & 1) {
+        c->par ^= 1;
+    }
+    TRY(prof_drain(c));
+    c->dp_nranks = 1;
+    c->dp_rank = 0;
+    c->dp_active = false;
+    return BPE_OK;
+}

@@ -1,0 +1,208 @@
+// api_encode.hip -- bpe_encode_batch.
+// Part of bpe_api.hip, which includes the parts in order (one translation unit).
+
+// ---------------------------------------------------------------------------
+// encode
+
+namespace {
+inline uint64_t mix_key(uint64_t key) { return (key * 0x9E3779B97F4A7C15ull) >> 40; }
+
+int upload_offsets(bpe_ctx *c, const uint64_t *chunk_offsets, uint64_t n_chunks) {
+    if (n_chunks > c->cap_offsets) {
+        TRY(dev_realloc(c, c->d_offsets, (size_t)n_chunks));
+        c->cap_offsets = n_chunks;
+    }
+    if (n_chunks)
+        HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
+                                 hipMemcpyHostToDevice, c->stream));
+    return BPE_OK;
+}
+}  // namespace
+
+extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                                const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                                uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
+                                uint64_t *n_out) {
+    if (!c || M < 0 || (!merges && M) || (!bytes && n)) return fail(c, BPE_E_ARG, "bad arguments");
+    if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "batch of %llu bytes exceeds 2^32-1", (unsigned long long)n);
+    static const uint64_t zero = 0;
+    if (!chunk_offsets) {
+        chunk_offsets = &zero;
+        n_chunks = 1;
+    }
+    if (n_out) *n_out = 0;
+    if (n == 0 || n_chunks == 0) {
+        if (out_offsets)
+            for (uint64_t i = 0; i <= n_chunks; i++) out_offsets[i] = 0;
+        return BPE_OK;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    // this call reuses the ctx's input and id-stream buffers
+    c->have_bytes = false;
+    c->weighted = false;
+    c->have_ids = false;
+    c->stats_valid = false;
+
+    // 1. rank table: pair -> position in the (priority-ordered) merge list
+    uint64_t hs = 16;
+    while (hs < 2 * (uint64_t)M + 2) hs <<= 1;
+    std::vector<unsigned long long> hk(hs, ~0ull);
+    std::vector<uint32_t> hv(hs, 0xFFFFFFFFu);
+    for (int32_t r = 0; r < M; r++) {
+        const int32_t a = merges[2 * r], b = merges[2 * r + 1];
+        if (a < 0 || b < 0) return fail(c, BPE_E_ARG, "negative id in merges[%d]", r);
+        const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
+        uint64_t h = mix_key(key) & (hs - 1);
+        while (hk[h] != ~0ull && hk[h] != key) h = (h + 1) & (hs - 1);
+        hk[h] = key;
+        hv[h] = (uint32_t)r;  // a repeated pair keeps its last entry, like a dict
+    }
+    if (hs > c->cap_ht) {
+        TRY(dev_realloc(c, c->d_ht_keys, (size_t)hs));
+        TRY(dev_realloc(c, c->d_ht_vals, (size_t)hs));
+        c->cap_ht = hs;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ht_keys, hk.data(), hs * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ht_vals, hv.data(), hs * 4, hipMemcpyHostToDevice, c->stream));
+    const int32_t *d_mids = nullptr;
+    if (merge_ids && M) {
+        if ((uint64_t)M > c->cap_merge_ids) {
+            TRY(dev_realloc(c, c->d_merge_ids, (size_t)M));
+            c->cap_merge_ids = (uint64_t)M;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_merge_ids, merge_ids, (size_t)M * 4, hipMemcpyHostToDevice, c->stream));
+        d_mids = c->d_merge_ids;
+    }
+    // 2. input
+    if (n + 16 > c->cap_bytes) {
+        TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
+        c->cap_bytes = n + 16;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, hipMemcpyHostToDevice, c->stream));
+    TRY(upload_offsets(c, chunk_offsets, n_chunks));
+    // 3. scratch
+    if (n > c->cap_enc_n) {
+        TRY(dev_realloc(c, c->d_enc_tmp, (size_t)n));
+        TRY(dev_realloc(c, c->d_enc_out, (size_t)n));
+        TRY(dev_realloc(c, c->d_enc_long, (size_t)(n / (ENC_LMAX + 1) + 2)));
+        c->cap_enc_n = n;
+    }
+    const uint64_t nb = (n_chunks + SCAN_TILE - 1) / SCAN_TILE;
+    if (n_chunks > c->cap_enc_chunks) {
+        TRY(dev_realloc(c, c->d_enc_len, (size_t)n_chunks));
+        TRY(dev_realloc(c, c->d_enc_off, (size_t)n_chunks + 1));
+        TRY(dev_realloc(c, c->d_enc_bsum, (size_t)nb + 1));
+        c->cap_enc_chunks = n_chunks;
+    }
+    unsigned long long *d_nlong = c->d_scratch, *d_total = c->d_scratch + 1;
+    uint32_t *d_min = (uint32_t *)(c->d_scratch + 2);
+    HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, 2 * sizeof(unsigned long long), c->stream));
+    const uint32_t mask = (uint32_t)(hs - 1);
+    // 4. one chunk per lane
+    TRY(prof_begin(c, BPE_PROF_ENCODE, n));
+    hipLaunchKernelGGL(k_encode_short, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
+                       dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                       c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
+                       c->d_enc_long, d_nlong);
+    LAUNCHCHK(c, "k_encode_short");
+    TRY(prof_end(c));
+    unsigned long long n_long = 0;
+    HIPCHK(c, hipMemcpyAsync(&n_long, d_nlong, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // 5. the few long chunks: stream-wide rounds (lowest rank present -> merge everywhere)
+    if (n_long) {
+        std::vector<unsigned long long> ids_l(n_long);
+        HIPCHK(c, hipMemcpy(ids_l.data(), c->d_enc_long, n_long * 8, hipMemcpyDeviceToHost));
+        std::sort(ids_l.begin(), ids_l.end());
+        std::vector<unsigned long long> src(n_long), dst(n_long + 1);
+        unsigned long long tot = 0;
+        for (uint64_t k = 0; k < n_long; k++) {
+            const uint64_t ch = ids_l[k];
+            const uint64_t s0 = chunk_offsets[ch], e0 = (ch + 1 < n_chunks) ? chunk_offsets[ch + 1] : n;
+            src[k] = s0;
+            dst[k] = tot;
+            tot += e0 - s0;
+        }
+        dst[n_long] = tot;
+        TRY(ensure_table(c, 256));
+        TRY(ensure_ids(c, tot));
+        DevTmp t_src, t_dst, t_cid, t_starts;
+        HIPCHK(c, t_src.alloc(n_long * 8));
+        HIPCHK(c, t_dst.alloc((n_long + 1) * 8));
+        HIPCHK(c, t_cid.alloc(n_long * 8));
+        HIPCHK(c, t_starts.alloc((n_long + 1) * 8));
+        unsigned long long *d_src = t_src.as<unsigned long long>(), *d_dst = t_dst.as<unsigned long long>(),
+                           *d_cid = t_cid.as<unsigned long long>(), *d_starts = t_starts.as<unsigned long long>();
+        HIPCHK(c, hipMemcpyAsync(d_src, src.data(), n_long * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_dst, dst.data(), (n_long + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_cid, ids_l.data(), n_long * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_long_gather, dim3((unsigned)n_long), dim3(256), 0, c->stream, c->d_bytes,
+                           d_src, d_dst, (uint64_t)n_long, c->d_ids[0]);
+        LAUNCHCHK(c, "k_long_gather");
+        hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, tot);
+        c->apply_target = 0;
+        c->par = 0;
+        c->n = tot;
+        int rc_long = BPE_OK;
+        for (;;) {
+            HIPCHK(c, hipMemsetAsync(d_min, 0xFF, 4, c->stream));
+            if (c->n >= 2) {
+                hipLaunchKernelGGL(k_min_rank, dim3(grid_for(c->n, 256, c->num_cus * 8)), dim3(256), 0,
+                                   c->stream, c->d_ids[c->par], c->d_st, c->par, c->d_ht_keys,
+                                   c->d_ht_vals, mask, d_min);
+                LAUNCHCHK(c, "k_min_rank");
+            }
+            uint32_t r = 0xFFFFFFFFu;
+            HIPCHK(c, hipMemcpyAsync(&r, d_min, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (r == 0xFFFFFFFFu) break;
+            const int32_t newid = merge_ids ? merge_ids[r] : 256 + (int32_t)r;
+            hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(1), 0, c->stream, c->d_st, merges[2 * r],
+                               merges[2 * r + 1]);
+            if ((rc_long = launch_merge(c, (uint32_t)newid, 0, nullptr, false)) != BPE_OK) break;
+            DevState stt;
+            if ((rc_long = read_state(c, &stt)) != BPE_OK) break;
+            c->n = stt.n[c->par];
+        }
+        if (rc_long == BPE_OK) {
+            HIPCHK(c, hipMemsetAsync(c->d_scratch + 3, 0, 8, c->stream));
+            hipLaunchKernelGGL(k_collect_starts, dim3(grid_for(c->n, 256, c->num_cus * 8)), dim3(256), 0,
+                               c->stream, c->d_ids[c->par], c->n, d_starts, (unsigned long long)n_long,
+                               c->d_scratch + 3);
+            std::vector<unsigned long long> starts(n_long + 1);
+            HIPCHK(c, hipMemcpyAsync(starts.data(), d_starts, n_long * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            std::sort(starts.begin(), starts.begin() + n_long);
+            starts[n_long] = c->n;
+            HIPCHK(c, hipMemcpyAsync(d_starts, starts.data(), (n_long + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_long_scatter, dim3((unsigned)n_long), dim3(256), 0, c->stream,
+                               c->d_ids[c->par], d_starts, d_cid, d_src, (uint64_t)n_long, c->d_enc_tmp,
+                               c->d_enc_len);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (rc_long != BPE_OK) return rc_long;
+    }
+    // 6. output offsets = exclusive scan of the per-chunk lengths
+    hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len,
+                       n_chunks, c->d_enc_bsum);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
+                       c->d_enc_bsum, c->d_enc_off);
+    LAUNCHCHK(c, "k_scan_*");
+    // 7. placement and copy-out
+    hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
+                       c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+    LAUNCHCHK(c, "k_encode_place");
+    unsigned long long total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ids_out && total)
+        HIPCHK(c, hipMemcpy(ids_out, c->d_enc_out, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out_offsets) {
+        HIPCHK(c, hipMemcpy(out_offsets, c->d_enc_off, n_chunks * 8, hipMemcpyDeviceToHost));
+        out_offsets[n_chunks] = total;
+    }
+    if (n_out) *n_out = total;
+    TRY(prof_drain(c));
+    return BPE_OK;
+}

@@ -1,0 +1,28 @@
+// api_prof.hip -- bpe_prof_*.
+// Part of bpe_api.hip, which includes the parts in order (one translation unit).
+
+extern "C" {
+
+int bpe_prof_reset(bpe_ctx *c) {
+    if (!c) return BPE_E_ARG;
+    TRY(prof_drain(c));
+    for (int k = 0; k < BPE_PROF_NKINDS; k++) {
+        c->prof_ms[k] = 0;
+        c->prof_launches[k] = 0;
+        c->prof_bytes[k] = 0;
+    }
+    return BPE_OK;
+}
+
+int bpe_prof_read(bpe_ctx *c, double *ms, uint64_t *launches, uint64_t *alg_bytes) {
+    if (!c) return BPE_E_ARG;
+    TRY(prof_drain(c));
+    for (int k = 0; k < BPE_PROF_NKINDS; k++) {
+        if (ms) ms[k] = c->prof_ms[k];
+        if (launches) launches[k] = c->prof_launches[k];
+        if (alg_bytes) alg_bytes[k] = c->prof_bytes[k];
+    }
+    return BPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,151 @@
+// api_train.hip -- bpe_train: the pipelined training loop.
+// Part of bpe_api.hip, which includes the parts in order (one translation unit).
+
+extern "C" {
+
+int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
+              double *iter_ms_out, uint64_t *len_out, int32_t *n_done) {
+    if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
+    if (c->dp_active) return fail(c, BPE_E_STATE, "bpe_dp_end first");
+    if (n_done) *n_done = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(ensure_table(c, 256u + (uint32_t)num_merges));
+    TRY(ensure_rec(c, std::max(num_merges, 1)));
+    memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
+    TRY(start_from_bytes(c));
+    const bool delta = (c->mode == 1);
+    EventList ev_list;  // destroyed on every exit path
+    std::vector<hipEvent_t> &evs = ev_list.v;
+    if (iter_ms_out) {
+        evs.assign((size_t)num_merges + 1, nullptr);
+        for (auto &e : evs) HIPCHK(c, hipEventCreate(&e));
+    }
+    // statistics of the initial byte stream (iteration 0 of both modes)
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
+    TRY(prof_end(c));
+    if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[0], c->stream));
+    const uint64_t n0 = c->n;
+    TRY(launch_pair_count(c, false));
+
+    int done = 0, rc = BPE_OK, consumed = 0;
+    uint64_t cur_len = n0;  // exact length before iteration `consumed`
+    bool stop = false;
+    c->rep_shift = 5;
+    const bool slots = delta && c->use_slots && c->merge_impl == 0;
+    if (slots) TRY(slots_enter(c));
+    // The device writes one IterRec per iteration into pinned host memory; the
+    // host runs up to `depth` iterations ahead and only ever waits on those
+    // records, never on the stream (no hipStreamSynchronize in the loop).
+    auto consume = [&](int j) -> int {
+        volatile IterRec *r = &c->h_rec[j];
+        for (uint64_t spins = 1; r->seq != (unsigned long long)j + 1; spins++) {
+            if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
+                r->seq != (unsigned long long)j + 1)
+                return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
+        }
+        __sync_synchronize();
+        if (r->status == ST_EMPTY) {
+            stop = true;
+            rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
+            return BPE_OK;
+        }
+        if (r->status != ST_OK) {
+            stop = true;
+            rc = fail(c, BPE_E_INTERNAL, "device status %u at iteration %d%s", r->status, j,
+                      r->status == ST_LOOKBACK ? " (look-back wait timed out; set option merge=0)" : "");
+            return BPE_OK;
+        }
+        if (pairs_out) {
+            pairs_out[2 * j] = r->a;
+            pairs_out[2 * j + 1] = r->b;
+        }
+        if (counts_out) counts_out[j] = r->count;
+        if (len_out) len_out[j] = r->new_len;
+        if (c->profile) {
+            // algorithmic bytes: get_stats reads 4N_i, merge reads 4N_i, writes 4N_{i+1}
+            if (delta) {
+                c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * cur_len + r->new_len);
+            } else {
+                c->prof_bytes[BPE_PROF_MERGE] += 4 * (cur_len + r->new_len);
+                if (j > 0) c->prof_bytes[BPE_PROF_PAIR_COUNT] += 4 * cur_len;
+            }
+        }
+        cur_len = r->new_len;
+        c->n = cur_len;  // tighter launch bound for what is enqueued next
+        // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
+        // few sites -> few same-address atomics -> fewer replicas to fold (measured: going
+        // below 32 while a pass still has tens of thousands of sites slows the merge pass)
+        c->rep_shift = 5;  // (k_apply_delta folds 32 replicas with 16 loads in flight per lane: no need to shrink)
+        done = j + 1;
+        return BPE_OK;
+    };
+
+    int i = 0;
+    while (!stop) {
+        // enqueue iteration i (if any is left), then look at the record `depth` back
+        if (i < num_merges) {
+            c->vcur = 256u + (uint32_t)i;
+            bool full_rowmax = (i == 0);
+            if (!delta && i > 0) {
+                TRY(clear_table(c));
+                TRY(launch_pair_count(c, false));
+                full_rowmax = true;
+            }
+            // Slots thinning out: re-pack (between merges nothing is pending).  A pass costs
+            // per slot as much as per id, so the slot count should follow the stream length
+            // closely; at 31/32 fill a whole cfg2 run re-packs ~45 times, ~60 us each.
+            if (c->slotted && c->slot_T > 64 &&
+                c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
+                TRY(slots_leave(c));
+                TRY(slots_enter(c));
+            }
+            TRY(launch_select(c, full_rowmax));
+            if (c->slotted)
+                TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));
+            else
+                TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
+            if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
+            i++;
+        }
+        if (consumed < i && (i - consumed > c->depth || i == num_merges)) {
+            TRY(consume(consumed));
+            if (!stop) consumed++;
+        }
+        if (consumed >= num_merges) break;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->slotted) {
+        // leave the ids contiguous for whoever reads them next
+        if (stop) {  // parity of the no-op iterations enqueued after the failing one
+            const int back = i - done;
+            if (back & 1) {
+                c->par ^= 1;
+                c->mq ^= 1;
+            }
+            hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
+        }
+        TRY(slots_leave(c));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->n = cur_len;
+        c->vcur = 256u + (uint32_t)done;
+    } else {
+        c->par = done & 1;
+        c->n = cur_len;
+        c->vcur = 256u + (uint32_t)done;
+    }
+    // device buffers hold the stream after `done` merges
+    if (iter_ms_out) {
+        for (int i = 0; i < done; i++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, evs[(size_t)i], evs[(size_t)i + 1]));
+            iter_ms_out[i] = ms;
+        }
+    }
+    TRY(prof_drain(c));
+    if (n_done) *n_done = done;
+    return rc;
+}
+
+}  // extern "C"
