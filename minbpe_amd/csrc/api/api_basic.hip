@@ -112,6 +112,18 @@ static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const u
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream of %llu bytes exceeds 2^32-1 per GPU",
                                        (unsigned long long)n);
     if (wexp && !chunk_offsets) return fail(c, BPE_E_ARG, "weights need chunk offsets");
+    if (wexp) {  // (checked before anything is queued: no copy may outlive a failed call)
+        // pair counts are 32-bit: the text the weighted chunks stand for must stay below 2^32 bytes
+        unsigned __int128 stands_for = 0;
+        for (uint64_t i = 0; i < n_chunks; i++) {
+            if (wexp[i] > 31) return fail(c, BPE_E_ARG, "weight exponent %u of chunk %llu exceeds 31", wexp[i],
+                                          (unsigned long long)i);
+            const uint64_t b = chunk_offsets[i], e = i + 1 < n_chunks ? chunk_offsets[i + 1] : n;
+            if (e > b && e <= n) stands_for += (unsigned __int128)(e - b) << wexp[i];
+        }
+        if (stands_for >= ((unsigned __int128)1 << 32))
+            return fail(c, BPE_E_LIMIT, "the weighted chunks stand for >= 2^32 bytes of text (32-bit pair counts)");
+    }
     HIPCHK(c, hipSetDevice(c->device));
     if (n + 16 > c->cap_bytes) {
         TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
@@ -132,16 +144,6 @@ static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const u
                                  hipMemcpyHostToDevice, c->stream));
     c->weighted = false;
     if (wexp && n_chunks) {
-        // pair counts are 32-bit: the text the weighted chunks stand for must stay below 2^32 bytes
-        unsigned __int128 stands_for = 0;
-        for (uint64_t i = 0; i < n_chunks; i++) {
-            if (wexp[i] > 31) return fail(c, BPE_E_ARG, "weight exponent %u of chunk %llu exceeds 31", wexp[i],
-                                          (unsigned long long)i);
-            const uint64_t b = chunk_offsets[i], e = i + 1 < n_chunks ? chunk_offsets[i + 1] : n;
-            if (e > b && e <= n) stands_for += (unsigned __int128)(e - b) << wexp[i];
-        }
-        if (stands_for >= ((unsigned __int128)1 << 32))
-            return fail(c, BPE_E_LIMIT, "the weighted chunks stand for >= 2^32 bytes of text (32-bit pair counts)");
         if (n_chunks > c->cap_wexp) {
             TRY(dev_realloc(c, c->d_wexp, (size_t)n_chunks));
             c->cap_wexp = n_chunks;
