@@ -1,6 +1,5 @@
 """GPU: the HIP path (through the C-ABI) against the CPU oracle and the golden
 vectors generated from the reference.  Integer work: every comparison is exact."""
-import hashlib
 import random
 
 import numpy as np

@@ -1,9 +1,7 @@
 """CPU: host-side logic of the drop-in classes that needs no GPU: the .model /
 .vocab formats (base.py:97-165), decode (basic.py:51-55, regex.py:78-90),
 vocab construction, chunk concatenation."""
-import os
 
-import numpy as np
 import pytest
 
 from minbpe_amd import BasicTokenizer, RegexTokenizer, Tokenizer

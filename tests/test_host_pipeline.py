@@ -3,7 +3,6 @@ test double built on the oracle (tests/fake_engine.py).  What runs here is minbp
 itself -- native pre-split, de-duplication, special-token splicing, batch offsets, vocab tables,
 error mapping -- against the golden vectors generated from the reference.  The kernels behind the
 same calls are covered by test_gpu_parity.py."""
-import numpy as np
 import pytest
 
 from helpers import case_text

@@ -7,7 +7,6 @@ import os
 import sys
 import types
 
-import numpy as np
 import pytest
 
 import oracle

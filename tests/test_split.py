@@ -37,7 +37,6 @@ def check(native, text, threads=1):
 
 def test_unicode_tables_match_the_regex_module(native):
     """every class used by the scanner, for every code point, against `regex` itself"""
-    import ctypes
     # probe the tables through the splitter: a lone character's class decides how "xC" splits
     L, N, S = re.compile(r"\\p{L}"), re.compile(r"\\p{N}"), re.compile(r"\\s")
     rng = random.Random(1)
