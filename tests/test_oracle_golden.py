@@ -89,3 +89,55 @@ def test_against_live_reference_taylorswift(golden):
     assert h(list(merges.items())) == g["regex512_merges_hash"]
     ids, _ = oracle.encode(pairs, data, offs)
     assert len(ids) == g["regex512_encode_len"] and h(ids.tolist()) == g["regex512_encode_hash"]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_against_live_reference_random(native):
+    """Differential check: the reference itself (imported from its read-only tree) against the
+    oracle on random inputs -- tie-heavy alphabets, runs, multi-byte text, special tokens."""
+    import random
+    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from minbpe import BasicTokenizer as RefBasic, RegexTokenizer as RefRegex
+    from helpers import split_chunks
+    rng = random.Random(424242)
+    texts = []
+    for k, n in [(2, 400), (3, 900), (5, 1500), (26, 2500)]:
+        texts.append("".join(rng.choice([chr(97 + rng.randrange(k)), " ", chr(97 + rng.randrange(k))]) for _ in range(n)))
+    texts.append("aaaa" * 50 + " " + "ab" * 80 + "   \n\n" + "aaa " * 40)
+    texts.append(native.synth_text(6000, 99).decode())
+    for text in texts:
+        for nm in (5, 40):
+            # BasicTokenizer (basic.py:20-49, 57-74)
+            ref = RefBasic()
+            try:
+                ref.train(text, 256 + nm)
+                ref_pairs = list(ref.merges)
+            except ValueError:
+                ref_pairs = None
+            if ref_pairs is None:
+                with pytest.raises(oracle.OracleEmptyStats):
+                    oracle.train(text.encode(), nm)
+            else:
+                pairs, _, _ = oracle.train(text.encode(), nm)
+                assert pairs == ref_pairs
+                probe = text[: len(text) // 3] + text[::-1][:50]
+                assert oracle.encode(pairs, probe.encode())[0].tolist() == ref.encode(probe)
+            # RegexTokenizer (regex.py:36-70, 92-121)
+            ref = RefRegex()
+            data, offs = split_chunks(text)
+            try:
+                ref.train(text, 256 + nm)
+                ref_pairs = list(ref.merges)
+            except ValueError:
+                ref_pairs = None
+            if ref_pairs is None:
+                with pytest.raises(oracle.OracleEmptyStats):
+                    oracle.train(data, nm, offs)
+            else:
+                pairs, _, _ = oracle.train(data, nm, offs)
+                assert pairs == ref_pairs
+                probe = text[: len(text) // 3]
+                pd, po = split_chunks(probe)
+                assert oracle.encode(pairs, pd, po)[0].tolist() == ref.encode_ordinary(probe)
