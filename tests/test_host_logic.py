@@ -102,3 +102,21 @@ def test_gpt4_merge_recovery_from_ranks(native):
     ranks = {tok: idx for idx, tok in vocab.items()}
     rec = _recover_merges(ranks)
     assert rec == {p: 256 + i for i, p in enumerate(pairs)}
+
+
+def test_reference_import_paths():
+    # the reference's module layout (minbpe/base.py, basic.py, regex.py, gpt4.py) resolves here too
+    import minbpe_amd
+    from minbpe_amd.base import Tokenizer as T1, get_stats, merge, render_token  # noqa: F401
+    from minbpe_amd.basic import BasicTokenizer as B1
+    from minbpe_amd.regex import GPT2_SPLIT_PATTERN, GPT4_SPLIT_PATTERN as P4, RegexTokenizer as R1  # noqa: F401
+    from minbpe_amd.gpt4 import GPT4_SPECIAL_TOKENS, GPT4Tokenizer as G1, bpe, recover_merges
+    assert (T1, B1, R1, G1) == (minbpe_amd.Tokenizer, minbpe_amd.BasicTokenizer, minbpe_amd.RegexTokenizer,
+                                minbpe_amd.GPT4Tokenizer)
+    assert P4 == minbpe_amd.GPT4_SPLIT_PATTERN and GPT4_SPECIAL_TOKENS["<|endoftext|>"] == 100257
+    # gpt4.py:11-46 on a toy rank table: "ab" merged first, then "abc"
+    ranks = {bytes([i]): i for i in range(256)}
+    ranks[b"ab"] = 256
+    ranks[b"abc"] = 257
+    assert bpe(ranks, b"abc", max_rank=257) == [b"ab", b"c"]
+    assert recover_merges(ranks) == {(97, 98): 256, (256, 99): 257}
