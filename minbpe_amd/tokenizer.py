@@ -429,13 +429,21 @@ class GPT4Tokenizer(RegexTokenizer):
         '<|fim_suffix|>': 100260, '<|endofprompt|>': 100276,
     }
 
-    def __init__(self):
+    def __init__(self, ranks=None):
+        """ranks: None -> cl100k_base from the `tiktoken` package, as the reference does
+        (gpt4.py:63-64); or the same table given directly -- a {token bytes: rank} dict, or the
+        path of a `.tiktoken` file (lines of "<base64 token> <rank>") -- for machines without
+        the package or without network access."""
         super().__init__(pattern=GPT4_SPLIT_PATTERN)
-        try:
-            import tiktoken
-        except ImportError as e:
-            raise ImportError("GPT4Tokenizer needs the `tiktoken` package for cl100k_base ranks") from e
-        ranks = tiktoken.get_encoding("cl100k_base")._mergeable_ranks
+        if ranks is None:
+            try:
+                import tiktoken
+            except ImportError as e:
+                raise ImportError("GPT4Tokenizer needs the `tiktoken` package for cl100k_base ranks "
+                                  "(or pass ranks= a dict / a .tiktoken file)") from e
+            ranks = tiktoken.get_encoding("cl100k_base")._mergeable_ranks
+        elif not isinstance(ranks, dict):
+            ranks = load_tiktoken_ranks(ranks)
         self.merges = _recover_merges(ranks)
         vocab = {i: bytes([i]) for i in range(256)}
         for (a, b), idx in self.merges.items():
@@ -485,6 +493,18 @@ class GPT4Tokenizer(RegexTokenizer):
                             f" -> [{render_token(tok)}] {idx}\n")
                 else:
                     f.write(f"[{render_token(tok)}] {idx}\n")
+
+
+def load_tiktoken_ranks(path):
+    """A `.tiktoken` rank file -> {token bytes: rank}."""
+    import base64
+    ranks = {}
+    with open(path, "rb") as f:
+        for line in f:
+            if line.strip():
+                tok, rank = line.split()
+                ranks[base64.b64decode(tok)] = int(rank)
+    return ranks
 
 
 def _split_by_ranks(ranks, token, max_rank):

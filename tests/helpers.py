@@ -34,3 +34,16 @@ def data_for(case, native):
     if case["kind"] == "basic":
         return text.encode("utf-8"), None
     return split_chunks(text, pattern_of(case))
+
+
+def toy_rank_table(base_tok, seed):
+    """A cl100k-shaped {token bytes: rank} table from a trained tokenizer: single bytes get a
+    permutation of 0..255 (tiktoken's byte order is not the identity), merged tokens rank = id."""
+    import random
+    perm = list(range(256))
+    random.Random(seed).shuffle(perm)
+    ranks = {bytes([b]): perm[b] for b in range(256)}
+    for idx in range(256, 256 + len(base_tok.merges)):
+        assert base_tok.vocab[idx] not in ranks  # vocabularies this small have no duplicate byte strings
+        ranks[base_tok.vocab[idx]] = idx
+    return perm, ranks

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from helpers import case_text, data_for, split_chunks
+from helpers import case_text, data_for, split_chunks, toy_rank_table
 
 pytestmark = pytest.mark.gpu
 
@@ -666,3 +666,21 @@ def test_encode_ordinary_batch_and_back(native):
     assert len(ids) == 0 and doff.tolist() == [0]
     ids, doff = tok.encode_ordinary_batch(["", ""])
     assert len(ids) == 0 and doff.tolist() == [0, 0, 0]
+
+
+def test_gpt4_tokenizer_on_a_toy_rank_table(native):
+    """GPT4Tokenizer through the device (byte shuffle + merge ids that are ranks, gpt4.py:57-130);
+    cl100k_base itself is not available offline, so the rank table is built from a tokenizer
+    trained here."""
+    from minbpe_amd import GPT4Tokenizer, RegexTokenizer
+    text = native.synth_text(300_000, 79).decode()
+    base = RegexTokenizer()
+    base.train(text, 256 + 400)
+    perm, ranks = toy_rank_table(base, 6)
+    g = GPT4Tokenizer(ranks)
+    probe = text[:50_000] + " don't  stop 12345 ünïcödé 😉"
+    want = [perm[i] if i < 256 else i for i in base.encode_ordinary(probe)]
+    assert g.encode_ordinary(probe) == want
+    assert g.decode(want) == probe and g.decode_batch(want) == probe.encode("utf-8")
+    ids = g.encode("<|endoftext|>" + probe[:200], allowed_special="all")
+    assert ids[0] == 100257 and ids[1:] == g.encode_ordinary(probe[:200])

@@ -5,7 +5,7 @@ error mapping -- against the golden vectors generated from the reference.  The k
 same calls are covered by test_gpu_parity.py."""
 import pytest
 
-from helpers import case_text
+from helpers import case_text, toy_rank_table
 
 
 @pytest.fixture()
@@ -74,3 +74,35 @@ def test_custom_pattern_takes_the_regex_module_path(classes, native):
     assert ids[int(doff[0]):int(doff[1])].tolist() == tok.encode_ordinary("one two")
     assert ids[int(doff[2]):int(doff[3])].tolist() == tok.encode_ordinary("33 three")
     assert tok.decode(tok.encode(text)) == text
+
+
+def test_gpt4_tokenizer_from_a_rank_table(classes, native, tmp_path):
+    """GPT4Tokenizer end to end (gpt4.py:57-130: merge recovery, byte shuffle, ids = ranks) on a
+    toy rank table -- the cl100k_base ranks themselves are not available offline."""
+    import base64
+    base = classes.RegexTokenizer()
+    text = native.synth_text(30_000, 77).decode()
+    base.train(text, 256 + 120)
+    perm, ranks = toy_rank_table(base, 5)
+    path = tmp_path / "toy.tiktoken"
+    with open(path, "wb") as f:
+        for tok, r in sorted(ranks.items(), key=lambda kv: kv[1]):
+            f.write(base64.b64encode(tok) + b" " + str(r).encode() + b"\n")
+    probe = text[:4000] + " don't  stop 12345 ünïcödé 😉"
+    want = [perm[i] if i < 256 else i for i in base.encode_ordinary(probe)]
+    for src in (ranks, str(path)):
+        g = classes.GPT4Tokenizer(src)
+        assert len(g.merges) == 120 and set(g.merges.values()) == set(range(256, 376))
+        assert g.encode_ordinary(probe) == want
+        assert g.decode(want) == probe
+        assert g.decode_batch(want) == probe.encode("utf-8")
+        ids = g.encode("<|endoftext|>" + probe[:200], allowed_special="all")
+        assert ids[0] == 100257 and ids[1:] == g.encode_ordinary(probe[:200])
+        with pytest.raises(KeyError):  # gpt4.py:89 looks ids up in vocab only: specials do not decode
+            g.decode([100257])
+        with pytest.raises(KeyError):
+            g.decode_batch([100257])
+        with pytest.raises(NotImplementedError):
+            g.train("x", 300)
+    with pytest.raises(ImportError):
+        classes.GPT4Tokenizer()  # no tiktoken in this environment
