@@ -38,3 +38,37 @@ def test_reference_test_module_passes_against_this_package(native, monkeypatch, 
         ref.test_save_load(specials)
         ran += 1
     assert ran == 12 and os.listdir(tmp_path) == []
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_saved_files_are_byte_identical_to_the_reference(native, monkeypatch, tmp_path):
+    """train.py's flow (train, register specials, save) on a slice of the reference's own sample
+    text: the .model and .vocab files written by this package and by the reference are the same bytes."""
+    import minbpe_amd.tokenizer as T
+    from fake_engine import OracleEngine
+    eng = OracleEngine()
+    monkeypatch.setattr(T, "engine", lambda device=None: eng)
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
+    monkeypatch.syspath_prepend(REF)
+    import minbpe as ref
+    text = open(os.path.join(REF, "tests", "taylorswift.txt"), encoding="utf-8").read()[:40_000]
+    text += "\x00\x07 control ​ chars � and a lone \x80 byte".encode("utf-8", "surrogatepass").decode("utf-8", "replace")
+    for name, ours, theirs in (("basic", T.BasicTokenizer, ref.BasicTokenizer),
+                               ("regex", T.RegexTokenizer, ref.RegexTokenizer)):
+        a, b = ours(), theirs()
+        a.train(text, 256 + 80)
+        b.train(text, 256 + 80)
+        assert a.merges == b.merges and a.vocab == b.vocab
+        if name == "regex":
+            a.register_special_tokens({"<|endoftext|>": 100257, "<|pad|>": 100258})
+            b.register_special_tokens({"<|endoftext|>": 100257, "<|pad|>": 100258})
+        a.save(str(tmp_path / f"ours_{name}"))
+        b.save(str(tmp_path / f"ref_{name}"))
+        for ext in (".model", ".vocab"):
+            assert open(tmp_path / f"ours_{name}{ext}", "rb").read() == open(tmp_path / f"ref_{name}{ext}", "rb").read()
+        # and each side loads the other's file
+        c = ours()
+        c.load(str(tmp_path / f"ref_{name}.model"))
+        assert c.merges == b.merges and c.special_tokens == b.special_tokens and c.pattern == b.pattern
+        probe = text[1000:3000]
+        assert c.encode(probe) == b.encode(probe) and c.decode(c.encode(probe)) == probe
