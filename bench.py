@@ -14,7 +14,7 @@ PCIe-inclusive rate is noted in DESIGN.md, never reported as `value`).
 Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel class,
 timed with hipEvents on the library's own stream during the timed steps;
 `cpu_baseline` is the CPU oracle (a C port of the reference's loop, one thread)
-on the first iterations of the same stream, on this host.
+on the first 50 iterations of the same stream, on this host.
 """
 import argparse
 import json
@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--mode", type=int, default=int(os.environ.get("BPE_MODE", "-1")),
                     help="-1 library default | 0 recount | 1 delta")
-    ap.add_argument("--cpu-iters", type=int, default=4, help="oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=50,
+                    help="oracle iterations for cpu_baseline, ~10 s of one host core at 100 MB (0 = skip); "
+                         "the GPU's first merges are asserted equal to them")
     args = ap.parse_args()
 
     import torch  # device sync + torch.distributed (RCCL) plumbing only
