@@ -2,21 +2,34 @@
 """bench.py -- headline benchmark (BASELINE.json: "BPE merges/sec + pair-count
 GB/s vs HBM roofline").
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME] [--secondary a,b]
 
-Workload (N=1): BASELINE.json configs[1] -- BasicTokenizer.train on 100 MB of
-synthetic UTF-8 (synth_text(100_000_000, seed=1)), vocab 4096 = 3840 merges, one
-MI355X.  A "step" is one complete train() over the stream: widen the resident
-bytes to ids, then 3840 x (pair statistics, arg-max with the reference's
-tie-break, merge).  The bytes are uploaded once, before the timed region (the
-PCIe-inclusive rate is noted in DESIGN.md, never reported as `value`).
+Workloads (one "step" = one complete train() from bytes already resident in HBM:
+widen to ids, initial get_stats, then vocab-256 x (arg-max with the reference's
+tie-break, merge, pair-table update)):
 
-Prints ONE JSON line on rank 0.  `roofline` is the dominant kernel class,
-timed with hipEvents on the library's own stream during the timed steps;
-`cpu_baseline` is the CPU oracle (a C port of the reference's loop, one thread)
-on the first 50 iterations of the same stream, on this host.
+  regex1g  (default, N=1)  BASELINE.json configs[2]: RegexTokenizer.train with the
+           GPT-4 split pattern (regex.py:19,41) on 1 GB of synthetic UTF-8
+           (synth_text(1e9, seed 2)), vocab 32000 = 31,744 merges, no chunk
+           de-duplication.  The split runs on the host (bpe_split) before the clock.
+  basic1g  the north_star target sentence: BasicTokenizer.train, same 1 GB, vocab 32000.
+  cfg2     BASELINE.json configs[1]: BasicTokenizer.train, 100 MB (seed 1), vocab 4096.
+  encode   BASELINE.json configs[4] shape: batch encode of documents (own vocabulary).
+
+The headline workload is timed for --steps; the --secondary workloads (default
+basic1g,cfg2 at N=1) run --secondary-steps each after it and are reported under
+"secondary".  N > 1: the chunk list of regex1g is sharded (contiguous chunk ranges,
+--bytes per GPU = cfg4 shape, weak scaling); `value` is the rate of the ONE sharded job.
+
+Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel class timed with
+hipEvents on the library's own stream inside the timed steps; `cpu_baseline` = the CPU
+oracle (C restatement of the reference loop, one thread) on a bounded slice of the same
+input, on this host, plus the unmodified Python reference when /root/reference exists.
+Parity with the oracle is CHECKED in the run against committed full-length digests
+(tests/golden/big_golden.json) and reported, never assumed.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,9 +37,318 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
 HBM_COPY_GBPS = 6290.0  # measured float4 copy, same guide
+
+WORKLOADS = {
+    "regex1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=True,
+                    desc="RegexTokenizer.train (GPT-4 split pattern, no de-duplication)"),
+    "basic1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=False, desc="BasicTokenizer.train"),
+    "cfg2": dict(bytes=100_000_000, seed=1, vocab=4096, chunked=False, desc="BasicTokenizer.train"),
+}
+
+
+def source_hash():
+    """sha256 over the device/host sources of libbpe_hip.so: identifies the kernels a
+    committed PMC profile was measured on."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "minbpe_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".h", ".cpp")):
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def host_info():
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def golden_entry(name):
+    p = os.path.join(ROOT, "tests", "golden", "big_golden.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f).get(name)
+
+
+def parity_report(name, wl, data_sha, offs, res):
+    """Compare the GPU result with the committed oracle digests of this exact input."""
+    from helpers import checkpoint_digests, first_divergence
+    g = golden_entry(name)
+    rep = {"golden": None, "merges_checked": 0, "equal": None}
+    if not g or g["bytes"] != wl["bytes"] or g["seed"] != wl["seed"] or g["data_sha256"] != data_sha:
+        return rep
+    rep["golden"] = f"tests/golden/big_golden.json[{name}] (oracle, {g['done']} merges)"
+    if g.get("offsets_sha256") and offs is not None:
+        rep["split_equals_regex_module"] = hashlib.sha256(offs.tobytes()).hexdigest() == g["offsets_sha256"]
+    k = min(g["done"], len(res["pairs"]))
+    got = checkpoint_digests(res["pairs"][:k], res["counts"][:k], res["lens"][:k], g["step"])
+    bad = first_divergence(got, g["digests"])
+    checked = [c for c, _ in got if c in {c2 for c2, _ in g["digests"]}]
+    rep["merges_checked"] = max(checked) if checked else 0
+    rep["equal"] = bool(checked) and bad is None
+    if bad is not None:
+        rep["first_bad_checkpoint"] = bad
+    return rep
+
+
+def invariants(res, n0):
+    """Size-independent checks at full length: every a != b merge removes exactly `count` ids;
+    an a == b merge removes between ceil(count/2)... and count; counts never increase."""
+    import numpy as np
+    lens = np.array([n0] + res["lens"], dtype=np.int64)
+    cnt = np.array(res["counts"], dtype=np.int64)
+    pairs = np.array(res["pairs"], dtype=np.int64).reshape(-1, 2)
+    same = pairs[:, 0] == pairs[:, 1]
+    removed = lens[:-1] - lens[1:]
+    ok = bool(np.all(removed[~same] == cnt[~same]) and np.all(removed[same] <= cnt[same])
+              and np.all(removed > 0) and np.all(np.diff(cnt) <= 0))
+    return {"len_drop_equals_count_and_counts_monotone": ok, "merges": int(len(cnt))}
+
+
+_INPUT_CACHE = {}
+
+
+def synth_cached(n, seed):
+    """synth_text is a sequential generator (~30 MB/s): keep the last stream in memory and, for
+    streams of 100 MB and more, on local disk, so that several workloads / tools of one session
+    do not regenerate it."""
+    import minbpe_amd
+    if (n, seed) in _INPUT_CACHE:
+        return _INPUT_CACHE[(n, seed)]
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"minbpe_synth_{n}_{seed}.bin")
+    data = None
+    if n >= 100_000_000 and os.path.exists(path) and os.path.getsize(path) == n:
+        with open(path, "rb") as f:
+            data = f.read()
+    if data is None:
+        data = minbpe_amd.synth_text(n, seed)
+        if n >= 100_000_000:
+            try:
+                with open(path + ".tmp", "wb") as f:
+                    f.write(data)
+                os.replace(path + ".tmp", path)
+            except OSError:
+                pass
+    _INPUT_CACHE.clear()
+    _INPUT_CACHE[(n, seed)] = data
+    return data
+
+
+def make_input(wl, rank=0):
+    from minbpe_amd import _native
+    t0 = time.perf_counter()
+    data = synth_cached(wl["bytes"], wl["seed"] + rank)
+    offs = _native.split_offsets(data, 4) if wl["chunked"] else None
+    return data, offs, time.perf_counter() - t0
+
+
+def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
+    """Upload once, warm up, one untimed step with events around every kernel class (the
+    breakdown), then `steps` timed steps with events around the merge pass only."""
+    data, offs, prep_s = make_input(wl)
+    data_sha = hashlib.sha256(data).hexdigest()
+    num_merges = wl["vocab"] - 256
+    if mode >= 0:
+        eng.set_option("mode", mode)
+    t0 = time.perf_counter()
+    eng.load_bytes(data, offs)  # H2D once, outside the timed region
+    upload_s = time.perf_counter() - t0
+    step = lambda: eng.train(num_merges)
+    for _ in range(warmup):
+        step()
+    eng.set_option("profile", 2)
+    eng.prof_reset()
+    step()
+    breakdown = eng.prof_read()
+    eng.set_option("profile", 1)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    barrier()
+    dt = reduce_max(time.perf_counter() - t0)
+    prof = eng.prof_read()
+    eng.set_option("profile", 0)
+    out = {
+        "workload": f"{wl['desc']}, {wl['bytes']} B synthetic UTF-8 (seed {wl['seed']}), vocab {wl['vocab']} "
+                    f"({num_merges} merges)" + (f", {len(offs)} chunks" if offs is not None else ""),
+        "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+        "merges_per_s": round(num_merges * steps / dt, 2),
+        "host_prep_s": round(prep_s, 2), "upload_s": round(upload_s, 3),
+        "pcie_inclusive_merges_per_s": round(num_merges / (dt / steps + upload_s), 2),
+        "final_len": res["lens"][-1] if res["lens"] else len(data),
+        "parity": parity_report(name, wl, data_sha, offs, res),
+        "invariants": invariants(res, len(data)),
+    }
+    # dominant kernel class by device time -> roofline (timed live in the timed region)
+    hot = max(("pair_count", "merge", "widen"), key=lambda k: breakdown[k]["ms"])
+    hp = prof[hot] if prof[hot]["launches"] else breakdown[hot]
+    achieved = hp["alg_bytes"] / (hp["ms"] * 1e-3) / 1e9 if hp["ms"] > 0 else 0.0
+    launches = max(hp["launches"], 1)
+    roofline = {
+        "bound": "hbm",
+        "kernel": {"merge": "merge pass (k_merge_*: merge + pair-table delta)", "pair_count": "k_pair_count",
+                   "widen": "k_widen"}[hot],
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 4),
+        "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
+        "traffic": None, "frac_physical": None, "traffic_source": None,
+        "launches": hp["launches"], "avg_launch_ms": round(hp["ms"] / launches, 5),
+        "alg_bytes_per_launch": hp["alg_bytes"] // launches,
+        "note": "achieved/frac = ALGORITHMIC bytes (SURVEY 8d: 4(2N_i + N_{i+1}) per merge: what the reference's "
+                "get_stats + merge touch) / hipEvent time of the merge pass; frac_physical = HBM bytes actually "
+                "moved (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of the same command, committed profile) / the same "
+                "time / 8 TB/s.  The pass does not re-read the stream for get_stats and skips slots a merge "
+                "cannot touch, so the algorithmic figure exceeds the physical one (and may exceed 1).",
+    }
+    # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the
+    # committed rocprofv3 --pmc passes of this same command, and only if they were measured on the
+    # same library sources (hash below).
+    pmc_file = os.path.join(ROOT, "profiles", f"r2_{name}_pmc.json")
+    if hot == "merge" and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pmc = json.load(f)
+        if pmc.get("source_hash") == source_hash() and pmc.get("launches"):
+            per = pmc["hbm_bytes_total"] / pmc["launches"]
+            roofline["traffic"] = int(per)
+            roofline["traffic_source"] = f"profiles/r2_{name}_pmc.json (source_hash {pmc['source_hash']})"
+            roofline["frac_physical"] = round(per / (hp["ms"] / launches * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        else:
+            roofline["traffic_source"] = "committed PMC profile is from other library sources: not attached"
+    out["roofline"] = roofline
+    pc, mg = breakdown["pair_count"], breakdown["merge"]
+    alg_bytes_step = pc["alg_bytes"] + mg["alg_bytes"]
+    out["pair_count_GBps"] = round(pc["alg_bytes"] / (pc["ms"] * 1e-3) / 1e9, 1) if pc["ms"] else None
+    out["merge_GBps"] = round(mg["alg_bytes"] / (mg["ms"] * 1e-3) / 1e9, 1) if mg["ms"] else None
+    out["iter_GBps_wall"] = round(alg_bytes_step * steps / dt / 1e9, 1)
+    out["device_ms_per_step"] = {k: round(v["ms"], 3) for k, v in breakdown.items() if v["ms"]}
+    return out, data, offs, res
+
+
+def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters):
+    """The oracle (C port of the reference loop, one thread) on the first `cpu_bytes` of the same input
+    for `cpu_iters` iterations; the rate is scaled linearly in N to the full size (the reference loop is
+    O(N) per merge).  Also the unmodified Python reference on a smaller slice when it is importable."""
+    import numpy as np
+    import oracle
+    nb = min(cpu_bytes, len(data))
+    if offs is not None:
+        k = int(np.searchsorted(offs, nb, side="right")) - 1
+        nb = int(offs[k]) if nb < len(data) else nb
+        so = offs[:k] if nb < len(data) else offs
+    else:
+        while nb < len(data) and (data[nb] & 0xC0) == 0x80:
+            nb -= 1
+        so = None
+    sample = data[:nb]
+    t0 = time.perf_counter()
+    cp, _, _ = oracle.train(sample, cpu_iters, so)
+    ct = time.perf_counter() - t0
+    rate = cpu_iters / ct
+    scale = nb / len(data)
+    out = {
+        "value": round(rate * scale, 4), "unit": "merges/s", "cores": 1, "kind": "port",
+        "sample": f"oracle/bpe_oracle.c (get_stats + max + merge, one thread): first {cpu_iters} merges of the "
+                  f"first {nb} bytes of the same input in {ct:.1f} s = {rate:.2f} merges/s, scaled by "
+                  f"{scale:.3f} (O(N) per merge) to the full {len(data)} bytes",
+        "sample_merges_per_s": round(rate, 3), **host_info(),
+    }
+    if nb == len(data):
+        out["gpu_first_merges_equal"] = bool(cp == res["pairs"][:cpu_iters])
+    # the unmodified reference (train.py:20-31 style loop) exists only in the build container
+    if os.path.isdir("/root/reference/minbpe"):
+        try:
+            import types
+            sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+            sys.path.insert(0, "/root/reference")
+            from minbpe.base import get_stats, merge
+            py_n = min(4_000_000, nb)
+            ids = list(sample[:py_n])
+            t0 = time.perf_counter()
+            K = 3
+            for i in range(K):
+                stats = get_stats(ids)
+                pair = max(stats, key=stats.get)
+                ids = merge(ids, pair, 256 + i)
+            pt = (time.perf_counter() - t0) / K
+            out["python_reference"] = {
+                "s_per_merge_on_sample": round(pt, 3), "sample_bytes": py_n,
+                "extrapolated_merges_per_s_full_size": round(1.0 / (pt * len(data) / py_n), 6),
+                "note": "minbpe.base.get_stats + max + merge, unmodified, one thread, as one stream "
+                        "(BasicTokenizer-style), linear extrapolation in N"}
+        except Exception as e:  # the bench line must still come out
+            out["python_reference"] = f"not timed: {type(e).__name__}: {e}"
+    else:
+        out["python_reference"] = ("not timed: /root/reference is absent on this host (pure-Python reference "
+                                   "cannot travel; see BASELINE.md for its timing in the build container)")
+    return out
+
+
+def run_encode_workload(eng, steps, warmup, barrier):
+    """configs[4] shape: batch encode of documents with an own vocabulary (cl100k ranks are
+    not available offline).  Device-only and PCIe-inclusive rates; cpu_baseline = oracle.encode."""
+    import numpy as np
+    import minbpe_amd
+    from minbpe_amd import _native
+    import oracle
+    train_bytes, vocab = 50_000_000, 16384
+    tdata = minbpe_amd.synth_text(train_bytes, 4)
+    toffs = _native.split_offsets(tdata, 4)
+    eng.load_bytes(tdata, toffs)
+    pairs = eng.train(vocab - 256)["pairs"]
+    data = minbpe_amd.synth_text(600_000_000, 5)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    nl = np.flatnonzero((arr[:-1] == 10) & (arr[1:] == 10)).astype(np.uint64) + 2
+    doc_offs = np.unique(np.concatenate([np.zeros(1, np.uint64), nl[nl < len(data)]]))
+    offs, _first = _native.split_docs(data, doc_offs, 4)
+    n_docs = len(doc_offs)
+    for _ in range(warmup):
+        eng.encode_batch(pairs, None, data, offs)
+    eng.set_option("profile", 2)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids, out_offs = eng.encode_batch(pairs, None, data, offs)
+    barrier()
+    dt = (time.perf_counter() - t0) / steps
+    prof = eng.prof_read()["encode"]
+    eng.set_option("profile", 0)
+    dev_s = prof["ms"] * 1e-3 / max(steps, 1)
+    nb = 2_000_000
+    k = int(np.searchsorted(offs, nb, side="right")) - 1
+    nb = int(offs[k])
+    t0 = time.perf_counter()
+    oid, _ = oracle.encode(pairs, data[:nb], offs[:k])
+    ct = time.perf_counter() - t0
+    tok_k = int(out_offs[k])
+    return {
+        "workload": f"batch encode, {n_docs} documents / {len(data)} B synthetic UTF-8 / {len(offs)} GPT-4-split "
+                    f"chunks, own vocabulary of {vocab} trained on {train_bytes} B",
+        "docs_per_s_device": round(n_docs / dev_s, 1) if dev_s else None,
+        "tokens_per_s_device": round(len(ids) / dev_s, 1) if dev_s else None,
+        "text_GBps_device": round(len(data) / dev_s / 1e9, 2) if dev_s else None,
+        "docs_per_s_pcie_inclusive": round(n_docs / dt, 1), "tokens_per_s_pcie_inclusive": round(len(ids) / dt, 1),
+        "ms_per_step": round(dt * 1e3, 2), "device_ms_per_step": round(dev_s * 1e3, 2), "tokens": int(len(ids)),
+        "parity": {"first_bytes_checked": nb, "equal_oracle": bool(np.array_equal(oid, ids[:tok_k]))},
+        "cpu_baseline": {"value": round(nb / ct, 1), "unit": "bytes/s", "cores": 1, "kind": "port",
+                         "sample": f"oracle.encode on the first {nb} bytes", **host_info()},
+    }
 
 
 def main():
@@ -34,14 +356,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bytes", type=int, default=100_000_000, help="stream size per GPU")
-    ap.add_argument("--vocab", type=int, default=4096)
-    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--workload", default=None, help="regex1g (default) | basic1g | cfg2 | encode")
+    ap.add_argument("--secondary", default=None,
+                    help="comma list of further workloads reported under 'secondary' (default at N=1 with the "
+                         "default headline: basic1g,cfg2; 'none' to skip)")
+    ap.add_argument("--secondary-steps", type=int, default=1)
+    ap.add_argument("--bytes", type=int, default=None, help="override the workload's stream size (per GPU)")
+    ap.add_argument("--vocab", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--mode", type=int, default=int(os.environ.get("BPE_MODE", "-1")),
-                    help="-1 library default | 0 recount | 1 delta")
-    ap.add_argument("--cpu-iters", type=int, default=50,
-                    help="oracle iterations for cpu_baseline, ~10 s of one host core at 100 MB (0 = skip); "
-                         "whether the GPU's first merges equal them is reported")
+                    help="-1 library default | 0 recount (the literal get_stats-every-iteration loop) | 1 delta")
+    ap.add_argument("--cpu-iters", type=int, default=40, help="oracle iterations for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-bytes", type=int, default=100_000_000, help="slice of the input the oracle is timed on")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (experiments)")
     args = ap.parse_args()
 
     import torch  # device sync + torch.distributed (RCCL) plumbing only
@@ -54,7 +381,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     force_dp = os.environ.get("BENCH_FORCE_DP") == "1"  # exercise the sharded path on one GPU
-    if world > 1 or force_dp:
+    sharded = world > 1 or force_dp
+    if sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -62,34 +390,83 @@ def main():
     import minbpe_amd
     from minbpe_amd import Engine
 
-    num_merges = args.vocab - 256
+    name = args.workload or "regex1g"
     eng = Engine(local_rank)
-    if args.mode >= 0:
-        eng.set_option("mode", args.mode)
-    if "BPE_MERGE" in os.environ:  # experiments: 0 three-pass | 1 single-pass look-back
-        eng.set_option("merge", int(os.environ["BPE_MERGE"]))
-    if world == 1 and not force_dp:
-        # configs[1]: BasicTokenizer.train, one unchunked stream, one GPU
-        data = minbpe_amd.synth_text(args.bytes, args.seed)
-        eng.load_bytes(data)  # H2D once, outside the timed region
-        step = lambda: eng.train(num_merges)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+
+    def barrier():
+        if sharded:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(dt):
+        if not sharded:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    line = {"metric": "BPE merges/sec", "unit": "merges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic", "library": minbpe_amd.version(), "source_hash": source_hash()}
+
+    if name == "encode":
+        r = run_encode_workload(eng, args.steps, args.warmup, barrier)
+        line.update({"metric": "batch encode docs/sec", "unit": "docs/s", "value": r["docs_per_s_device"],
+                     "ms_per_step": r["device_ms_per_step"], "config": {"workload": r["workload"]},
+                     "roofline": None, "cpu_baseline": r.pop("cpu_baseline"), "encode": r})
+        print(json.dumps(line))
+        eng.close()
+        return
+
+    wl = dict(WORKLOADS[name])
+    for k in ("bytes", "vocab", "seed"):
+        if getattr(args, k) is not None:
+            wl[k] = getattr(args, k)
+
+    if not sharded:
+        r, data, offs, res = run_train_workload(name, wl, eng, args.steps, args.warmup, barrier, reduce_max, args.mode)
+        cpu = None
+        if args.cpu_iters > 0:
+            cpu = cpu_baseline(wl, data, offs, res, args.cpu_bytes, args.cpu_iters)
+        par = r["parity"]
+        line.update({
+            "value": r["merges_per_s"], "ms_per_step": r["ms_per_step"],
+            "config": {"workload": r["workload"] + "; " + (
+                           f"first {par['merges_checked']} merges equal the oracle's committed digests: {par['equal']}"
+                           if par["golden"] else "no committed oracle digest for this input") +
+                       f"; full-length invariants hold: {r['invariants']['len_drop_equals_count_and_counts_monotone']}",
+                       "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
+                       "parallelism": "single"},
+            "roofline": r.pop("roofline"), "cpu_baseline": cpu,
+        })
+        line.update({k: v for k, v in r.items() if k not in ("workload", "merges_per_s", "ms_per_step", "steps")})
+        del data, offs, res
+        sec = args.secondary
+        if sec is None:
+            sec = "basic1g,cfg2" if (args.workload is None and args.bytes is None and args.vocab is None) else "none"
+        secondary = {}
+        for sname in [s for s in sec.split(",") if s and s != "none"]:
+            try:
+                sr, _d, _o, _r = run_train_workload(sname, dict(WORKLOADS[sname]), eng, args.secondary_steps, 0,
+                                                    barrier, reduce_max, args.mode)
+                del _d, _o, _r
+                secondary[sname] = sr
+            except Exception as e:  # the headline line must still come out
+                secondary[sname] = f"failed: {type(e).__name__}: {e}"
+        line["secondary"] = secondary
     else:
-        # BasicTokenizer's single stream does not shard; N > 1 runs the
-        # chunked (RegexTokenizer-style) training sharded by chunks, `bytes` per GPU
-        # (weak scaling), with the two per-merge all-reduces over RCCL.  Chunks are
-        # cut before every space/newline (a vectorised stand-in for the regex split,
-        # which runs at 5 MB/s on the host and is not part of the timed path).
+        # BasicTokenizer's single stream does not shard; N > 1 runs the chunked
+        # (RegexTokenizer) training sharded by chunks: every rank generates and splits its own
+        # `bytes` of text (weak scaling, cfg4 shape), the two per-merge all-reduces go over RCCL.
+        from minbpe_amd.dist import GpuShard, TorchComm, train_sharded, init_native_comm
         import numpy as np
-        from minbpe_amd.dist import GpuShard, TorchComm, train_sharded
-        data = minbpe_amd.synth_text(args.bytes, args.seed + rank)
-        arr = np.frombuffer(data, dtype=np.uint8)
-        cut = np.flatnonzero((arr == 32) | (arr == 10)).astype(np.uint64)
-        offs = np.unique(np.concatenate([np.zeros(1, np.uint64), cut]))
+        num_merges = wl["vocab"] - 256
+        data, offs, _ = make_input(wl, rank)
         eng.load_bytes(data, offs)
-        from minbpe_amd.dist import init_native_comm
         comm = TorchComm()
-        # default: the library issues its own RCCL all-reduces (bpe_dp_train); BPE_DIST=torch, or a
-        # failed communicator set-up on any rank, falls back to the torch.distributed driver
         dist_path = "torch.distributed"
         if os.environ.get("BPE_DIST", "native") == "native" and init_native_comm(eng, comm):
             dist_path = "librccl (in-library loop)"
@@ -97,39 +474,14 @@ def main():
         else:
             shard = GpuShard(eng, local_rank)
             step = lambda: train_sharded(shard, comm, num_merges)
-
-    def barrier():
-        if world > 1 or force_dp:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    # one untimed step with events around every kernel class: the breakdown
-    eng.set_option("profile", 2)
-    eng.prof_reset()
-    step()
-    breakdown = eng.prof_read()
-    # timed steps: events only around the dominant kernel (two records per iteration)
-    eng.set_option("profile", 1)
-    eng.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = eng.prof_read()
-    if world > 1 or force_dp:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # N > 1: the ranks must agree, and the sharded result must be the single-GPU result on the
-    # concatenation of all shards (rank 0 re-trains it unsharded, outside the timed region).
-    dp_check = None
-    if world > 1 or force_dp:
-        import hashlib
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        barrier()
+        dt = reduce_max(time.perf_counter() - t0)
         digest = int.from_bytes(hashlib.sha256(repr((res["pairs"], res["counts"], res["lens"])).encode())
                                 .digest()[:7], "big")
         lo = torch.tensor([digest], dtype=torch.int64, device="cuda")
@@ -137,14 +489,11 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dp_check = {"ranks_agree": bool(lo.item() == hi.item()), "equals_single_gpu": None}
-        if rank == 0 and os.environ.get("BENCH_DP_CHECK", "1") == "1":
-            try:
+        if rank == 0 and os.environ.get("BENCH_DP_CHECK", "1") == "1" and wl["bytes"] * world <= 2_000_000_000:
+            try:  # the sharded result must be the single-GPU result on the concatenation of all shards
                 parts, offl, base = [], [], 0
-                for r in range(world):
-                    d = minbpe_amd.synth_text(args.bytes, args.seed + r)
-                    a = np.frombuffer(d, dtype=np.uint8)
-                    cuts = np.flatnonzero((a == 32) | (a == 10)).astype(np.uint64)
-                    o = np.unique(np.concatenate([np.zeros(1, np.uint64), cuts]))
+                for r_ in range(world):
+                    d, o, _ = make_input(wl, r_)
                     parts.append(d)
                     offl.append(o + np.uint64(base))
                     base += len(d)
@@ -155,91 +504,23 @@ def main():
                 dp_check["equals_single_gpu"] = bool(
                     single["pairs"] == res["pairs"] and single["counts"] == res["counts"]
                     and single["lens"] == res["lens"])
-            except Exception as e:  # the bench line must still come out
+            except Exception as e:
                 dp_check["equals_single_gpu"] = f"not checked: {type(e).__name__}: {e}"
-
-    # Weak scaling: every rank runs num_merges merge passes over its own `bytes`.  The whole-job
-    # aggregate is therefore merge passes summed over ranks (= merges/s at N=1); the plain rate of
-    # the one sharded job is reported next to it as job_merges_per_s.
-    merges_total = num_merges * args.steps * world
-    value = merges_total / dt
-    job_merges_per_s = num_merges * args.steps / dt
-
-    # dominant kernel class by device time -> roofline (timed live in the timed region)
-    hot = max(("pair_count", "merge", "widen"), key=lambda k: breakdown[k]["ms"])
-    hp = prof[hot] if prof[hot]["launches"] else breakdown[hot]
-    achieved = hp["alg_bytes"] / (hp["ms"] * 1e-3) / 1e9 if hp["ms"] > 0 else 0.0
-    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this
-    # process; they come from the committed rocprofv3 --pmc passes of this same command
-    # (profiles/, FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950).
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r1_final_cfg2_pmc_merge_slot.json")
-    if (hot == "merge" and world == 1 and not force_dp and args.bytes == 100_000_000 and args.vocab == 4096
-            and args.mode < 0 and "BPE_MERGE" not in os.environ and os.path.exists(pmc_file)):
-        with open(pmc_file) as f:
-            traffic = int(json.load(f)["hbm_bytes_per_launch"])
-        traffic_src = "profiles/r1_final_cfg2_pmc_merge_slot.json"
-    roofline = {
-        "bound": "hbm", "kernel": {"merge": "k_merge_slot (merge + pair-table delta)",
-                                   "pair_count": "k_pair_count", "widen": "k_widen"}[hot],
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-        "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),  # vs the 6.29 TB/s float4 copy
-        "traffic": traffic,
-        "traffic_source": traffic_src,
-        "launches": hp["launches"], "avg_launch_ms": round(hp["ms"] / max(hp["launches"], 1), 5),
-        "alg_bytes_per_launch": hp["alg_bytes"] // max(hp["launches"], 1),
-        "note": "achieved = algorithmic bytes (4 B per id read or written by get_stats+merge, "
-                "SURVEY 8d) / hipEvent time; traffic = measured HBM bytes per launch",
-    }
-    # the two figures the metric names, over the whole timed region
-    pc, mg = breakdown["pair_count"], breakdown["merge"]
-    alg_bytes_step = pc["alg_bytes"] + mg["alg_bytes"]  # sum of B_i = 4(2N_i + N_{i+1})
-    extra = {
-        "pair_count_GBps": round(pc["alg_bytes"] / (pc["ms"] * 1e-3) / 1e9, 1) if pc["ms"] else None,
-        "merge_GBps": round(mg["alg_bytes"] / (mg["ms"] * 1e-3) / 1e9, 1) if mg["ms"] else None,
-        # whole-iteration algorithmic rate, wall clock of the timed region (includes every small kernel and gap)
-        "iter_GBps_wall": round(alg_bytes_step * args.steps / dt / 1e9, 1),
-        "device_ms_per_step": {k: round(v["ms"], 3) for k, v in breakdown.items()},
-        "final_len": res["lens"][-1] if res["lens"] else len(data),
-    }
-
-    cpu_baseline = None
-    if rank == 0 and args.cpu_iters > 0 and world == 1 and not force_dp:
-        import oracle
-        t0 = time.perf_counter()
-        cp, _, _ = oracle.train(data, args.cpu_iters)
-        ct = time.perf_counter() - t0
-        cpu_baseline = {
-            "value": round(args.cpu_iters / ct, 4), "unit": "merges/s", "cores": 1, "kind": "port",
-            # parity at the bench's full size, reported rather than asserted so that the line always comes out
-            "gpu_first_merges_equal": bool(cp == res["pairs"][:args.cpu_iters]),
-            "sample": f"first {args.cpu_iters} iterations (get_stats+max+merge) of the same "
-                      f"{args.bytes}-byte stream, oracle/bpe_oracle.c, single thread",
-        }
+        line.update({
+            "value": round(num_merges * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "config": {"workload": f"{wl['desc']} sharded over {world} GPUs by contiguous chunk ranges, "
+                                   f"{wl['bytes']} B synthetic UTF-8 per GPU (seed {wl['seed']}+rank), vocab "
+                                   f"{wl['vocab']} ({num_merges} merges); ranks agree: {dp_check['ranks_agree']}",
+                       "parallelism": f"dp{world} (per-merge all-reduce of tie key + table deltas; "
+                                      f"collectives via {dist_path})"},
+            "value_definition": "merges per second of the ONE sharded job (not summed over ranks)",
+            "sharded_check": dp_check, "roofline": None, "cpu_baseline": None,
+        })
 
     if rank == 0:
-        print(json.dumps({
-            "metric": "BPE merges/sec", "value": round(value, 2), "unit": "merges/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": (f"BasicTokenizer.train, {args.bytes} B synthetic UTF-8, " if world == 1 else
-                                    f"chunked (RegexTokenizer-style) train sharded over {world} GPUs, "
-                                    f"{args.bytes} B synthetic UTF-8 per GPU, ") +
-                                   f"vocab {args.vocab} ({num_merges} merges), bit-exact vs oracle",
-                       "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
-                       "parallelism": f"dp{world} (chunk shards; per-merge all-reduce of tie key + table deltas; "
-                                                      f"collectives via {dist_path})"
-                                      if (world > 1 or force_dp) else "single"},
-            "job_merges_per_s": round(job_merges_per_s, 2),
-            "value_definition": "merge passes per second summed over GPUs (each rank merges its own shard); "
-                                "equals job_merges_per_s x n_gpus",
-            "sharded_check": dp_check,
-            "roofline": roofline, "cpu_baseline": cpu_baseline, **extra,
-        }))
+        print(json.dumps(line))
     eng.close()
-    if world > 1 or force_dp:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -112,14 +112,18 @@ int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
  *   bpe_dp_table_ready()
  *   for i in range(num_merges):
  *       bpe_dp_select(i)                     arg-max on the replica; local tie-break candidate
- *       [all-reduce MIN   tiekey  (int64 x 2)]   lowest (rank, position) wins the tie (F3/F5)
+ *       [all-reduce MIN   tiekey  (int64 x 3)]   lowest (rank, position) wins the tie (F3/F5);
+ *                                               word 2 = -(device status): any rank's failure stops all
  *       bpe_dp_merge(i)                      merge locally, produce the 4 delta vectors
  *       [all-reduce SUM   delta   (int32 x delta_count)]
  *       bpe_dp_apply(i)                      fold them into the replica
  *   bpe_dp_poll(i, ...) any time after bpe_dp_merge(i): the iteration's record
  *   bpe_dp_end()
  * All calls only enqueue work on the ctx's stream (bpe_set_stream) except
- * bpe_dp_poll, which waits for the device to report iteration i. */
+ * bpe_dp_poll, which waits for the device to report iteration i.
+ * EVERY rank must issue this same schedule for every i in [0, num_merges), also after one of
+ * its own polls reported a failure: the remaining iterations are no-ops on the device, and a
+ * rank that stopped issuing collectives would leave its peers blocked in theirs. */
 int bpe_dp_begin(bpe_ctx *ctx, int32_t num_merges, int32_t rank, int32_t nranks);
 int bpe_dp_buffers(bpe_ctx *ctx, void **table, uint64_t *table_count, void **delta,
                    uint64_t *delta_count, void **tiekey);
@@ -134,6 +138,10 @@ int bpe_dp_end(bpe_ctx *ctx);
  * dlopen'ed): rank 0 makes a 128-byte id (bpe_comm_unique_id), the application
  * broadcasts it by whatever means it has, every rank calls bpe_comm_init, then
  * bpe_dp_train.  Identical results on every rank; len_out holds GLOBAL lengths. */
+/* 1 if librccl could be loaded in this process (ranks should agree on this, e.g. with a MIN
+ * all-reduce over their bootstrap transport, BEFORE any of them enters bpe_comm_init: a rank
+ * without the library would leave the others blocked in ncclCommInitRank). */
+int bpe_comm_available(void);
 int bpe_comm_unique_id(uint8_t *out128);
 int bpe_comm_init(bpe_ctx *ctx, int32_t rank, int32_t nranks, const uint8_t *id128);
 int bpe_comm_destroy(bpe_ctx *ctx);

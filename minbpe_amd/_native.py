@@ -81,6 +81,7 @@ _SIGS = {
     "bpe_dp_poll": (C.c_int, [_p, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64),
                               C.POINTER(_u64), C.POINTER(_i32)]),
     "bpe_dp_end": (C.c_int, [_p]),
+    "bpe_comm_available": (C.c_int, []),
     "bpe_comm_unique_id": (C.c_int, [_p]),
     "bpe_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
     "bpe_comm_destroy": (C.c_int, [_p]),
@@ -360,6 +361,11 @@ class Engine:
         self._check(_lib.bpe_dp_end(self._h))
 
     # -- RCCL called from inside the library ---------------------------------------------
+    @staticmethod
+    def comm_available() -> bool:
+        """librccl can be loaded in this process (bpe_comm_available)."""
+        return bool(_lib.bpe_comm_available())
+
     @staticmethod
     def comm_unique_id() -> bytes:
         buf = np.zeros(128, np.uint8)

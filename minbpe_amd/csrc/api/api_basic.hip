@@ -106,9 +106,26 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     return BPE_OK;
 }
 
+// chunk start offsets as the header states them: ascending (equal neighbours = an empty chunk),
+// none beyond n.  Every entry point that takes offsets checks them: the kernels compute chunk
+// lengths as differences and would index out of bounds on a descending pair.
+static int check_offsets(bpe_ctx *c, const uint64_t *chunk_offsets, uint64_t n_chunks, uint64_t n) {
+    if (!chunk_offsets) return BPE_OK;
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < n_chunks; i++) {
+        const uint64_t o = chunk_offsets[i];
+        if (o < prev || o > n)
+            return fail(c, BPE_E_ARG, "chunk_offsets[%llu] = %llu: offsets must ascend and stay <= n = %llu",
+                        (unsigned long long)i, (unsigned long long)o, (unsigned long long)n);
+        prev = o;
+    }
+    return BPE_OK;
+}
+
 static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
                            uint64_t n_chunks, const uint8_t *wexp) {
     if (!c || (!bytes && n)) return fail(c, BPE_E_ARG, "bytes is NULL");
+    TRY(check_offsets(c, chunk_offsets, n_chunks, n));
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream of %llu bytes exceeds 2^32-1 per GPU",
                                        (unsigned long long)n);
     if (wexp && !chunk_offsets) return fail(c, BPE_E_ARG, "weights need chunk offsets");
@@ -175,6 +192,7 @@ int bpe_load_ids(bpe_ctx *c, const int32_t *ids, uint64_t n, const uint64_t *chu
                  uint64_t n_chunks) {
     if (!c || (!ids && n)) return fail(c, BPE_E_ARG, "ids is NULL");
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "stream too long");
+    TRY(check_offsets(c, chunk_offsets, n_chunks, n));
     HIPCHK(c, hipSetDevice(c->device));
     int32_t mx = 255;
     for (uint64_t i = 0; i < n; i++) {

@@ -20,7 +20,7 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     c->d_dp_folded = nullptr;
     HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, (size_t)c->vcap * 4 * sizeof(uint32_t)));
     if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
-    if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 2 * sizeof(long long)));
+    if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 3 * sizeof(long long)));
     TRY(start_from_bytes(c));
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
     TRY(launch_pair_count(c, false));

@@ -25,6 +25,7 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
                                 uint64_t *n_out) {
     if (!c || M < 0 || (!merges && M) || (!bytes && n)) return fail(c, BPE_E_ARG, "bad arguments");
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "batch of %llu bytes exceeds 2^32-1", (unsigned long long)n);
+    TRY(check_offsets(c, chunk_offsets, n_chunks, n));
     static const uint64_t zero = 0;
     if (!chunk_offsets) {
         chunk_offsets = &zero;

@@ -47,6 +47,8 @@ RcclApi *rccl() {
     } while (0)
 }  // namespace
 
+extern "C" int bpe_comm_available(void) { return rccl() ? 1 : 0; }
+
 extern "C" int bpe_comm_unique_id(uint8_t *out128) {
     if (!out128) return BPE_E_ARG;
     RcclApi *r = rccl();
@@ -121,22 +123,39 @@ extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, 
         done = j + 1;
         return BPE_OK;
     };
-    for (int i = 0; i < num_merges && !stop; i++) {
-        TRY(bpe_dp_select(c, i));
-        RCCLCHK(c, r->AllReduce(c->d_dp_key, c->d_dp_key, 2, RCCL_INT64, RCCL_MIN, c->comm, c->stream));
-        TRY(bpe_dp_merge(c, i));
-        RCCLCHK(c, r->AllReduce(c->d_dp_folded, c->d_dp_folded, (size_t)c->vcap * 4, RCCL_INT32, RCCL_SUM,
-                                c->comm, c->stream));
-        TRY(bpe_dp_apply(c, i));
-        // the schedule depends on i only: every rank issues the same collectives even when one stops
-        if (i - consumed >= c->depth) {
-            TRY(consume(consumed));
+    // Every rank issues the SAME collectives for every i in [0, num_merges), whatever it has learnt
+    // about its own or a peer's failure in the meantime: once a device status is raised the kernels
+    // of the remaining iterations are no-ops (each checks st->status), the all-reduces still match
+    // up, and the third key word carries the status to every rank at the next merge (k_dp_key).
+    // A host-side failure (a HIP or RCCL call that returns an error) cannot be recovered from --
+    // the stream is lost -- and is reported after the peers have been released as far as possible.
+    int host_rc = BPE_OK;
+    auto keep = [&](int r_) {
+        if (r_ != BPE_OK && host_rc == BPE_OK) host_rc = r_;
+    };
+    auto allreduce = [&](void *buf, size_t count, int dtype, int op) -> int {
+        RCCLCHK(c, r->AllReduce(buf, buf, count, dtype, op, c->comm, c->stream));
+        return BPE_OK;
+    };
+    for (int i = 0; i < num_merges; i++) {
+        if (host_rc == BPE_OK) keep(bpe_dp_select(c, i));
+        keep(allreduce(c->d_dp_key, 3, RCCL_INT64, RCCL_MIN));
+        if (host_rc == BPE_OK) keep(bpe_dp_merge(c, i));
+        keep(allreduce(c->d_dp_folded, (size_t)c->vcap * 4, RCCL_INT32, RCCL_SUM));
+        if (host_rc == BPE_OK) keep(bpe_dp_apply(c, i));
+        if (host_rc == BPE_OK && !stop && i - consumed >= c->depth) {
+            keep(consume(consumed));
             if (!stop) consumed++;
         }
     }
-    while (!stop && consumed < num_merges) {
-        TRY(consume(consumed));
+    while (host_rc == BPE_OK && !stop && consumed < num_merges) {
+        keep(consume(consumed));
         if (!stop) consumed++;
+    }
+    if (host_rc != BPE_OK) {
+        c->dp_active = false;
+        c->slotted = false;
+        return host_rc;
     }
     TRY(bpe_dp_end(c));
     // global lengths: one SUM over the per-shard lengths

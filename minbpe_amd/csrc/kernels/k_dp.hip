@@ -40,10 +40,18 @@ __global__ void k_dp_key(SlotRef ref, int par, const DevState *__restrict__ st,
     }
     key[0] = w0;
     key[1] = w1;
+    // third word: this rank's status, negated.  The MIN all-reduce hands every rank the worst one,
+    // so a rank-local failure (a bounded wait that timed out, a consistency check) stops ALL ranks
+    // at this same merge instead of leaving the peers to merge on without this shard.
+    key[2] = -(long long)st->status;
 }
 __global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->status) return;
+    if (key[2] < 0) {  // some rank failed (ST_EMPTY is replica-identical and never gets here)
+        st->status = ST_INTERNAL;
+        return;
+    }
     if (key[0] == 0x7FFFFFFFFFFFFFFFll) {
         st->status = ST_INTERNAL;  // a tie at the maximum, yet no rank holds a tied pair
         return;

@@ -205,6 +205,9 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             __builtin_amdgcn_s_sleep(4);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // never sweep on a decision that was not seen: a block that silently skipped its share
+        // could leave a later tied position as "the earliest" (wrong merge, no error)
+        if (!ok) atomicExch(&st->status, ST_LOOKBACK);
         s_go = (ok && st->status == 0 && st->found == 0 &&
                 __atomic_load_n(&st->firstpos, __ATOMIC_RELAXED) == NOPOS);
     }

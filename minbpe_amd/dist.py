@@ -3,8 +3,10 @@
 One process per GPU.  Each rank owns a contiguous range of the regex chunks
 (pairs never span chunks, regex.py:44/60, so the chunk list shards exactly) and
 keeps a replica of the GLOBAL pair table.  Per merge the ranks exchange
-  - two int64 words  (MIN all-reduce): decides the reference's first-occurrence
-    tie-break across ranks -- lowest (rank, local position) wins (F3/F5),
+  - three int64 words (MIN all-reduce): two decide the reference's first-occurrence
+    tie-break across ranks -- lowest (rank, local position) wins (F3/F5) -- and the
+    third carries -(status), so that a failure on any rank stops every rank at the
+    same merge,
   - four dense vectors of length vocab (SUM all-reduce): how the table changes.
 The id streams and the table itself never cross xGMI.
 
@@ -44,7 +46,7 @@ class GpuShard:
         t, tc, d, dc, k = self.eng.dp_buffers()
         self.table = torch.as_tensor(_DevicePtr(t, tc, "<i4"), device=self.device)
         self.delta = torch.as_tensor(_DevicePtr(d, dc, "<i4"), device=self.device)
-        self.key = torch.as_tensor(_DevicePtr(k, 2, "<i8"), device=self.device)
+        self.key = torch.as_tensor(_DevicePtr(k, 3, "<i8"), device=self.device)
 
     def table_ready(self):
         self.eng.dp_table_ready()
@@ -114,18 +116,18 @@ def train_sharded(shard, comm, num_merges, depth=8):
         local_lens.append(local_len)
 
     for i in range(num_merges):
+        # Every rank issues this same schedule for every i, also after one of its polls has
+        # reported a failure: from then on the shard's steps are no-ops, the collectives still
+        # pair up with the peers', and the status word of the key stops the peers one merge later.
+        # (Breaking out here would leave the other ranks blocked in their next all-reduce.)
         shard.select(i)
         comm.min_(shard.key)
         shard.merge(i)
         comm.sum_(shard.delta)
         shard.apply(i)
-        # run `depth` merges ahead of the device; the schedule below depends on i
-        # only, so every rank issues the same collectives even when one stops
-        if i - consumed >= depth:
+        if failed is None and i - consumed >= depth:  # run `depth` merges ahead of the device
             consume(consumed)
             consumed += 1
-            if failed is not None:
-                break
     while failed is None and consumed < num_merges:
         consume(consumed)
         consumed += 1
@@ -168,6 +170,20 @@ def init_native_comm(engine, comm):
     import torch
     import torch.distributed as dist
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(comm.group) == "nccl" else None
+    def agree(flag_value):
+        flag = torch.tensor([flag_value], dtype=torch.int32)
+        flag = flag.to(dev) if dev is not None else flag
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
+        return bool(flag.item())
+
+    # A rank that cannot load librccl must not leave the others waiting inside ncclCommInitRank:
+    # agree on availability first, over the group that already works.
+    try:
+        have = 1 if engine.comm_available() else 0
+    except Exception:
+        have = 0
+    if not agree(have):
+        return False
     ok = 1
     uid = torch.zeros(128, dtype=torch.uint8)
     if comm.rank == 0:
@@ -185,10 +201,7 @@ def init_native_comm(engine, comm):
             ok = 0
     else:
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32)
-    flag = flag.to(dev) if dev is not None else flag
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=comm.group)
-    return bool(flag.item())
+    return agree(ok)
 
 
 def train_tokenizer(tok, text, vocab_size, comm=None, verbose=False, make_shard=None, device_index=None):
@@ -232,7 +245,9 @@ def train_tokenizer(tok, text, vocab_size, comm=None, verbose=False, make_shard=
             else:
                 res = train_sharded(GpuShard(eng, device_index), comm, num_merges)
     except ValueError as e:
-        res, failure = e.partial, e
+        res, failure = getattr(e, "partial", None), e
+        if res is None:
+            raise
     merges, vocab = {}, {i: bytes([i]) for i in range(256)}
     for i, pair in enumerate(res["pairs"]):
         idx = 256 + i

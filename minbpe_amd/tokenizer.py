@@ -149,9 +149,11 @@ class Tokenizer:
     def _merge_table(self):
         """merges as device arrays, ordered by priority = the dict's value
         (`min(stats, key=merges.get)` in the reference, basic.py:64)."""
-        key = (id(self.merges), len(self.merges))
+        # the cache holds the dict OBJECT (an id() alone can be recycled by a later dict once
+        # train()/load() have dropped the old one) and its length
+        key = (self.merges, len(self.merges))
         cached = getattr(self, "_mt_cache", None)
-        if cached is None or cached[0] != key:
+        if cached is None or cached[0][0] is not key[0] or cached[0][1] != key[1]:
             items = sorted(self.merges.items(), key=lambda kv: kv[1])
             pairs = np.array([p for p, _ in items], dtype=np.int32).reshape(-1, 2)
             mids = np.array([i for _, i in items], dtype=np.int32)
@@ -174,9 +176,10 @@ class Tokenizer:
         sparse) where ids 0..V-1 are table indices as they are and `sparse` maps every
         other known id to its index."""
         extra = self._decode_extra()
-        key = (id(self.vocab), len(self.vocab), id(extra), len(extra))
+        key = (self.vocab, len(self.vocab), tuple(sorted(extra.items())))
         cached = getattr(self, "_dt_cache", None)
-        if cached is None or cached[0] != key:
+        if (cached is None or cached[0][0] is not key[0] or cached[0][1] != key[1]
+                or cached[0][2] != key[2]):
             vocab = self.vocab
             V = 0
             while V in vocab:

@@ -10,7 +10,8 @@ I64MAX = 0x7FFFFFFFFFFFFFFF
 
 
 class CpuShard:
-    def __init__(self, data: bytes, offsets, weight_exp=None):
+    def __init__(self, data: bytes, offsets, weight_exp=None, fail_at=None):
+        self.fail_at = fail_at  # inject a rank-local failure into merge() of this iteration
         self.data = data
         self.offsets = offsets
         self.weight_exp = weight_exp  # per chunk: pairs inside it count 2**e times (bpe_load_bytes_weighted)
@@ -40,13 +41,19 @@ class CpuShard:
                 t256[self.ids[p], self.ids[p + 1]] += self.w[p]
         self.table = torch.from_numpy(t256.reshape(-1))
         self.delta = torch.zeros(4 * self.V, dtype=torch.int32)
-        self.key = torch.zeros(2, dtype=torch.int64)
+        self.key = torch.zeros(3, dtype=torch.int64)
+        self._status = 0
         self.rec = {}
 
     def table_ready(self):
         self.tab[:256, :256] = self.table.numpy().reshape(256, 256)
 
     def select(self, i):
+        self.key[2] = 0
+        if self._status not in (0, -3):  # a failure is sticky: later steps are no-ops
+            self.key[0] = self.key[1] = I64MAX
+            self.key[2] = -2
+            return
         M = int(self.tab.max())
         self._count = M
         if M == 0:
@@ -70,6 +77,10 @@ class CpuShard:
     def merge(self, i):
         V, Z = self.V, 256 + i
         self.delta.zero_()
+        if self._status == 0 and int(self.key[2]) < 0:
+            self._status = -7  # a peer failed
+        if self._status == 0 and self.fail_at == i:
+            self._status = -7  # injected: e.g. a bounded device-side wait that timed out
         if self._status != 0:
             self.rec[i] = ((0, 0), 0, len(self.ids), self._status)
             return

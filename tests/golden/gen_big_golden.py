@@ -1,0 +1,94 @@
+"""Full-length golden digests at BASELINE sizes, produced by the CPU oracle
+(oracle/bpe_oracle.c, itself pinned against the reference by gen_golden.py /
+tests/test_oracle_golden.py) in the build container.  One-off CPU jobs of
+10-40 minutes each; the digests are committed in tests/golden/big_golden.json and
+consumed by tests/test_gpu_big.py and bench.py.
+
+    python tests/golden/gen_big_golden.py cfg2      # Basic, 100 MB, 3840 merges
+    python tests/golden/gen_big_golden.py cfg3s     # GPT-4 split, 150 MB, 8192 merges
+    python tests/golden/gen_big_golden.py basic1g   # Basic, 1 GB, first 64 merges (bench spot check)
+
+The GPT-4 split of `cfg3s` is done here with the `regex` module exactly as the
+reference does (regex.py:19,41), NOT with the native splitter: the digest of the
+chunk offsets is stored too, so the GPU-side test also proves bpe_split == regex
+on 150 MB of text.
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+from helpers import checkpoint_digests  # noqa: E402
+from minbpe_amd import synth_text  # noqa: E402
+
+OUT = os.path.join(HERE, "big_golden.json")
+GPT4_SPLIT_PATTERN = r"""'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]++[\r\n]*|\s*[\r\n]|\s+(?!\S)|\s+"""
+
+CASES = {
+    # name: (bytes, seed, merges, chunked)
+    "cfg2": (100_000_000, 1, 3840, False),
+    "cfg3s": (150_000_000, 2, 8192, True),
+    "basic1g": (1_000_000_000, 2, 64, False),
+    "regex1g": (1_000_000_000, 2, 48, True),
+}
+
+
+def regex_offsets(data: bytes) -> np.ndarray:
+    import regex as re
+    pat = re.compile(GPT4_SPLIT_PATTERN)
+    text = data.decode("utf-8")
+    from array import array
+    offs = array("Q")
+    pos = 0
+    ascii_only = len(text) == len(data)
+    for m in pat.finditer(text):
+        offs.append(pos if not ascii_only else m.start())
+        if not ascii_only:
+            pos += len(m.group().encode("utf-8"))
+    return np.frombuffer(offs, dtype=np.uint64).copy()
+
+
+def main():
+    name = sys.argv[1]
+    nbytes, seed, merges, chunked = CASES[name]
+    t0 = time.time()
+    data = synth_text(nbytes, seed)
+    entry = {"bytes": nbytes, "seed": seed, "merges": merges, "chunked": chunked,
+             "data_sha256": hashlib.sha256(data).hexdigest()}
+    offs = None
+    if chunked:
+        offs = regex_offsets(data)
+        entry["n_chunks"] = int(len(offs))
+        entry["offsets_sha256"] = hashlib.sha256(offs.tobytes()).hexdigest()
+        print(f"{name}: regex split {len(offs)} chunks in {time.time() - t0:.0f}s", flush=True)
+    t1 = time.time()
+    pairs, counts, lens = oracle.train(data, merges, offs)
+    entry["oracle_seconds"] = round(time.time() - t1, 1)
+    entry["done"] = len(pairs)
+    entry["first"] = [list(p) for p in pairs[:4]]
+    entry["last"] = [list(p) for p in pairs[-2:]]
+    entry["final_len"] = lens[-1]
+    entry["step"] = 256 if merges >= 256 else 16
+    entry["digests"] = checkpoint_digests(pairs, counts, lens, entry["step"])
+    allg = {}
+    if os.path.exists(OUT):
+        with open(OUT) as f:
+            allg = json.load(f)
+    allg[name] = entry
+    with open(OUT, "w") as f:
+        json.dump(allg, f, indent=1)
+    print(f"{name}: {len(pairs)} merges, oracle {entry['oracle_seconds']}s, final digest "
+          f"{entry['digests'][-1][1]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

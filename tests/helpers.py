@@ -47,3 +47,35 @@ def toy_rank_table(base_tok, seed):
         assert base_tok.vocab[idx] not in ranks  # vocabularies this small have no duplicate byte strings
         ranks[base_tok.vocab[idx]] = idx
     return perm, ranks
+
+
+def checkpoint_digests(pairs, counts, lens, step):
+    """[[k, sha256-prefix of the first k merges], ...] every `step` merges and at the end.
+    The digest covers pairs, counts AND stream lengths, as little-endian int64 triples
+    (a, b, count, len) -- cheap to recompute for tens of thousands of merges."""
+    import hashlib
+    n = len(pairs)
+    arr = np.empty((n, 4), dtype="<i8")
+    if n:
+        arr[:, 0:2] = np.asarray(pairs, dtype=np.int64).reshape(n, 2)
+        arr[:, 2] = np.asarray(counts, dtype=np.int64)
+        arr[:, 3] = np.asarray(lens, dtype=np.int64)
+    h = hashlib.sha256()
+    out = []
+    k = 0
+    while k < n:
+        k2 = min(k + step, n)
+        h.update(arr[k:k2].tobytes())
+        out.append([k2, h.copy().hexdigest()[:16]])
+        k = k2
+    return out
+
+
+def first_divergence(got, want):
+    """Compare two checkpoint lists; returns None if every common checkpoint agrees, else the
+    merge count of the first checkpoint that differs."""
+    want_d = {k: d for k, d in want}
+    for k, d in got:
+        if k in want_d and want_d[k] != d:
+            return k
+    return None

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, chunks, num_merges, out_q, dedup=False):
+def _worker(rank, world, port, chunks, num_merges, out_q, dedup=False, fail=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,19 +42,23 @@ def _worker(rank, world, port, chunks, num_merges, out_q, dedup=False):
             from minbpe_amd import _native
             data, offs, wexp, _ = _native.dedup_chunks(data, offs)
         try:
-            res = train_sharded(CpuShard(data, offs, wexp), TorchComm(), num_merges, depth=3)
+            fail_at = fail[1] if fail and fail[0] == rank else None
+            res = train_sharded(CpuShard(data, offs, wexp, fail_at=fail_at), TorchComm(), num_merges, depth=3)
             out_q.put((rank, "ok", res["pairs"], res["counts"], res["lens"]))
+        except RuntimeError as e:
+            out_q.put((rank, "failed", str(e), None, None))
         except ValueError as e:
             out_q.put((rank, "empty", e.partial["pairs"], e.partial["counts"], e.partial["lens"]))
     finally:
         dist.destroy_process_group()
 
 
-def _run(chunks, num_merges, world=2, dedup=False):
+def _run(chunks, num_merges, world=2, dedup=False, fail=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, num_merges, q, dedup)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, chunks, num_merges, q, dedup, fail))
+             for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=240) for _ in procs]
@@ -108,6 +112,16 @@ def test_sharded_training_with_per_rank_dedup(native):
         assert pairs == exp[0] and counts == exp[1]  # lens refer to the de-duplicated shards
 
 
+@pytest.mark.parametrize("bad_rank", [0, 2])
+def test_rank_local_failure_stops_every_rank_without_deadlock(native, bad_rank):
+    """One rank's shard fails inside merge() of iteration 7 (as a timed-out device-side wait would):
+    no rank may be left blocked in an all-reduce, and every rank must report the failure."""
+    chunks = _chunks(native.synth_text(4000, 44))
+    outs = _run(chunks, 30, world=3, fail=(bad_rank, 7))
+    assert [o[1] for o in outs] == ["failed"] * 3
+    assert all("failed with status" in o[2] for o in outs)
+
+
 def test_sharded_exhaustion_stops_all_ranks_together():
     chunks = [b"ab", b"ab", b"cd", b"ab"]
     exp = _oracle(chunks, 6)
@@ -121,9 +135,13 @@ def test_sharded_exhaustion_stops_all_ranks_together():
 # waiting in a collective, whichever rank fails to set the library's communicator up
 
 class _FakeEngine:
-    def __init__(self, rank, fail_uid=False, fail_init_on=None):
+    def __init__(self, rank, fail_uid=False, fail_init_on=None, no_lib_on=None):
         self.rank, self.fail_uid, self.fail_init_on = rank, fail_uid, fail_init_on
+        self.no_lib_on = no_lib_on
         self.inited = None
+
+    def comm_available(self):
+        return self.no_lib_on != self.rank
 
     def comm_unique_id(self):
         if self.fail_uid:
@@ -142,14 +160,15 @@ def _comm_worker(rank, world, port, mode, out_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from minbpe_amd.dist import TorchComm, init_native_comm
-        eng = _FakeEngine(rank, fail_uid=(mode == "uid"), fail_init_on=(1 if mode == "init" else None))
+        eng = _FakeEngine(rank, fail_uid=(mode == "uid"), fail_init_on=(1 if mode == "init" else None),
+                          no_lib_on=(1 if mode == "nolib" else None))
         ok = init_native_comm(eng, TorchComm())
         out_q.put((rank, ok, eng.inited))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["ok", "uid", "init"])
+@pytest.mark.parametrize("mode", ["ok", "uid", "init", "nolib"])
 def test_native_comm_setup_is_all_or_nothing(mode):
     world = 2
     ctx = mp.get_context("spawn")
@@ -165,6 +184,8 @@ def test_native_comm_setup_is_all_or_nothing(mode):
     assert [o[1] for o in outs] == [mode == "ok"] * world
     if mode == "ok":  # every rank got rank 0's id
         assert all(o[2] == (o[0], world, bytes(range(1, 129))) for o in outs)
+    if mode == "nolib":  # one rank without librccl: NO rank may have entered comm_init
+        assert all(o[2] is None for o in outs)
 
 
 # ---------------------------------------------------------------------------

@@ -1,0 +1,98 @@
+"""GPU: full-length parity at BASELINE sizes.
+
+* cfg1: the reference's own fixture text (tests/golden/taylorswift.txt, a verbatim copy of
+  /root/reference/tests/taylorswift.txt, sha256-pinned) through the drop-in classes, against
+  the hashes the reference itself produced (tests/golden/golden.json["taylorswift"]).
+* cfg2 and a cfg3-shaped run: every merge (pair, count, stream length) against digests the CPU
+  oracle produced once, offline (tests/golden/gen_big_golden.py -> big_golden.json).
+Integer work: every comparison is exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import checkpoint_digests, first_divergence
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def big_golden():
+    with open(os.path.join(HERE, "golden", "big_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def taylor():
+    with open(os.path.join(HERE, "golden", "taylorswift.txt"), encoding="utf-8") as f:
+        return f.read()
+
+
+def h16(obj):
+    return hashlib.sha256(repr(obj).encode()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("kind", ["basic", "regex"])
+def test_taylorswift_vocab512_reference_hashes(golden, taylor, kind):
+    """configs[0]: train.py's workload (train.py:20-31), hashes from the live reference."""
+    from minbpe_amd import BasicTokenizer, RegexTokenizer
+    g = golden["taylorswift"]
+    assert hashlib.sha256(taylor.encode("utf-8")).hexdigest()[:16] == g["sha256_prefix"]
+    tok = BasicTokenizer() if kind == "basic" else RegexTokenizer()
+    tok.train(taylor, 512)
+    assert h16(list(tok.merges.items())) == g[f"{kind}512_merges_hash"]
+    ids = tok.encode(taylor)
+    assert len(ids) == g[f"{kind}512_encode_len"]
+    assert h16(ids) == g[f"{kind}512_encode_hash"]
+    assert tok.decode(ids) == taylor
+
+
+def _check_digests(res, g):
+    assert len(res["pairs"]) == g["done"]
+    got = checkpoint_digests(res["pairs"], res["counts"], res["lens"], g["step"])
+    bad = first_divergence(got, g["digests"])
+    assert bad is None, f"first differing checkpoint: merge {bad}"
+    assert got[-1] == g["digests"][-1]
+    assert res["lens"][-1] == g["final_len"]
+
+
+def test_cfg2_all_3840_merges_equal_oracle(native, engine, big_golden):
+    """configs[1] at full length: BasicTokenizer.train, 100 MB, vocab 4096."""
+    g = big_golden["cfg2"]
+    data = native.synth_text(g["bytes"], g["seed"])
+    assert hashlib.sha256(data).hexdigest() == g["data_sha256"]
+    engine.load_bytes(data)
+    _check_digests(engine.train(g["merges"]), g)
+
+
+def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golden):
+    """configs[2] shape: GPT-4 split, 150 MB, 8192 merges; chunk offsets (produced by the `regex`
+    module when the golden was made) must be reproduced by the native splitter first."""
+    g = big_golden["cfg3s"]
+    data = native.synth_text(g["bytes"], g["seed"])
+    assert hashlib.sha256(data).hexdigest() == g["data_sha256"]
+    offs = native.split_offsets(data, 4)
+    assert len(offs) == g["n_chunks"]
+    assert hashlib.sha256(np.ascontiguousarray(offs, dtype=np.uint64).tobytes()).hexdigest() == g["offsets_sha256"]
+    engine.load_bytes(data, offs)
+    _check_digests(engine.train(g["merges"]), g)
+
+
+def test_cross_mode_large_chunked(native, engine):
+    """The literal reference loop (mode 0: clear, get_stats, arg-max, merge every iteration) and the
+    default engine (pair table kept current by the merge pass) must agree merge for merge on a stream
+    far larger than the oracle-sized tests: 400 MB, GPT-4 split, first 600 merges."""
+    data = native.synth_text(400_000_000, 7)
+    offs = native.split_offsets(data, 4)
+    engine.load_bytes(data, offs)
+    fast = engine.train(600)
+    engine.set_option("mode", 0)
+    try:
+        slow = engine.train(600)
+    finally:
+        engine.set_option("mode", 1)
+    assert slow["pairs"] == fast["pairs"]
+    assert slow["counts"] == fast["counts"] and slow["lens"] == fast["lens"]
