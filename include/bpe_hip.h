@@ -191,6 +191,10 @@ int bpe_decode_read(bpe_ctx *ctx, uint8_t *out, uint64_t cap, const uint64_t *do
  * tables and flags not counted). */
 int bpe_prof_reset(bpe_ctx *ctx);
 int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_bytes);
+/* How the last bpe_train ran its merge passes: out[0] = dense passes (every slot of the stream
+ * is visited), out[1] = sparse passes (only the slots the inverted slot index cannot rule out),
+ * out[2] = builds of that index, out[3] = slots of the stream at the end. */
+int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */
 /* regex.findall(pattern, text) for the two GPT split patterns (regex.py:18-19, 41, 114),

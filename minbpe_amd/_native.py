@@ -92,6 +92,7 @@ _SIGS = {
     "bpe_decode_read": (C.c_int, [_p, _p, _u64, _p, _u64, _p]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
+    "bpe_train_stats": (C.c_int, [_p, _p]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_dedup_chunks": (C.c_int, [_p, _u64, _p, _u64, _p, _p, _p, C.POINTER(_u64), C.POINTER(_u64),
                                   C.POINTER(_u64), C.c_int]),
@@ -446,6 +447,12 @@ class Engine:
     # -- measurement ----------------------------------------------------------------
     def prof_reset(self):
         self._check(_lib.bpe_prof_reset(self._h))
+
+    def train_stats(self):
+        """dict(dense, sparse, index_builds, slots) of the last train() (bpe_train_stats)."""
+        out = np.zeros(4, np.uint64)
+        self._check(_lib.bpe_train_stats(self._h, _ptr(out)))
+        return dict(dense=int(out[0]), sparse=int(out[1]), index_builds=int(out[2]), slots=int(out[3]))
 
     def prof_read(self):
         k = len(PROF_KINDS)

@@ -43,7 +43,7 @@ struct bpe_ctx {
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
     // slotted stream (training loop, a != b merges)
-    int use_slots = 1;
+    int use_slots = 2;  // 0 contiguous | 1 slotted, first form (k_slots.hip) | 2 second form (k_slots2.hip)
     int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
     uint32_t sel_epoch = 0;              // k_select decision flag value of the last launch
     unsigned long long apply_target = 0;  // apply blocks launched since the state was initialised
@@ -56,6 +56,20 @@ struct bpe_ctx {
     uint32_t *d_slot_lens = nullptr;
     unsigned long long *d_slot_off = nullptr, *d_slot_bsum = nullptr;
     uint32_t *d_ids2 = nullptr;  // third stream buffer: target of compactions
+    // second slotted form (k_slots2.hip; use_slots == 2, the default)
+    bool slot2 = false;                       // the slotted stream currently uses the 32-byte headers
+    SlotHdr *d_hdr2[2] = {nullptr, nullptr};
+    StageRec *d_stage = nullptr;              // staged headers of a sparse pass: stage[t] for slot t
+    uint32_t *d_smask = nullptr;              // [slot / 32] which slots have a staged header
+    uint32_t *d_idx = nullptr;                // inverted slot index [slot / 32][IDX_H]
+    uint32_t *d_idx_dirty = nullptr;          // [slot / 32]: slots rewritten by a == b passes since the last build
+    uint32_t *d_removed = nullptr;            // [256] removal counters of a merge pass
+    uint64_t idx_cap_words = 0;               // index groups allocated
+    bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
+    bool idx_live = false;                    // the index describes the current slots
+    int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
+    uint64_t last_count = ~0ull;              // count of the last merge the host has seen: an upper bound of the next ones
+    uint64_t n_sparse = 0, n_dense = 0, n_index_builds = 0;  // passes of the last train() (bpe_train_stats)
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
@@ -187,6 +201,11 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_meta[1], nt));
         TRY(dev_realloc(c, c->d_hdr[0], nt));
         TRY(dev_realloc(c, c->d_hdr[1], nt));
+        TRY(dev_realloc(c, c->d_hdr2[0], nt));
+        TRY(dev_realloc(c, c->d_hdr2[1], nt));
+        TRY(dev_realloc(c, c->d_stage, nt));
+        TRY(dev_realloc(c, c->d_smask, nt / 32 + 2));
+        HIPCHK(c, hipMemsetAsync(c->d_smask, 0, (nt / 32 + 2) * sizeof(uint32_t), c->stream));
         TRY(dev_realloc(c, c->d_slot_lens, nt));
         TRY(dev_realloc(c, c->d_slot_off, nt + 1));
         TRY(dev_realloc(c, c->d_slot_bsum, nt / SCAN_TILE + 2));
@@ -205,10 +224,14 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     uint32_t nv = std::max<uint32_t>(v, 256);
     nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
     TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
-    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv));
+    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv * 2));  // rowmax[nv] | rowarg[nv]
     TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL));
     TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
     if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
+    if (!c->d_removed) {
+        HIPCHK(c, hipMalloc((void **)&c->d_removed, 256 * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_removed, 0, 256 * sizeof(uint32_t), c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * DELTA_REPL * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
     if (c->d_first) {
@@ -367,7 +390,17 @@ SlotRef stream_ref(const bpe_ctx *c) {
     return r;
 }
 
-// K2 + tie-break: after these, resolved_pair() gives the pair on the device
+SlotRefH stream_ref_h(const bpe_ctx *c) {
+    SlotRefH r;
+    r.b0 = c->d_ids[0];
+    r.b1 = c->d_ids[1];
+    r.hdr = c->d_hdr2[c->mq];
+    r.T = c->slot_T;
+    return r;
+}
+
+// K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
+// this rank's candidate)
 int launch_select(bpe_ctx *c, bool rowmax_all) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     if (rowmax_all) {
@@ -375,11 +408,16 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
                            c->vcur, c->d_rowmax);
         LAUNCHCHK(c, "k_rowmax_all");
     }
-    const SlotRef ref = stream_ref(c);
-    const uint64_t space = c->slotted ? c->slot_T * TILE : c->n;
-    const unsigned blocks = space > TIE_WINDOW0 ? grid_for(space - TIE_WINDOW0, 1024, TIE_BLOCKS) : 1u;
-    hipLaunchKernelGGL(k_select, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
-                       c->vcap, c->vcur, c->d_st, ref, c->par, c->dp_active ? 1 : 0, ++c->sel_epoch);
+    const uint64_t nslots = c->slotted ? c->slot_T : ntiles_of(c->n);
+    const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nslots, TIE_BLOCKS));
+    if (c->slotted && c->slot2)
+        hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                           c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
+                           ++c->sel_epoch);
+    else
+        hipLaunchKernelGGL(k_select<SlotRef>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                           c->vcap, c->vcur, c->d_st, stream_ref(c), c->par, c->dp_active ? 1 : 0,
+                           ++c->sel_epoch);
     LAUNCHCHK(c, "k_select");
     TRY(prof_end(c));
     return BPE_OK;
@@ -541,6 +579,170 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     }
     c->par ^= 1;
     c->mq ^= 1;
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    return BPE_OK;
+}
+
+// ---- slotted stream, second form (k_slots2.hip) -------------------------------------------------
+constexpr unsigned SPARSE_GRID = 1024;      // resident workgroups of a sparse pass (4 per CU)
+
+int index_build(bpe_ctx *c) {
+    const uint64_t nwords = (c->slot_T + 31) / 32;
+    if (nwords > c->idx_cap_words) {
+        if (c->d_idx) HIPCHK(c, hipFree(c->d_idx));
+        if (c->d_idx_dirty) HIPCHK(c, hipFree(c->d_idx_dirty));
+        c->d_idx = c->d_idx_dirty = nullptr;
+        const uint64_t cap = nwords + 1;
+        HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * IDX_H * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_idx_dirty, cap * sizeof(uint32_t)));
+        c->idx_cap_words = cap;
+    }
+    if (nwords) {
+        hipLaunchKernelGGL(k_index_build, dim3((unsigned)nwords), dim3(1024), (size_t)IDX_H * 4, c->stream,
+                           c->d_ids[0], c->d_ids[1], c->d_hdr2[c->mq], (uint32_t)c->slot_T, c->d_idx,
+                           c->d_idx_dirty);
+        LAUNCHCHK(c, "k_index_build");
+    }
+    c->idx_live = true;
+    c->idx_rebuild = false;
+    c->n_index_builds++;
+    return BPE_OK;
+}
+
+int slots2_enter(bpe_ctx *c) {
+    c->slot_T = ntiles_of(c->n);
+    c->mq = 0;
+    hipLaunchKernelGGL(k_slot2_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
+                       dim3(256), 0, c->stream, c->d_hdr2[0], c->slot_T, c->d_st, c->par, (uint32_t)c->par,
+                       c->d_ids[c->par]);
+    LAUNCHCHK(c, "k_slot2_init");
+    c->slotted = true;
+    c->slot2 = true;
+    // (a pass that was cut short by a device status may have left staged-header marks behind)
+    HIPCHK(c, hipMemsetAsync(c->d_smask, 0, (c->slot_T / 32 + 1) * sizeof(uint32_t), c->stream));
+    if (c->idx_live) TRY(index_build(c));  // the slots changed: the index is rebuilt
+    return BPE_OK;
+}
+
+// slots -> contiguous in d_ids[0] (par 0); st->n[0] = the stream length
+int slots2_leave(bpe_ctx *c) {
+    const uint64_t T = c->slot_T;
+    if (T) {
+        const uint64_t nb = (T + SCAN_TILE - 1) / SCAN_TILE;
+        hipLaunchKernelGGL(k_slot2_lens, dim3(grid_for(T, 256, c->num_cus * 4)), dim3(256), 0, c->stream,
+                           c->d_hdr2[c->mq], T, c->d_slot_lens);
+        hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_slot_bsum, nb,
+                           c->d_scratch + 3);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
+                           c->d_slot_bsum, c->d_slot_off);
+        hipLaunchKernelGGL(k_slot2_compact, dim3((unsigned)T), dim3(256), 0, c->stream, c->d_ids[0],
+                           c->d_ids[1], c->d_hdr2[c->mq], c->d_slot_off, c->d_ids2);
+        LAUNCHCHK(c, "k_slot2_compact");
+    }
+    std::swap(c->d_ids[0], c->d_ids2);
+    if (c->par != 0) {
+        hipLaunchKernelGGL(k_move_n, dim3(1), dim3(1), 0, c->stream, c->d_st, c->par, 0);
+        LAUNCHCHK(c, "k_move_n");
+    }
+    c->par = 0;
+    c->slotted = false;
+    c->slot2 = false;
+    return BPE_OK;
+}
+
+// replicas of the delta vectors for this pass: as many as the buffer holds at this vocabulary
+// (the hot tokens of an early merge serialise at ~11 ns per same-address atomic), fewer when
+// the merged pair is rare (the table update folds every replica).  dstride = vector stride.
+inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
+    const uint32_t dstride = std::min<uint32_t>(c->vcap, ((Z + 1 + 63) / 64) * 64);
+    const uint64_t buf_words = (uint64_t)c->vcap * 4 * DELTA_REPL;
+    int shift = 0;
+    while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;
+    const uint64_t cnt = c->last_count;
+    const int want = cnt >= (1u << 20) ? 8 : (cnt >= (1u << 16) ? 5 : (cnt >= (1u << 12) ? 3 : 0));
+    return dstride | ((uint32_t)std::min(shift, want) << 24);
+}
+
+// one merge pass of the second slotted form + table update.  The host does not know the pair
+// (it runs `depth` merges ahead): the a != b kernel and the a == b kernel are both launched and
+// the one the pair does not call for returns at once.
+int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+        c->epoch++;
+    }
+    const uint32_t T = (uint32_t)c->slot_T;
+    const uint32_t dl = delta_layout(c, newid);
+    // a sparse pass pays when the pair is rare enough that most slots cannot hold it
+    // (use_sparse == 2: every a != b pass is a sparse one -- tests drive the sparse kernel and the
+    // index through streams of a few slots with it)
+    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 4 * SPARSE_GRID);
+    const bool sparse = can_index && (c->use_sparse == 2 || (c->last_count != ~0ull && c->last_count * 3 < T));
+    // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
+    // one go by, the index is rebuilt so that those marks do not pile up)
+    if (sparse && (!c->idx_live || c->idx_rebuild)) TRY(index_build(c));
+    AbArgs A;
+    A.b0 = c->d_ids[0];
+    A.b1 = c->d_ids[1];
+    A.hdr_in = c->d_hdr2[c->mq];
+    A.hdr_out = c->d_hdr2[c->mq ^ 1];
+    A.stage = c->d_stage;
+    A.smask = c->d_smask;
+    A.T = T;
+    A.st = c->d_st;
+    A.newid = newid;
+    A.delta = c->d_delta;
+    A.vcap = dl;
+    A.idx = c->idx_live ? c->d_idx : nullptr;
+    A.dirty = c->d_idx_dirty;
+    A.removed = c->d_removed;
+    A.dirty_n = c->d_dirty_n;
+    if (sparse) {
+        hipLaunchKernelGGL(k_merge_ab_sparse, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
+        c->n_sparse++;
+    } else {
+        hipLaunchKernelGGL(k_merge_ab_dense, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
+        c->n_dense++;
+    }
+    LAUNCHCHK(c, "k_merge_ab");
+    AaArgs B;
+    B.b0 = c->d_ids[0];
+    B.b1 = c->d_ids[1];
+    B.w0 = c->d_ids[0];
+    B.w1 = c->d_ids[1];
+    B.hdr_in = A.hdr_in;
+    B.hdr_out = A.hdr_out;
+    B.stage = sparse ? c->d_stage : nullptr;
+    B.smask = c->d_smask;
+    B.T = T;
+    B.st = c->d_st;
+    B.newid = newid;
+    B.delta = c->d_delta;
+    B.vcap = dl;
+    B.sdesc = c->d_desc;
+    B.epoch = c->epoch;
+    B.dirty = c->idx_live ? c->d_idx_dirty : nullptr;
+    B.removed = c->d_removed;
+    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 2u * (unsigned)c->num_cus))), dim3(MT), 0,
+                       c->stream, B);
+    LAUNCHCHK(c, "k_merge_aa");
+    TRY(prof_end(c));
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    const uint32_t na = (newid + 1 + 31) / 32;
+    hipLaunchKernelGGL(k_apply2, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
+                       c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, na,
+                       c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
+    LAUNCHCHK(c, "k_apply2");
+    hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
+                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    LAUNCHCHK(c, "k_rowmax_list");
+    TRY(prof_end(c));
+    c->par ^= 1;
+    if (!sparse) c->mq ^= 1;
     c->stats_valid = false;
     c->stream_is_bytes = false;
     return BPE_OK;

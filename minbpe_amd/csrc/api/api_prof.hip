@@ -25,4 +25,13 @@ int bpe_prof_read(bpe_ctx *c, double *ms, uint64_t *launches, uint64_t *alg_byte
     return BPE_OK;
 }
 
+int bpe_train_stats(bpe_ctx *c, uint64_t *out4) {
+    if (!c || !out4) return BPE_E_ARG;
+    out4[0] = c->n_dense;
+    out4[1] = c->n_sparse;
+    out4[2] = c->n_index_builds;
+    out4[3] = c->slot_T;
+    return BPE_OK;
+}
+
 }  // extern "C"

@@ -34,7 +34,15 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     bool stop = false;
     c->rep_shift = 5;
     const bool slots = delta && c->use_slots && c->merge_impl == 0;
-    if (slots) TRY(slots_enter(c));
+    const bool form2 = slots && c->use_slots == 2;
+    c->idx_live = false;
+    c->idx_rebuild = false;
+    c->last_count = ~0ull;
+    c->n_sparse = c->n_dense = c->n_index_builds = 0;
+    // second form: which iterations flipped the header arrays (a sparse pass does not), so that an
+    // early stop can undo the flips of the no-op iterations enqueued behind the failing one
+    std::vector<uint8_t> hdr_flip(form2 ? (size_t)num_merges : 0, 0);
+    if (slots) TRY(form2 ? slots2_enter(c) : slots_enter(c));
     // The device writes one IterRec per iteration into pinned host memory; the
     // host runs up to `depth` iterations ahead and only ever waits on those
     // records, never on the stream (no hipStreamSynchronize in the loop).
@@ -74,6 +82,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         cur_len = r->new_len;
         c->n = cur_len;  // tighter launch bound for what is enqueued next
+        c->last_count = r->count;  // counts never grow: an upper bound for every later merge
+        if (r->a == r->b && c->idx_live) c->idx_rebuild = true;
         // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
         // few sites -> few same-address atomics -> fewer replicas to fold (measured: going
         // below 32 while a pass still has tens of thousands of sites slows the merge pass)
@@ -96,13 +106,24 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             // Slots thinning out: re-pack (between merges nothing is pending).  A pass costs
             // per slot as much as per id, so the slot count should follow the stream length
             // closely; at 31/32 fill a whole cfg2 run re-packs ~45 times, ~60 us each.
-            if (c->slotted && c->slot_T > 64 &&
-                c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
-                TRY(slots_leave(c));
-                TRY(slots_enter(c));
+            // (with the inverted index live most passes skip most slots, and a re-packing also costs
+            // an index build: re-pack at 7/8 there)
+            const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
+            if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE * (den - 1)) {
+                if (c->slot2) {
+                    TRY(slots2_leave(c));
+                    TRY(slots2_enter(c));
+                } else {
+                    TRY(slots_leave(c));
+                    TRY(slots_enter(c));
+                }
             }
             TRY(launch_select(c, full_rowmax));
-            if (c->slotted)
+            if (c->slotted && c->slot2) {
+                const int mq0 = c->mq;
+                TRY(launch_merge2(c, 256u + (uint32_t)i, i, c->h_rec));
+                hdr_flip[(size_t)i] = (uint8_t)(c->mq != mq0);
+            } else if (c->slotted)
                 TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));
             else
                 TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
@@ -120,13 +141,16 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         // leave the ids contiguous for whoever reads them next
         if (stop) {  // parity of the no-op iterations enqueued after the failing one
             const int back = i - done;
-            if (back & 1) {
-                c->par ^= 1;
+            if (back & 1) c->par ^= 1;
+            if (c->slot2) {
+                for (int j = done; j < i; j++)
+                    if (hdr_flip[(size_t)j]) c->mq ^= 1;
+            } else if (back & 1) {
                 c->mq ^= 1;
             }
             hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
         }
-        TRY(slots_leave(c));
+        TRY(c->slot2 ? slots2_leave(c) : slots_leave(c));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->n = cur_len;
         c->vcur = 256u + (uint32_t)done;

@@ -35,7 +35,7 @@ constexpr int PCB_ROUND = 61440;  // byte-stream kernel: positions between flush
 constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
 constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
 constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches alone on a tie (0: all blocks sweep together)
-constexpr int TIE_BLOCKS = 64;      // extra k_select blocks that sweep the rest of the stream
+constexpr int TIE_BLOCKS = 256;     // k_select blocks: block 0 decides, all of them sweep the stream on a tie
 constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
 
@@ -58,6 +58,28 @@ struct SlotRef {
     unsigned long long T;
 };
 
+// Slotted stream, second form (the training loop's default, k_slots2.hip): one 32-byte header
+// per slot instead of a meta word + a 16-byte header, so that a workgroup gets everything it
+// needs from its neighbours in one coalesced 96-byte load.
+struct SlotHdr {
+    uint32_t w0, w1, w2;  // first three words of the slot (INVALID_WORD beyond its length)
+    uint32_t meta;        // len | buffer << 31
+    uint32_t l0, l1;      // second-to-last and last word (INVALID_WORD if len < 2 / len < 1)
+    uint32_t pad0, pad1;
+};
+struct SlotRefH {
+    const uint32_t *b0, *b1;
+    const SlotHdr *hdr;
+    unsigned long long T;
+};
+// a header waiting to be committed (sparse merge passes visit few slots and must not touch the
+// header array their neighbours are reading)
+struct StageRec {
+    uint32_t t, pad[3];
+    uint32_t h[8];
+};
+constexpr uint32_t ROWARG_MULTI = 0xFFFFFFFFu;  // rowarg[x]: several columns attain rowmax[x]
+
 // one per ctx, in device memory
 struct DevState {
     unsigned long long n[2];      // length of the id stream in ping-pong buffer 0/1
@@ -72,7 +94,12 @@ struct DevState {
     unsigned long long removed;   // slotted merge: ids removed by the current pass
     unsigned long long apply_done;  // k_apply_delta blocks finished (monotonic; row blocks wait on it)
     uint32_t sel_flag;            // k_select: block 0 publishes its decision to the tie-break blocks
-    uint32_t pad_;
+    uint32_t sel_tie;             // ... and whether a tie is open (every block then sweeps and takes a ticket)
+    uint32_t sel_done;            // tickets of the sweeping blocks: the last one finalises the pair
+    uint32_t adj;                 // delta format B: sites whose right neighbour starts another site
+    uint32_t nstage;              // staged slot headers of a sparse pass (StageRec list)
+    uint32_t gap;                 // some slot other than the last holds < 3 ids: sparse passes visit every slot
+    uint32_t pad_[2];
 };
 
 // one per training iteration, written by the device into pinned host memory

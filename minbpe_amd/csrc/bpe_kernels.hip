@@ -36,6 +36,7 @@
 #include "kernels/k_merge.hip"
 #include "kernels/k_lookback.hip"
 #include "kernels/k_slots.hip"
+#include "kernels/k_slots2.hip"
 #include "kernels/k_table.hip"
 #include "kernels/k_dp.hip"
 #include "kernels/k_encode.hip"

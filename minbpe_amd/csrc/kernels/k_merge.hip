@@ -384,7 +384,9 @@ k_tile_scan(const uint64_t *__restrict__ tsum, uint64_t ntiles, uint64_t *__rest
 // own_len: the tile owns positions [0, own_len); words beyond are context only.
 // SKIP_UNCHANGED: do not store when no owned element changes (slotted streams:
 // the slot simply stays where it is).  *kept_out / *changed_out: block totals.
-template <bool DELTA, bool SKIP_UNCHANGED>
+// HL: layout behind hdr4 -- 0: {first three, last}; 1: a SlotHdr image {first three, (meta),
+// second-to-last, last} (k_slots2.hip; hdr4 may then point into LDS).
+template <bool DELTA, bool SKIP_UNCHANGED, int HL = 0>
 __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t a, uint32_t b,
                                              uint32_t newid, uint32_t *__restrict__ dst_tile,
                                              uint32_t *s_wsum, uint32_t *__restrict__ delta,
@@ -440,7 +442,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
 #pragma unroll
             for (int j = 0; j < MJ; j++) {
                 const uint32_t lo = wbase + ex[j], hi = lo + __popc(kb[j]);
-                if (kb[j] && (lo < 3 || hi == total)) {
+                if (kb[j] && (lo < 3 || (HL == 0 ? hi == total : hi + 1 >= total))) {
                     uint32_t gi = lo;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -448,7 +450,12 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                             const uint32_t w = t.x[j][k];
                             const uint32_t ow = ((mb[j] >> k) & 1u) ? (newid | (w & (FLAG | WMASK))) : w;
                             if (gi < 3) hdr4[gi] = ow;
-                            if (gi + 1 == total) hdr4[3] = ow;
+                            if (HL == 0) {
+                                if (gi + 1 == total) hdr4[3] = ow;
+                            } else {
+                                if (gi + 1 == total) hdr4[5] = ow;
+                                if (gi + 2 == total) hdr4[4] = ow;
+                            }
                             gi++;
                         }
                     }

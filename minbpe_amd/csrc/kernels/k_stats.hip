@@ -6,6 +6,7 @@
 
 #include "../bpe_device.h"
 #include "k_common.hip"
+#include "k_table.hip"
 
 namespace bpe {
 
@@ -158,24 +159,18 @@ k_pair_count_bytes(const uint32_t *__restrict__ ids, const DevState *__restrict_
 // ---------------------------------------------------------------------------
 // K2: pair = max(stats, key=stats.get)  (basic.py:35, regex.py:56)
 
-// one workgroup per row: rowmax[x] = max_y count[x][y]
+// one workgroup per row: rowmax[x] = max_y count[x][y], rowarg[x] = the column attaining it
+// (row_scan, k_table.hip; rowarg lives right behind rowmax: rowmax[stride + x])
 __global__ void __launch_bounds__(256)
-k_rowmax_all(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur,
-             uint32_t *__restrict__ rowmax) {
-    __shared__ uint32_t s_red[4];
+k_rowmax_all(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, uint32_t *__restrict__ rowmax) {
+    __shared__ unsigned long long s_red[8];
     const uint32_t x = blockIdx.x;
-    const uint32_t *row = mat + (size_t)x * stride;
-    uint32_t m = 0;
-    const uint32_t v4 = vcur & ~3u;
-    for (uint32_t y = threadIdx.x * 4; y < v4; y += 256 * 4) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(row + y);
-        m = max(max(m, q.x), max(max(q.y, q.z), q.w));
+    uint32_t m = 0, arg = 0;
+    row_scan(mat + (size_t)x * stride, vcur, -1, s_red, m, arg);
+    if (threadIdx.x == 0) {
+        rowmax[x] = m;
+        rowmax[stride + x] = arg;
     }
-    for (uint32_t y = v4 + threadIdx.x; y < vcur; y += 256) m = max(m, row[y]);
-    m = wave_max_u32(m);
-    if (lane_id() == 0) s_red[wave_id()] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
 }
 
 }  // namespace bpe

@@ -13,7 +13,10 @@ namespace bpe {
 // Thread t owns token t: column a, row b, the new column Z and the new row Z.
 // Rows whose maximum may have dropped are queued for k_rowmax_list; for every
 // other row the only entry that grew is the brand-new column Z.
-template <bool FOLDED>
+// FMTB: the a != b merge passes of the second slotted form (k_slots2.hip) write delta format B
+// -- vector 0 = SL (pairs (L,a) -> (L,Z)), vector 1 = SR (pairs (b,R) -> (Z,R)), st->adj = pairs
+// (b,a) -> (Z,Z) -- which expands to the four vectors here; a == b passes write format A.
+template <bool FOLDED, bool FMTB = false>
 __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t stride,
                                            uint32_t *__restrict__ delta, uint32_t vcap,
                                            uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
@@ -49,33 +52,44 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
     uint32_t acc4[4] = {0, 0, 0, 0};
     const uint32_t nrep = 1u << (vcap >> 24);
     vcap &= 0xFFFFFFu;
+    const bool fmtb = FMTB && a != b;
+    const int nv = fmtb ? 2 : 4;
     if (FOLDED) {
         if (live && g == 0) {
 #pragma unroll
             for (int v = 0; v < 4; v++) acc4[v] = delta[(size_t)v * vcap + t];
         }
     } else if (live) {
-        uint32_t x[4][4];
+        // lane g folds replicas g, g+8, ...: four of them (all their loads) in flight at a time
+        for (uint32_t r0 = g; r0 < nrep; r0 += 32) {
+            uint32_t x[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+            for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                const uint32_t r = g + 8u * k;
-                x[k][v] = (r < nrep) ? delta[((size_t)r * 4 + v) * vcap + t] : 0u;
-            }
+                for (int v = 0; v < 4; v++) {
+                    const uint32_t r = r0 + 8u * k;
+                    x[k][v] = (r < nrep && v < nv) ? delta[((size_t)r * 4 + v) * vcap + t] : 0u;
+                }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+            for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
-                if (x[k][v]) delta[((size_t)(g + 8u * k) * 4 + v) * vcap + t] = 0;
-                acc4[v] += x[k][v];
-            }
+                for (int v = 0; v < 4; v++) {
+                    if (x[k][v]) delta[((size_t)(r0 + 8u * k) * 4 + v) * vcap + t] = 0;
+                    acc4[v] += x[k][v];
+                }
+        }
     }
 #pragma unroll
     for (int v = 0; v < 4; v++) {
         acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 1);
         acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 2);
         acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 4);
+    }
+    if (fmtb) {
+        const uint32_t adj = st->adj;  // (reset by the next k_select)
+        acc4[2] = acc4[0];
+        acc4[3] = acc4[1] + (t == Z ? adj : 0u);
+        acc4[1] += (t == a ? adj : 0u);
     }
     if (!live || g != 0) return;
     const uint32_t dl = acc4[0], dr = acc4[1], il = acc4[2], ir = acc4[3];
@@ -89,42 +103,92 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
     if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
     if (dirty) {
         dirty_list[atomicAdd(dirty_n, 1u)] = t;
-    } else if (il > rowmax[t]) {
-        rowmax[t] = il;  // column Z was empty before this iteration
+    } else if (il) {
+        // column Z was empty before this iteration: it is the only entry of this row that grew
+        uint32_t *rowarg = rowmax + stride;
+        const uint32_t m = rowmax[t];
+        if (il > m) {
+            rowmax[t] = il;
+            rowarg[t] = Z;
+        } else if (il == m) {
+            rowarg[t] = ROWARG_MULTI;  // a second column attains the row maximum
+        }
     }
 }
 
-// Recompute rowmax for the queued rows; also retires the merged pair: after the
+// One workgroup scans one row of the table: its maximum, and WHICH column attains it
+// (rowarg = that column, or ROWARG_MULTI when several do) -- k_select then reads the tied pairs
+// straight from rowarg instead of re-scanning every row at the maximum.  16-byte loads (rows are
+// 256-byte aligned and padded with zero columns up to the stride).  zero_col >= 0: that entry
+// is retired (set to 0) on the way.  Returns the result to thread 0.
+__device__ __forceinline__ void row_scan(uint32_t *__restrict__ row, uint32_t ncols, int zero_col,
+                                         unsigned long long *s_red, uint32_t &m_out, uint32_t &arg_out) {
+    unsigned long long kf = 0, kl = 0;  // count << 32 | ~column  and  count << 32 | column
+    const uint32_t n4 = (ncols + 3) & ~3u;
+    for (uint32_t y = threadIdx.x * 4; y < n4; y += blockDim.x * 4) {
+        uint4 q = *reinterpret_cast<const uint4 *>(row + y);
+        if (zero_col >= 0 && (uint32_t)zero_col - y < 4u) {
+            const uint32_t k = (uint32_t)zero_col - y;
+            if (k == 0) q.x = 0; else if (k == 1) q.y = 0; else if (k == 2) q.z = 0; else q.w = 0;
+            row[zero_col] = 0;
+        }
+        const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (v[k]) {
+                const unsigned long long hi = (unsigned long long)v[k] << 32;
+                const unsigned long long f = hi | (0xFFFFFFFFu - (y + k)), l = hi | (y + k);
+                kf = f > kf ? f : kf;
+                kl = l > kl ? l : kl;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long of = __shfl_xor(kf, d), ol = __shfl_xor(kl, d);
+        kf = of > kf ? of : kf;
+        kl = ol > kl ? ol : kl;
+    }
+    __syncthreads();  // s_red may still be read by the previous row's thread 0
+    if (lane_id() == 0) {
+        s_red[2 * wave_id()] = kf;
+        s_red[2 * wave_id() + 1] = kl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++) {
+            kf = s_red[2 * w] > kf ? s_red[2 * w] : kf;
+            kl = s_red[2 * w + 1] > kl ? s_red[2 * w + 1] : kl;
+        }
+        m_out = (uint32_t)(kf >> 32);
+        const uint32_t cf = 0xFFFFFFFFu - (uint32_t)kf, cl = (uint32_t)kl;
+        arg_out = (m_out == 0) ? 0u : (cf == cl ? cf : ROWARG_MULTI);
+    }
+}
+
+// Recompute rowmax / rowarg for the queued rows; also retires the merged pair: after the
 // merge no (a,b) remains (F2), whatever the a == b bookkeeping left there.
 __device__ __forceinline__ void rowmax_body(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
                                             uint32_t *__restrict__ rowmax, const DevState *st,
                                             const uint32_t *__restrict__ dirty_list,
                                             const uint32_t *__restrict__ dirty_n, uint32_t first,
                                             uint32_t step) {
-    __shared__ uint32_t s_red[4];
+    __shared__ unsigned long long s_red[32];
     if (st->status) return;
     const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
     const uint32_t nd = *dirty_n;
     for (uint32_t i = first; i < nd; i += step) {
         const uint32_t x = dirty_list[i];
-        uint32_t *row = mat + (size_t)x * stride;
-        uint32_t m = 0;
-        for (uint32_t y = threadIdx.x; y < vnew; y += 256) {
-            uint32_t v = row[y];
-            if (x == a && y == b) {
-                v = 0;
-                row[y] = 0;
-            }
-            m = max(m, v);
+        uint32_t m = 0, arg = 0;
+        row_scan(mat + (size_t)x * stride, vnew, x == a ? (int)b : -1, s_red, m, arg);
+        if (threadIdx.x == 0) {
+            rowmax[x] = m;
+            rowmax[stride + x] = arg;
         }
-        m = wave_max_u32(m);
-        __syncthreads();
-        if (lane_id() == 0) s_red[wave_id()] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) rowmax[x] = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
     }
 }
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_rowmax_list(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vnew,
               uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
               const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
@@ -170,6 +234,48 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     __syncthreads();
     if (!s_ok) return;
     rowmax_body(mat, stride, Z + 1, rowmax, st, dirty_list, dirty_n, blockIdx.x - na, gridDim.x - na);
+}
+
+// Table update of the second slotted form: blocks [0, na) apply the delta vectors (format B for
+// a != b), blocks [na, grid) commit the headers a sparse merge pass staged (k_slots2.hip).
+__global__ void __launch_bounds__(256)
+k_apply2(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
+         uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z, uint32_t *__restrict__ dirty_list,
+         uint32_t *__restrict__ dirty_n, int par, IterRec *rec, int iter, uint32_t na,
+         SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage, uint32_t *__restrict__ removed,
+         uint32_t *__restrict__ smask, uint32_t nwords) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // ids removed by the merge pass: 256 counters (one would serialise every changed slot)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = removed[threadIdx.x * 4 + i];
+            if (x) removed[threadIdx.x * 4 + i] = 0;
+            v += x;
+        }
+        v = wave_sum_u32(v);
+        if (threadIdx.x == 0) st->removed = v;  // read by this same thread in apply_body
+    }
+    if (blockIdx.x < na) {
+        apply_body<false, true>(mat, stride, delta, vcap, rowmax, st, Z, dirty_list, dirty_n, par, rec, iter, 1);
+        return;
+    }
+    if (st->status) return;
+    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
+    const uint32_t step = (gridDim.x - na) * blockDim.x;
+    for (uint32_t w = (blockIdx.x - na) * blockDim.x + threadIdx.x; w < nwords; w += step) {
+        uint32_t m = smask[w];
+        if (!m) continue;
+        smask[w] = 0;
+        while (m) {
+            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const StageRec r = stage[t];
+            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
+            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
+            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+        }
+    }
 }
 
 }  // namespace bpe

@@ -79,6 +79,11 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->removed = 0;
     st->apply_done = 0;
     st->sel_flag = 0;
+    st->sel_tie = 0;
+    st->sel_done = 0;
+    st->adj = 0;
+    st->nstage = 0;
+    st->gap = 0;
 }
 
 }  // namespace bpe

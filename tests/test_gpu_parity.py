@@ -114,15 +114,31 @@ def test_train_golden_cases(golden, engine, native):
         assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
 
 
-@pytest.mark.parametrize("mode,mimpl,slots", [(0, 0, 0), (1, 0, 1), (1, 0, 0), (1, 1, 0), (0, 1, 0)])
-@pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
-                                    (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
-def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, k, n, nm):
-    rng = random.Random(k * 1000 + n)
-    data = bytes(97 + rng.randrange(k) for _ in range(n))
+# engine variants: (mode, merge impl, slots, sparse) -- slots 2 = the second slotted form (default);
+# sparse 2 = every a != b pass goes through the inverted index and the sparse kernel
+VARIANTS = [(0, 0, 0, 1), (1, 0, 1, 1), (1, 0, 0, 1), (1, 1, 0, 1), (0, 1, 0, 1), (1, 0, 2, 1), (1, 0, 2, 2),
+            (1, 0, 2, 0)]
+
+
+def set_variant(engine, mode, mimpl, slots, sparse):
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
     engine.set_option("slots", slots)
+    engine.set_option("sparse", sparse)
+
+
+def reset_variant(engine):
+    set_variant(engine, 1, 0, 2, 1)
+    engine.set_option("depth", 8)
+
+
+@pytest.mark.parametrize("mode,mimpl,slots,sparse", VARIANTS)
+@pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
+                                    (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
+def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, sparse, k, n, nm):
+    rng = random.Random(k * 1000 + n)
+    data = bytes(97 + rng.randrange(k) for _ in range(n))
+    set_variant(engine, mode, mimpl, slots, sparse)
     try:
         engine.load_bytes(data)
         exp = oracle.train(data, nm, raise_on_empty=False)
@@ -141,14 +157,12 @@ def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, k, n, nm):
             ids = oracle.merge(ids, p, 256 + i)
         assert np.array_equal(engine.read_ids(), ids)
     finally:
-        engine.set_option("mode", 1)
-        engine.set_option("merge", 0)
-        engine.set_option("slots", 1)
+        reset_variant(engine)
 
 
-@pytest.mark.parametrize("mode,mimpl,slots", [(0, 0, 0), (1, 0, 1), (1, 0, 0), (1, 1, 0)])
+@pytest.mark.parametrize("mode,mimpl,slots,sparse", [v for v in VARIANTS if v != (0, 1, 0, 1)])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots):
+def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, sparse):
     text = native.synth_text(2_000_000, 11)
     if kind == "basic":
         data, offs = text, None
@@ -156,12 +170,12 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots):
         data, offs = split_chunks(text.decode())
     nm = 400
     exp = oracle.train(data, nm, offs)
-    engine.set_option("mode", mode)
-    engine.set_option("merge", mimpl)
-    engine.set_option("slots", slots)
+    set_variant(engine, mode, mimpl, slots, sparse)
     try:
         engine.load_bytes(data, offs)
         res = engine.train(nm)
+        if sparse == 2:
+            assert engine.train_stats()["sparse"] == nm
         assert res["pairs"] == exp[0]
         assert res["counts"] == exp[1]
         assert res["lens"] == exp[2]
@@ -178,10 +192,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots):
             o = off_full[:-1]
         assert np.array_equal(engine.read_ids(), ids)
     finally:
-        engine.set_option("mode", 1)
-        engine.set_option("merge", 0)
-        engine.set_option("slots", 1)
-        engine.set_option("depth", 8)
+        reset_variant(engine)
 
 
 # ---------------------------------------------------------------------------
@@ -452,12 +463,14 @@ def test_train_fused_row_maxima_option(engine, native):
     data = native.synth_text(400_000, 61)
     exp = oracle.train(data, 200)
     engine.set_option("fused_rows", 1)
+    engine.set_option("slots", 1)  # (an option of the first slotted form's table update)
     try:
         engine.load_bytes(data)
         res = engine.train(200)
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
     finally:
         engine.set_option("fused_rows", 0)
+        engine.set_option("slots", 2)
 
 
 def test_train_invariant_at_scale(engine, native):

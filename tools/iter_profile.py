@@ -36,7 +36,7 @@ cnt = np.array(res["counts"])
 lens = np.array(res["lens"])
 same = np.array([a == b for a, b in res["pairs"]])
 out = {"workload": name, "options": sys.argv[2:], "total_ms": round(float(ms.sum()) / 1e3, 1),
-       "a_eq_b_merges": int(same.sum()),
+       "a_eq_b_merges": int(same.sum()), "passes": eng.train_stats(),
        "device_ms_by_class": {k: round(v["ms"], 1) for k, v in bd.items() if v["ms"]}, "bins": []}
 edges = [0, 10, 100, 300, 1000, 2000, 4000, 8000, 16000, 24000, nm]
 for lo, hi in zip(edges[:-1], edges[1:]):
