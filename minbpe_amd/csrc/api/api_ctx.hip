@@ -61,6 +61,7 @@ struct bpe_ctx {
     SlotHdr *d_hdr2[2] = {nullptr, nullptr};
     StageRec *d_stage = nullptr;              // staged headers of a sparse pass: stage[t] for slot t
     uint32_t *d_smask = nullptr;              // [slot / 32] which slots have a staged header
+    uint32_t *d_cand = nullptr;               // candidate slots of a sparse pass (made by k_select)
     uint32_t *d_idx = nullptr;                // inverted slot index [slot / 32][IDX_H]
     uint32_t *d_idx_dirty = nullptr;          // [slot / 32]: slots rewritten by a == b passes since the last build
     uint32_t *d_removed = nullptr;            // [256] removal counters of a merge pass
@@ -68,6 +69,7 @@ struct bpe_ctx {
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
+    int sparse_ratio = 2;                     // sparse pass when (count of the pair) * ratio < slots
     uint64_t last_count = ~0ull;              // count of the last merge the host has seen: an upper bound of the next ones
     uint64_t n_sparse = 0, n_dense = 0, n_index_builds = 0;  // passes of the last train() (bpe_train_stats)
     uint64_t cap_slots = 0;
@@ -205,6 +207,7 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_hdr2[1], nt));
         TRY(dev_realloc(c, c->d_stage, nt));
         TRY(dev_realloc(c, c->d_smask, nt / 32 + 2));
+        TRY(dev_realloc(c, c->d_cand, nt));
         HIPCHK(c, hipMemsetAsync(c->d_smask, 0, (nt / 32 + 2) * sizeof(uint32_t), c->stream));
         TRY(dev_realloc(c, c->d_slot_lens, nt));
         TRY(dev_realloc(c, c->d_slot_off, nt + 1));
@@ -401,7 +404,7 @@ SlotRefH stream_ref_h(const bpe_ctx *c) {
 
 // K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
 // this rank's candidate)
-int launch_select(bpe_ctx *c, bool rowmax_all) {
+int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     if (rowmax_all) {
         hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
@@ -410,14 +413,20 @@ int launch_select(bpe_ctx *c, bool rowmax_all) {
     }
     const uint64_t nslots = c->slotted ? c->slot_T : ntiles_of(c->n);
     const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nslots, TIE_BLOCKS));
+    CandArgs C;
+    C.idx = c->d_idx;
+    C.dirty = c->d_idx_dirty;
+    C.cand = c->d_cand;
+    C.T = (uint32_t)c->slot_T;
+    C.enable = sparse_next ? 1u : 0u;  // the block that makes the pair final lists the slots a sparse pass visits
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
-                           ++c->sel_epoch);
+                           ++c->sel_epoch, C);
     else
         hipLaunchKernelGGL(k_select<SlotRef>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref(c), c->par, c->dp_active ? 1 : 0,
-                           ++c->sel_epoch);
+                           ++c->sel_epoch, C);
     LAUNCHCHK(c, "k_select");
     TRY(prof_end(c));
     return BPE_OK;
@@ -666,10 +675,26 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
     return dstride | ((uint32_t)std::min(shift, want) << 24);
 }
 
+// Will this iteration's a != b pass be a sparse one?  It pays when the pair is rare enough that
+// most slots cannot hold it.  Decided (and the index brought up to date) BEFORE k_select, whose
+// deciding block makes the pass's candidate list.  (use_sparse == 2: every a != b pass is a
+// sparse one -- tests drive the sparse kernel and the index through streams of a few slots.)
+int plan_pass2(bpe_ctx *c, bool *sparse_out) {
+    const uint32_t T = (uint32_t)c->slot_T;
+    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 4 * SPARSE_GRID);
+    const bool sparse = can_index && (c->use_sparse == 2 || (c->last_count != ~0ull &&
+                                                             c->last_count * (uint64_t)c->sparse_ratio < T));
+    // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
+    // one go by, the index is rebuilt so that those marks do not pile up)
+    if (sparse && (!c->idx_live || c->idx_rebuild)) TRY(index_build(c));
+    *sparse_out = sparse;
+    return BPE_OK;
+}
+
 // one merge pass of the second slotted form + table update.  The host does not know the pair
 // (it runs `depth` merges ahead): the a != b kernel and the a == b kernel are both launched and
 // the one the pair does not call for returns at once.
-int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
+int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse) {
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
         HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
@@ -677,14 +702,6 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     }
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, newid);
-    // a sparse pass pays when the pair is rare enough that most slots cannot hold it
-    // (use_sparse == 2: every a != b pass is a sparse one -- tests drive the sparse kernel and the
-    // index through streams of a few slots with it)
-    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 4 * SPARSE_GRID);
-    const bool sparse = can_index && (c->use_sparse == 2 || (c->last_count != ~0ull && c->last_count * 3 < T));
-    // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
-    // one go by, the index is rebuilt so that those marks do not pile up)
-    if (sparse && (!c->idx_live || c->idx_rebuild)) TRY(index_build(c));
     AbArgs A;
     A.b0 = c->d_ids[0];
     A.b1 = c->d_ids[1];
@@ -698,14 +715,17 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
     A.delta = c->d_delta;
     A.vcap = dl;
     A.idx = c->idx_live ? c->d_idx : nullptr;
-    A.dirty = c->d_idx_dirty;
+    A.cand = c->d_cand;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
     if (sparse) {
         hipLaunchKernelGGL(k_merge_ab_sparse, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
         c->n_sparse++;
     } else {
-        hipLaunchKernelGGL(k_merge_ab_dense, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
+        if (A.idx)
+            hipLaunchKernelGGL(k_merge_ab_dense<true>, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
+        else
+            hipLaunchKernelGGL(k_merge_ab_dense<false>, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
         c->n_dense++;
     }
     LAUNCHCHK(c, "k_merge_ab");

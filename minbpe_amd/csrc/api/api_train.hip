@@ -118,10 +118,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                     TRY(slots_enter(c));
                 }
             }
-            TRY(launch_select(c, full_rowmax));
+            bool sparse = false;
+            if (c->slotted && c->slot2) TRY(plan_pass2(c, &sparse));
+            TRY(launch_select(c, full_rowmax, sparse));
             if (c->slotted && c->slot2) {
                 const int mq0 = c->mq;
-                TRY(launch_merge2(c, 256u + (uint32_t)i, i, c->h_rec));
+                TRY(launch_merge2(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = (uint8_t)(c->mq != mq0);
             } else if (c->slotted)
                 TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));

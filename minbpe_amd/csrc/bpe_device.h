@@ -97,7 +97,7 @@ struct DevState {
     uint32_t sel_tie;             // ... and whether a tie is open (every block then sweeps and takes a ticket)
     uint32_t sel_done;            // tickets of the sweeping blocks: the last one finalises the pair
     uint32_t adj;                 // delta format B: sites whose right neighbour starts another site
-    uint32_t nstage;              // staged slot headers of a sparse pass (StageRec list)
+    uint32_t ncand;               // slots in the candidate list of this iteration's sparse pass (k_select)
     uint32_t gap;                 // some slot other than the last holds < 3 ids: sparse passes visit every slot
     uint32_t pad_[2];
 };

@@ -6,6 +6,7 @@
 
 #include "../bpe_device.h"
 #include "k_common.hip"
+#include "k_index.hip"
 
 namespace bpe {
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
     const uint32_t *__restrict__ rowarg = rowmax + stride;
     // every thread keeps its share of rowmax in registers: the second look (which rows attain the
     // maximum) needs no second trip to memory
-    constexpr int RPT = 64;  // 64 x 1024 = the 65536-token limit of the table
+    constexpr int RPT = 32;  // 32 x 1024 rows in registers; rows beyond (vocab > 32768) are read twice
     uint32_t rm[RPT];
     uint32_t m = 0;
 #pragma unroll
@@ -106,6 +107,7 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
         rm[i] = (x < vcur) ? rowmax[x] : 0u;
         m = max(m, rm[i]);
     }
+    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) m = max(m, rowmax[x]);
     m = wave_max_u32(m);
     if (lane_id() == 0) s_red[wave_id()] = m;
     if (threadIdx.x == 0) {
@@ -129,23 +131,24 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
         }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < RPT; i++) {
-        const uint32_t x = threadIdx.x + 1024u * i;
-        if (rm[i] == M) {  // (M > 0, rows beyond vcur hold 0)
-            const uint32_t y = rowarg[x];
-            if (y != ROWARG_MULTI) {
-                const uint32_t s = atomicAdd(&s_nt, 1u);
-                if (s < TIE_CAP) {
-                    s_tied[2 * s] = (int32_t)x;
-                    s_tied[2 * s + 1] = (int32_t)y;
-                }
-            } else {
-                const uint32_t s = atomicAdd(&s_nrows, 1u);
-                if (s < ARGMAX_ROWS) s_rows[s] = x;
+    auto row_at_max = [&](uint32_t x) {
+        const uint32_t y = rowarg[x];
+        if (y != ROWARG_MULTI) {
+            const uint32_t s = atomicAdd(&s_nt, 1u);
+            if (s < TIE_CAP) {
+                s_tied[2 * s] = (int32_t)x;
+                s_tied[2 * s + 1] = (int32_t)y;
             }
+        } else {
+            const uint32_t s = atomicAdd(&s_nrows, 1u);
+            if (s < ARGMAX_ROWS) s_rows[s] = x;
         }
-    }
+    };
+#pragma unroll
+    for (int i = 0; i < RPT; i++)
+        if (rm[i] == M) row_at_max(threadIdx.x + 1024u * i);  // (M > 0, rows beyond vcur hold 0)
+    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024)
+        if (rowmax[x] == M) row_at_max(x);
     __syncthreads();
     const uint32_t nrows = s_nrows;
     if (nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
@@ -193,17 +196,18 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
 // ticket) makes the pair final in st (unless `dist`: a sharded stream only yields this rank's
 // candidate, the ranks compare positions).  One launch; block 0 never waits, so there is no
 // circular dependency whatever the residency.
+// The block that makes the pair final (block 0 when there is no tie, else the last sweeper) also
+// makes the candidate list of this iteration's sparse merge pass, when the host asked for one (C).
 template <class Ref>
 __global__ void __launch_bounds__(1024)
 k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-         uint32_t vcur, DevState *st, Ref ref, int par, int dist, uint32_t epoch) {
+         uint32_t vcur, DevState *st, Ref ref, int par, int dist, uint32_t epoch, CandArgs C) {
     __shared__ int32_t s_tied[2 * TIE_CAP];
-    __shared__ uint32_t s_go;
+    __shared__ uint32_t s_go, s_pair[3];
     __shared__ uint32_t s_bits[2048];  // tokens x with rowmax[x] == M (vocab <= 65536)
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
-            st->nstage = 0;  // (staged headers of the previous sparse pass were committed by its table update)
-            st->adj = 0;     // (... and its format-B "adjacent sites" count was folded into the table)
+            st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
             __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (st->status == 0) select_body(rowmax, mat, stride, vcur, st);
@@ -213,7 +217,12 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&st->sel_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_go = (st->status == 0 && st->sel_tie != 0);
+            s_pair[0] = (st->status == 0 && st->found != 0);
+            s_pair[1] = (uint32_t)st->a;
+            s_pair[2] = (uint32_t)st->b;
         }
+        __syncthreads();
+        if (C.enable && s_pair[0] && s_pair[1] != s_pair[2]) build_cand_list(C, st, s_pair[1], s_pair[2]);
     } else if (threadIdx.x == 0) {
         bool ok = false;
         for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
@@ -276,6 +285,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
+        s_pair[0] = 0;
         const uint32_t ticket = __hip_atomic_fetch_add(&st->sel_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ticket == gridDim.x - 1) {  // last sweeper: the minimum is final
             const unsigned long long p = __hip_atomic_load(&st->firstpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -286,9 +296,14 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
                 st->fin_a = st->a;
                 st->fin_b = st->b;
                 st->found = 1;
+                s_pair[0] = 1;
+                s_pair[1] = w0 & IDMASK;
+                s_pair[2] = w1 & IDMASK;
             }  // else: found stays 0 and the merge pass raises ST_INTERNAL
         }
     }
+    __syncthreads();
+    if (C.enable && s_pair[0] && s_pair[1] != s_pair[2]) build_cand_list(C, st, s_pair[1], s_pair[2]);
 }
 
 // The pair to merge as every kernel after K2 sees it: decided by k_select, or (sharded streams)

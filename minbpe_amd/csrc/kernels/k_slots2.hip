@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../bpe_device.h"
+#include "k_index.hip"
 #include "k_merge.hip"
 #include "k_lookback.hip"
 
@@ -44,26 +45,6 @@ namespace bpe {
 // turns them into the four vectors of format A (decL = incL = SL, decR = SR + adj at a,
 // incR = SR + adj at Z).
 
-// Inverted slot index (sparse passes): for every group of 32 slots, a Bloom filter of the PAIRS
-// its slots hold -- IDX_H buckets of 32 bits (bit s = slot 32*g + s), three hash functions.  A pair
-// belongs to the slot of its LEFT word (the boundary pair to the slot that ends with it), which
-// is also the slot that has to run a merge of that pair.
-constexpr uint32_t IDX_H = 32768;
-__device__ __forceinline__ void pair_hash(uint32_t x, uint32_t y, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
-    h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> 17;
-    h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> 17;
-    h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> 17;
-}
-__device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t owner, uint32_t x, uint32_t y) {
-    uint32_t h1, h2, h3;
-    pair_hash(x, y, h1, h2, h3);
-    uint32_t *row = idx + (size_t)(owner >> 5) * IDX_H;
-    const uint32_t bit = 1u << (owner & 31);
-    atomicOr(&row[h1], bit);
-    atomicOr(&row[h2], bit);
-    atomicOr(&row[h3], bit);
-}
-
 struct AbArgs {
     uint32_t *b0, *b1;        // the two id buffers
     const SlotHdr *hdr_in;    // headers as they stand before this pass
@@ -77,7 +58,7 @@ struct AbArgs {
     uint32_t *delta;          // [replica][4][vcap]
     uint32_t vcap;            // row stride | log2(replicas) << 24
     uint32_t *idx;            // inverted index [slot / 32][IDX_H] (bit = slot % 32), or nullptr
-    uint32_t *dirty;          // [slot / 32]: slots an a == b pass rewrote since the index was built
+    const uint32_t *cand;     // sparse: the slots to visit (st->ncand of them, from k_select)
     uint32_t *removed;        // [256] ids removed by this pass, spread over counters (t & 255): one
                               // counter would serialise every changed slot of a dense pass (~11 ns each)
     uint32_t *dirty_n;        // reset here for the table update that follows
@@ -116,11 +97,13 @@ k_slot2_init(SlotHdr *__restrict__ hdr, uint64_t T, DevState *st, int par, uint3
 __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hdr, uint32_t t, uint32_t T,
                                                   uint32_t *ctx) {
     uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
+    uint32_t tn = 0xFFFFFFFFu;  // the next non-empty slot
     int got = 0;
     for (uint32_t u = t + 1; u < T && got < 3; u++) {
         const SlotHdr hh = hdr[u];
         const uint32_t lu = hh.meta & 0x7FFFFFFFu;
         const uint32_t ww[3] = {hh.w0, hh.w1, hh.w2};
+        if (lu && tn == 0xFFFFFFFFu) tn = u;
         for (uint32_t i = 0; i < lu && i < 3 && got < 3; i++) h[got++] = ww[i];
     }
     uint32_t p1 = INVALID_WORD, p2 = INVALID_WORD, tp = 0xFFFFFFFFu;
@@ -148,12 +131,15 @@ __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hd
     ctx[3] = p2;
     ctx[4] = p1;
     ctx[5] = tp;
+    ctx[6] = tn;
 }
 
 // One slot of an a != b pass, by one 256-thread workgroup.  Returns to the caller in every case
 // (the sparse pass loops over slots); ends with all LDS reads of this slot done only after the
 // caller's next __syncthreads().
-template <bool SPARSE>
+// INDEXED: the inverted slot index is live and learns the pairs this pass creates (costs ~10
+// VGPRs; the early dense passes, which run before the index exists, use the variant without).
+template <bool SPARSE, bool INDEXED>
 __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const AbArgs &A, const uint32_t a,
                                               const uint32_t b) {
     const int lane = lane_id(), wave = wave_id(), tid = threadIdx.x;
@@ -200,6 +186,7 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
     uint32_t halo0 = S.hdr[4].x, halo1 = S.hdr[4].y, halo2 = S.hdr[4].z;
     uint32_t prev2 = S.hdr[1].x, prev1 = S.hdr[1].y;
     uint32_t tprev = t - 1;  // the slot that owns the word before mine (t == 0: none, and prev1 is invalid)
+    uint32_t tnext = t + 1;  // ... and the words after mine
     {
         const uint32_t nlen = S.hdr[4].w & 0x7FFFFFFFu, plen = S.hdr[0].w & 0x7FFFFFFFu;
         if ((t + 1 < A.T && nlen < 3) || (t > 0 && plen < 2)) {  // (uniform, rare)
@@ -211,6 +198,7 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
             prev2 = S.ctx[3];
             prev1 = S.ctx[4];
             tprev = S.ctx[5];
+            tnext = S.ctx[6];
         }
     }
     // ---- (3) my words: positions >= len come from the halo, then nothing -------------------
@@ -387,8 +375,13 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
                 const bool ltail = ((LL & IDMASK) == a) & ((L & NWMASK) == b);
                 if (!ltail) {
                     atomicAdd(&dl[L & IDMASK], wt);
-                    // the new pair (L, Z) belongs to the slot that holds L
-                    if (A.idx) index_add(A.idx, (wrel + j * 256 + lane * 4 + k) ? t : tprev, L & IDMASK, A.newid);
+                    // the new pair (L, Z) enters the filter of the slot that holds L, and mine too if
+                    // that is another slot (a boundary pair is known to both slots it touches: the
+                    // one that owns its site and the one that drops the site's second word)
+                    if (INDEXED) {
+                        index_add(A.idx, t, L & IDMASK, A.newid);
+                        if (wrel + j * 256 + lane * 4 + k == 0) index_add(A.idx, tprev, L & IDMASK, A.newid);
+                    }
                 }
             }
             const uint32_t R = W[k + 4], RR = W[k + 5];
@@ -396,7 +389,11 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
                 const bool rsite = ((R & IDMASK) == a) & ((RR & NWMASK) == b);
                 if (rsite) adj += wt;
                 else atomicAdd(&dr[R & IDMASK], wt);
-                if (A.idx) index_add(A.idx, t, A.newid, rsite ? A.newid : (R & IDMASK));
+                if (INDEXED) {
+                    const uint32_t y = rsite ? A.newid : (R & IDMASK);
+                    index_add(A.idx, t, A.newid, y);
+                    if (wrel + j * 256 + lane * 4 + k + 2 >= (int)len) index_add(A.idx, tnext, A.newid, y);
+                }
             }
         }
     }
@@ -407,10 +404,8 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
 }
 
 // dense a != b pass: one workgroup per slot
-#ifndef AB_DENSE_WAVES
-#define AB_DENSE_WAVES 7
-#endif
-__global__ void __launch_bounds__(MT, AB_DENSE_WAVES)
+template <bool INDEXED>
+__global__ void __launch_bounds__(MT, INDEXED ? 5 : 7)
 k_merge_ab_dense(AbArgs A) {
     __shared__ AbLds S;
     const DevState *st = A.st;
@@ -422,14 +417,17 @@ k_merge_ab_dense(AbArgs A) {
     }
     const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
     if (a == b) return;  // k_merge_aa's pass
-    merge_ab_tile<false>(S, blockIdx.x, A, a, b);
+    merge_ab_tile<false, INDEXED>(S, blockIdx.x, A, a, b);
 }
 
-// sparse a != b pass: a resident grid; workgroup g owns the slot groups [g*W, (g+1)*W) and visits
-// the slots whose Bloom filter admits the pair (they may own a site), the slots an a == b pass
-// rewrote since the index was built, and the slots whose first word is the `b` of a site that
-// starts at the previous slot's last word (read off the headers).
-__global__ void __launch_bounds__(MT)
+// sparse a != b pass: a resident grid works through the candidate list that the deciding block of
+// k_select made from the index (st->ncand slots in A.cand: every slot whose filter admits the
+// pair, plus the slots an a == b pass rewrote since the index was built; all slots while
+// st->gap is up) -- evenly dealt, so the pass ends when ceil(ncand / grid) tiles are done.
+#ifndef AB_SPARSE_WAVES
+#define AB_SPARSE_WAVES 4
+#endif
+__global__ void __launch_bounds__(MT, AB_SPARSE_WAVES)
 k_merge_ab_sparse(AbArgs A) {
     __shared__ AbLds S;
     const DevState *st = A.st;
@@ -441,45 +439,10 @@ k_merge_ab_sparse(AbArgs A) {
     }
     const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
     if (a == b) return;
-    const uint32_t nwords = (A.T + 31) / 32;
-    const uint32_t W = (nwords + gridDim.x - 1) / gridDim.x;
-    const uint32_t w0 = blockIdx.x * W, w1 = min(w0 + W, nwords);
-    uint32_t h1, h2, h3;
-    pair_hash(a, b, h1, h2, h3);
-    const int lane = lane_id();
-    for (uint32_t w = w0; w < w1; w++) {
-        // The candidate mask must be the SAME for every wave of the workgroup (the tile code is
-        // full of barriers), but other workgroups add bits to the index and may set st->gap while
-        // this one reads them: wave 0 decides, LDS hands its word to the others (two words used
-        // alternately, so one barrier per group is enough).
-        if (wave_id() == 0) {
-            uint32_t cand;
-            // short slots about: adjacency in slot numbers means nothing, visit everything
-            if (__hip_atomic_load(&st->gap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                cand = 0xFFFFFFFFu;
-            } else {
-                const uint32_t *row = A.idx + (size_t)w * IDX_H;
-                cand = (row[h1] & row[h2] & row[h3]) | A.dirty[w];
-                // carry into slot 32*w + lane
-                const uint32_t tt = w * 32 + (uint32_t)(lane & 31);
-                bool cy = false;
-                if (tt > 0 && tt < A.T)
-                    cy = ((A.hdr_in[tt - 1].l1 & IDMASK) == a) & ((A.hdr_in[tt].w0 & NWMASK) == b);
-                cand |= (uint32_t)__ballot(cy && lane < 32);
-            }
-            cand = lane_first(cand);
-            const uint32_t left = A.T - w * 32;
-            if (left < 32) cand &= (1u << left) - 1u;
-            if (lane == 0) S.ctx[6 + (w & 1u)] = cand;
-        }
+    const uint32_t n = st->ncand;
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        merge_ab_tile<true, true>(S, A.cand[i], A, a, b);
         __syncthreads();
-        uint32_t cand = S.ctx[6 + (w & 1u)];
-        while (cand) {
-            const uint32_t bit = (uint32_t)__ffs((int)cand) - 1u;
-            cand &= cand - 1u;
-            merge_ab_tile<true>(S, w * 32 + bit, A, a, b);
-            __syncthreads();
-        }
     }
 }
 
@@ -663,10 +626,11 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
             atomicAdd(&A.removed[t & 255u], (uint32_t)len - kept);
             if (kept < 3 && t + 1 < A.T) A.st->gap = 1;
             if (A.dirty) {
-                // its pairs changed, and so did the pair that ends at its first word, which belongs
-                // to the slot before: neither is in the index until the next build
+                // its pairs changed, and so did the boundary pairs it shares with both neighbours:
+                // none of that is in the index until the next build
                 atomicOr(&A.dirty[t >> 5], 1u << (t & 31));
                 if (t > 0) atomicOr(&A.dirty[(t - 1) >> 5], 1u << ((t - 1) & 31));
+                if (t + 1 < A.T) atomicOr(&A.dirty[(t + 1) >> 5], 1u << ((t + 1) & 31));
             }
         } else {
             keep_header();
@@ -730,6 +694,24 @@ k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, 
                 if ((uint32_t)k == d) x[k] = nxt;
         }
         const uint32_t bit = 1u << sl;
+        if (q == 0 && t > 0 && !(x[0] & FLAG)) {
+            // the pair that ends at my first word: it belongs to the slot before, but a merge of it
+            // removes my first word, so my filter knows it too
+            uint32_t pw = INVALID_WORD;
+            for (uint32_t u = t; u-- > 0;) {
+                if (hdr[u].meta & 0x7FFFFFFFu) {
+                    pw = hdr[u].l1;
+                    break;
+                }
+            }
+            if (pw != INVALID_WORD) {
+                uint32_t h1, h2, h3;
+                pair_hash(pw & IDMASK, x[0] & IDMASK, h1, h2, h3);
+                atomicOr(&s_mask[h1], bit);
+                atomicOr(&s_mask[h2], bit);
+                atomicOr(&s_mask[h3], bit);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (q + k < len && !(x[k + 1] & FLAG)) {

@@ -82,7 +82,7 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->sel_tie = 0;
     st->sel_done = 0;
     st->adj = 0;
-    st->nstage = 0;
+    st->ncand = 0;
     st->gap = 0;
 }
 
