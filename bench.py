@@ -202,8 +202,8 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     launches = max(hp["launches"], 1)
     roofline = {
         "bound": "hbm",
-        "kernel": {"merge": "merge pass (k_merge_*: merge + pair-table delta)", "pair_count": "k_pair_count",
-                   "widen": "k_widen"}[hot],
+        "kernel": {"merge": "merge pass = k_merge_ab_dense | k_merge_ab_sparse (a != b: merge + pair-table delta) "
+                            "+ k_merge_aa (a == b)", "pair_count": "k_pair_count", "widen": "k_widen"}[hot],
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4),
         "frac_of_measured_copy": round(achieved / HBM_COPY_GBPS, 4),
@@ -237,6 +237,7 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     out["merge_GBps"] = round(mg["alg_bytes"] / (mg["ms"] * 1e-3) / 1e9, 1) if mg["ms"] else None
     out["iter_GBps_wall"] = round(alg_bytes_step * steps / dt / 1e9, 1)
     out["device_ms_per_step"] = {k: round(v["ms"], 3) for k, v in breakdown.items() if v["ms"]}
+    out["merge_passes"] = eng.train_stats()  # dense / sparse passes, index builds of the last train()
     return out, data, offs, res
 
 

@@ -33,7 +33,7 @@ int bpe_create(int device_id, bpe_ctx **out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     c->own_stream = true;
-    for (const void *fn : {(const void *)k_pair_count_lds, (const void *)k_pair_count_bytes})
+    for (const void *fn : {(const void *)k_pair_count_lds, (const void *)k_pair_count_bytes, (const void *)k_pair_count_h32})
         if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS_BYTES)) != hipSuccess)
             return bail("hipFuncSetAttribute(dynamic LDS)", e);
     if ((e = hipFuncSetAttribute((const void *)k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -110,7 +110,7 @@ struct bpe_ctx {
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
     bool prof_active = false;
-    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache | 2 = 1 + dense 16-bit LDS table for byte streams
+    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache (8-byte slots) | 2 dense 16-bit LDS table for byte streams, 4-byte-slot LDS cache otherwise (weighted streams: as 1)
     bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
 
     std::vector<ProfEv> prof_open;
@@ -362,6 +362,11 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
         } else if (c->k1 == 2 && c->vcur <= 256 && c->stream_is_bytes && !c->weighted) {
             // (16-bit LDS counters: unit increments only)
             hipLaunchKernelGGL(k_pair_count_bytes, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
+                               dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
+                               c->par, c->d_mat, c->vcap);
+        } else if (c->k1 >= 2 && !c->weighted && c->vcap <= 65536) {
+            // (4-byte LDS slots with 15-bit counts: unit increments, ids below 2^16)
+            hipLaunchKernelGGL(k_pair_count_h32, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
                                dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
                                c->par, c->d_mat, c->vcap);
         } else {

@@ -101,10 +101,19 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     const uint32_t mask = (uint32_t)(hs - 1);
     // 4. one chunk per lane
     TRY(prof_begin(c, BPE_PROF_ENCODE, n));
-    hipLaunchKernelGGL(k_encode_short, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
-                       dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
-                       c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
-                       c->d_enc_long, d_nlong);
+    // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
+    bool narrow = M < 65535;
+    for (int32_t r = 0; narrow && merge_ids && r < M; r++) narrow = merge_ids[r] >= 0 && merge_ids[r] < 65536;
+    if (narrow)
+        hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
+                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
+                           c->d_enc_long, d_nlong);
+    else
+        hipLaunchKernelGGL(k_encode_short<uint32_t>, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
+                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
+                           c->d_enc_long, d_nlong);
     LAUNCHCHK(c, "k_encode_short");
     TRY(prof_end(c));
     unsigned long long n_long = 0;

@@ -36,14 +36,20 @@ __device__ __forceinline__ uint32_t rank_lookup(const unsigned long long *__rest
     }
 }
 
+// TT: storage type of the lane-private token / rank columns.  uint16_t when every id and rank
+// fits (vocabularies up to 65535: 32 KiB of LDS per workgroup, 5 workgroups per CU -- the kernel
+// is bound by the latency of the rank look-ups, so resident waves are what counts); uint32_t
+// otherwise (cl100k-sized rank tables: 64 KiB, 2 per CU).
+template <typename TT>
 __global__ void __launch_bounds__(ENC_THREADS)
 k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks,
                uint64_t n, const unsigned long long *__restrict__ keys,
                const uint32_t *__restrict__ vals, uint32_t mask, const int32_t *__restrict__ merge_ids,
                uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
                unsigned long long *__restrict__ long_list, unsigned long long *__restrict__ n_long) {
-    __shared__ uint32_t s_tok[ENC_LMAX * ENC_THREADS];
-    __shared__ uint32_t s_rk[ENC_LMAX * ENC_THREADS];
+    constexpr uint32_t NONE = (uint32_t)(TT)0xFFFFFFFFu;  // "no rank" in storage
+    __shared__ TT s_tok[ENC_LMAX * ENC_THREADS];
+    __shared__ TT s_rk[ENC_LMAX * ENC_THREADS];
     const uint64_t c = (uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x;
     if (c >= n_chunks) return;
     const uint64_t s0 = off[c];
@@ -58,13 +64,13 @@ k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ o
         long_list[atomicAdd(n_long, 1ull)] = c;
         return;
     }
-    uint32_t *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
-    uint32_t *rk = s_rk + threadIdx.x;
-    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = bytes[s0 + i];
+    TT *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
+    TT *rk = s_rk + threadIdx.x;
+    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = (TT)bytes[s0 + i];
     for (uint32_t i = 0; i + 1 < L; i++)
-        rk[i * ENC_THREADS] = rank_lookup(keys, vals, mask, tok[i * ENC_THREADS], tok[(i + 1) * ENC_THREADS]);
+        rk[i * ENC_THREADS] = (TT)rank_lookup(keys, vals, mask, tok[i * ENC_THREADS], tok[(i + 1) * ENC_THREADS]);
     while (L >= 2) {
-        uint32_t best = 0xFFFFFFFFu, bi = 0;
+        uint32_t best = NONE, bi = 0;
         for (uint32_t i = 0; i + 1 < L; i++) {
             const uint32_t r = rk[i * ENC_THREADS];
             if (r < best) {  // strict: leftmost occurrence of the lowest rank
@@ -72,8 +78,8 @@ k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ o
                 bi = i;
             }
         }
-        if (best == 0xFFFFFFFFu) break;  // nothing else can be merged
-        tok[bi * ENC_THREADS] = merge_ids ? (uint32_t)merge_ids[best] : 256u + best;
+        if (best == NONE) break;  // nothing else can be merged
+        tok[bi * ENC_THREADS] = (TT)(merge_ids ? (uint32_t)merge_ids[best] : 256u + best);
         for (uint32_t i = bi + 1; i + 1 < L; i++) {
             tok[i * ENC_THREADS] = tok[(i + 1) * ENC_THREADS];
             rk[i * ENC_THREADS] = rk[(i + 1) * ENC_THREADS];
@@ -81,10 +87,10 @@ k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ o
         L--;
         if (bi > 0)
             rk[(bi - 1) * ENC_THREADS] =
-                rank_lookup(keys, vals, mask, tok[(bi - 1) * ENC_THREADS], tok[bi * ENC_THREADS]);
+                (TT)rank_lookup(keys, vals, mask, tok[(bi - 1) * ENC_THREADS], tok[bi * ENC_THREADS]);
         if (bi + 1 < L)
             rk[bi * ENC_THREADS] =
-                rank_lookup(keys, vals, mask, tok[bi * ENC_THREADS], tok[(bi + 1) * ENC_THREADS]);
+                (TT)rank_lookup(keys, vals, mask, tok[bi * ENC_THREADS], tok[(bi + 1) * ENC_THREADS]);
     }
     for (uint32_t i = 0; i < L; i++) tmp[s0 + i] = tok[i * ENC_THREADS];
     outlen[c] = L;

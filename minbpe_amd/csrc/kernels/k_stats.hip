@@ -95,6 +95,81 @@ k_pair_count_lds(const uint32_t *__restrict__ ids, const DevState *__restrict__ 
     }
 }
 
+// k_pair_count_h32: the general histogram for unweighted streams (every pair counts 1).  Same
+// plan as k_pair_count_lds -- one 1024-thread workgroup per CU over a contiguous span, all of its
+// 128 KiB of LDS a cache, one flush -- with twice the slots: 32 Ki direct-mapped 4-byte slots,
+//     slot word = tag (17 bits) << 15 | count (15 bits),
+// where key = a << 16 | b is scrambled by an odd multiplier (a bijection of 32-bit words): the top
+// 15 bits choose the slot, the low 17 are the tag, so slot + tag give the key back exactly at the
+// flush.  A key that finds its slot taken by another goes straight to an L2 atomic.  A count that
+// crosses 2^14 is drained by the one thread whose add crossed it (adds to one address are totally
+// ordered), so 15 bits never overflow: at most 4096 adds are in flight in a workgroup.
+constexpr uint32_t H32_MUL = 0x9E3779B1u, H32_INV = 0x0E8B2F51u;  // MUL * INV == 1 (mod 2^32)
+static_assert((uint32_t)(H32_MUL * 0x0E8B2F51u) == 1u, "H32_INV is not the inverse of H32_MUL");
+__global__ void __launch_bounds__(PC_THREADS)
+k_pair_count_h32(const uint32_t *__restrict__ ids, const DevState *__restrict__ st, int par,
+                 uint32_t *__restrict__ mat, uint32_t stride) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pc[];  // 32768 slots
+    for (int i = threadIdx.x; i < 32768; i += PC_THREADS) s_pc[i] = 0;
+    __syncthreads();
+    const uint64_t n = st->n[par];
+    const uint64_t groups = (n + 3) / 4;
+    const uint64_t per_wg = (groups + gridDim.x - 1) / gridDim.x;
+    const uint64_t g0 = per_wg * blockIdx.x;
+    const uint64_t g1 = min(g0 + per_wg, groups);
+    constexpr int U = 2;  // 4-id groups per thread in flight
+    for (uint64_t gb = g0; gb < g1; gb += (uint64_t)U * PC_THREADS) {
+        uint4 v[U];
+        uint32_t nx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t g = gb + (uint64_t)u * PC_THREADS + threadIdx.x;
+            if (g < g1) {
+                v[u] = *reinterpret_cast<const uint4 *>(ids + g * 4);
+                nx[u] = ids[g * 4 + 4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint64_t g = gb + (uint64_t)u * PC_THREADS + threadIdx.x;
+            if (g >= g1) continue;
+            const uint64_t p = g * 4;
+            const uint32_t x[5] = {v[u].x, v[u].y, v[u].z, v[u].w, nx[u]};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (p + k + 1 >= n || (x[k + 1] & FLAG)) continue;
+                const uint32_t a = x[k] & IDMASK, b = x[k + 1] & IDMASK;
+                const uint32_t kk = ((a << 16) | b) * H32_MUL;
+                const uint32_t slot = kk >> 17, tag = kk & 0x1FFFFu;
+                uint32_t cur = __atomic_load_n(&s_pc[slot], __ATOMIC_RELAXED);
+                if (cur == 0) {
+                    const uint32_t old = atomicCAS(&s_pc[slot], 0u, (tag << 15) | 1u);
+                    if (old == 0) continue;
+                    cur = old;
+                }
+                if ((cur >> 15) == tag) {
+                    const uint32_t old = atomicAdd(&s_pc[slot], 1u);
+                    if (!(old & 0x4000u) && ((old + 1u) & 0x4000u)) {  // my add crossed 2^14: drain it
+                        atomicSub(&s_pc[slot], 0x4000u);
+                        atomicAdd(&mat[(size_t)a * stride + b], 0x4000u);
+                    }
+                } else {
+                    atomicAdd(&mat[(size_t)a * stride + b], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32768; i += PC_THREADS) {
+        const uint32_t w = s_pc[i];
+        const uint32_t c = w & 0x7FFFu;
+        if (c) {
+            const uint32_t key = (((uint32_t)i << 17) | (w >> 15)) * H32_INV;
+            atomicAdd(&mat[(size_t)(key >> 16) * stride + (key & 0xFFFFu)], c);
+        }
+    }
+}
+
 // k_pair_count_bytes: get_stats of a freshly widened stream (every id < 256) --
 // the one full histogram a delta-mode train() runs.  The whole 256 x 256 table
 // fits in LDS as 16-bit counters (two per word, 128 KiB): one ds_add per

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Pair-count (get_stats) kernels on a fixed stream: GB/s of ids read (4 B each)."""
-import sys, os
+"""Pair-count (get_stats) kernels on a fixed stream: GB/s of ids read (4 B each), on the byte
+stream and mid-training (after 512 and 3840 merges of cfg2: vocab 768 / 4096)."""
+import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import minbpe_amd
@@ -10,27 +11,33 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 data = minbpe_amd.synth_text(n, 1)
 eng = Engine(0)
 eng.set_option("profile", 2)
+out = []
+
+
+def measure(label):
+    ref = None
+    for k1, name in ((0, "one L2 atomic per position"), (1, "LDS cache, 16 Ki 8-byte slots, 4 probes"),
+                     (2, "default (dense 16-bit LDS table on bytes, else 32 Ki 4-byte slots)")):
+        eng.set_option("k1", k1)
+        ts = []
+        for r in range(reps):
+            eng.prof_reset()
+            res = eng.argmax()
+            ts.append(eng.prof_read()["pair_count"]["ms"])
+        ref = ref or res
+        assert res == ref, (res, ref)
+        t = float(np.median(ts))
+        m = len(eng)
+        out.append({"stream": label, "ids": m, "k1": k1, "kernel": name, "median_us": round(t * 1e3, 1),
+                    "GBps": round(4 * m / t / 1e6, 1)})
+        print(out[-1], flush=True)
+
+
 eng.load_bytes(data)
-ref = None
-for k1, label in ((0, "one L2 atomic per position"), (1, "LDS hash cache"), (2, "dense 16-bit LDS table (byte stream)")):
-    eng.set_option("k1", k1)
+measure("bytes")
+for nm in (512, 3840):
+    eng.set_option("k1", 2)
     eng.load_bytes(data)
-    ts = []
-    for r in range(reps):
-        eng.prof_reset()
-        pair, cnt = eng.argmax()
-        ts.append(eng.prof_read()["pair_count"]["ms"])
-    if ref is None: ref = (pair, cnt)
-    assert (pair, cnt) == ref
-    t = np.median(ts)
-    print(f"k1={k1} {label:40s} n={n}: median {t*1e3:9.1f} us  {4*n/t/1e6:8.1f} GB/s", flush=True)
-# after some merges (ids >= 256): general kernel only
-eng.set_option("k1", 2); eng.set_option("mode", 1)
-eng.load_bytes(data); eng.train(512)
-for k1 in (0, 1):
-    eng.set_option("k1", k1)
-    ts = []
-    for r in range(reps):
-        eng.prof_reset(); res = eng.argmax(); ts.append(eng.prof_read()["pair_count"]["ms"])
-    m = len(eng)
-    print(f"k1={k1} after 512 merges n={m}: median {np.median(ts)*1e3:9.1f} us  {4*m/np.median(ts)/1e6:8.1f} GB/s  argmax={res}", flush=True)
+    eng.train(nm)
+    measure(f"after {nm} merges")
+print(json.dumps(out))
