@@ -62,13 +62,16 @@ struct bpe_ctx {
     StageRec *d_stage = nullptr;              // staged headers of a sparse pass: stage[t] for slot t
     uint32_t *d_smask = nullptr;              // [slot / 32] which slots have a staged header
     uint32_t *d_cand = nullptr;               // candidate slots of a sparse pass (made by k_select)
-    uint32_t *d_idx = nullptr;                // inverted slot index [slot / 32][IDX_H]
+    uint32_t *d_idx = nullptr;                // inverted slot index [IDX_H][idx_cap_words] (bucket-major)
+    uint32_t *d_idx_tmp = nullptr;            // group-major image the build kernel writes, transposed into d_idx
     uint32_t *d_idx_dirty = nullptr;          // [slot / 32]: slots rewritten by a == b passes since the last build
     uint32_t *d_removed = nullptr;            // [256] removal counters of a merge pass
     uint64_t idx_cap_words = 0;               // index groups allocated
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
+    int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
+    int tie_index = 1;                        // break ties through the index when it is live (0: always sweep)
     int sparse_ratio = 2;                     // sparse pass when (count of the pair) * ratio < slots
     uint64_t last_count = ~0ull;              // count of the last merge the host has seen: an upper bound of the next ones
     uint64_t n_sparse = 0, n_dense = 0, n_index_builds = 0;  // passes of the last train() (bpe_train_stats)
@@ -422,8 +425,11 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     C.idx = c->d_idx;
     C.dirty = c->d_idx_dirty;
     C.cand = c->d_cand;
+    C.stride = (uint32_t)c->idx_cap_words;
     C.T = (uint32_t)c->slot_T;
     C.enable = sparse_next ? 1u : 0u;  // the block that makes the pair final lists the slots a sparse pass visits
+    C.tie_index = (c->slotted && c->slot2 && c->idx_live && c->tie_index) ? 1u : 0u;
+    C.tie_window = c->tie_window ? 1u : 0u;
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
@@ -608,15 +614,21 @@ int index_build(bpe_ctx *c) {
         if (c->d_idx_dirty) HIPCHK(c, hipFree(c->d_idx_dirty));
         c->d_idx = c->d_idx_dirty = nullptr;
         const uint64_t cap = nwords + 1;
+        if (c->d_idx_tmp) HIPCHK(c, hipFree(c->d_idx_tmp));
+        c->d_idx_tmp = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * IDX_H * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_idx_tmp, cap * IDX_H * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void **)&c->d_idx_dirty, cap * sizeof(uint32_t)));
         c->idx_cap_words = cap;
     }
     if (nwords) {
         hipLaunchKernelGGL(k_index_build, dim3((unsigned)nwords), dim3(1024), (size_t)IDX_H * 4, c->stream,
-                           c->d_ids[0], c->d_ids[1], c->d_hdr2[c->mq], (uint32_t)c->slot_T, c->d_idx,
+                           c->d_ids[0], c->d_ids[1], c->d_hdr2[c->mq], (uint32_t)c->slot_T, c->d_idx_tmp,
                            c->d_idx_dirty);
         LAUNCHCHK(c, "k_index_build");
+        hipLaunchKernelGGL(k_index_transpose, dim3((unsigned)((nwords + 31) / 32), IDX_H / 32), dim3(256), 0,
+                           c->stream, c->d_idx_tmp, (uint32_t)nwords, c->d_idx, (uint32_t)c->idx_cap_words);
+        LAUNCHCHK(c, "k_index_transpose");
     }
     c->idx_live = true;
     c->idx_rebuild = false;
@@ -720,6 +732,7 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     A.delta = c->d_delta;
     A.vcap = dl;
     A.idx = c->idx_live ? c->d_idx : nullptr;
+    A.istride = (uint32_t)c->idx_cap_words;
     A.cand = c->d_cand;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;

@@ -32,7 +32,7 @@ constexpr int PC_THREADS = 1024;
 constexpr int PC_LDS_BYTES = 131072;
 constexpr int PCB_ROUND = 61440;  // byte-stream kernel: positions between flushes (< 65536)
 
-constexpr int TIE_CAP = 32;        // tied pairs carried explicitly; more -> table lookup
+constexpr int TIE_CAP = 96;        // tied pairs carried explicitly; more -> table lookup
 constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_select
 constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches alone on a tie (0: all blocks sweep together)
 constexpr int TIE_BLOCKS = 256;     // k_select blocks: block 0 decides, all of them sweep the stream on a tie
@@ -93,13 +93,17 @@ struct DevState {
     int32_t fin_a, fin_b;         // the pair as finalised by the merge pass (read by k_apply_delta)
     unsigned long long removed;   // slotted merge: ids removed by the current pass
     unsigned long long apply_done;  // k_apply_delta blocks finished (monotonic; row blocks wait on it)
-    uint32_t sel_flag;            // k_select: block 0 publishes its decision to the tie-break blocks
     uint32_t sel_tie;             // ... and whether a tie is open (every block then sweeps and takes a ticket)
     uint32_t sel_done;            // tickets of the sweeping blocks: the last one finalises the pair
     uint32_t adj;                 // delta format B: sites whose right neighbour starts another site
     uint32_t ncand;               // slots in the candidate list of this iteration's sparse pass (k_select)
     uint32_t gap;                 // some slot other than the last holds < 3 ids: sparse passes visit every slot
-    uint32_t pad_[2];
+    uint32_t pad_[3];
+    // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
+    // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
+    // front of block 0's own accesses to the fields above.
+    alignas(128) uint32_t sel_flag;
+    uint32_t pad_flag_[31];
 };
 
 // one per training iteration, written by the device into pinned host memory

@@ -12,22 +12,25 @@ namespace bpe {
 
 // Inverted slot index (sparse passes): for every group of 32 slots, a Bloom filter of the PAIRS
 // its slots hold -- IDX_H buckets of 32 bits (bit s = slot 32*g + s), three hash functions.  A pair
-// belongs to the slot of its LEFT word (the boundary pair to the slot that ends with it), which
-// is also the slot that has to run a merge of that pair.
+// belongs to the slot of its LEFT word; a boundary pair is known to both slots it touches (the one
+// that owns its site and the one that drops the site's second word).
+// Layout: bucket-major, idx[h * stride + g].  A query reads the three bucket rows of one pair --
+// contiguous, so that the single block that lists a pass's candidates (below) or breaks a tie
+// (k_select) streams a few KB instead of touching one cache line per group.
 constexpr uint32_t IDX_H = 32768;
 __device__ __forceinline__ void pair_hash(uint32_t x, uint32_t y, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
     h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> 17;
     h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> 17;
     h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> 17;
 }
-__device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t owner, uint32_t x, uint32_t y) {
+__device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t stride, uint32_t owner, uint32_t x,
+                                          uint32_t y) {
     uint32_t h1, h2, h3;
     pair_hash(x, y, h1, h2, h3);
-    uint32_t *row = idx + (size_t)(owner >> 5) * IDX_H;
-    const uint32_t bit = 1u << (owner & 31);
-    atomicOr(&row[h1], bit);
-    atomicOr(&row[h2], bit);
-    atomicOr(&row[h3], bit);
+    const uint32_t g = owner >> 5, bit = 1u << (owner & 31);
+    atomicOr(&idx[(size_t)h1 * stride + g], bit);
+    atomicOr(&idx[(size_t)h2 * stride + g], bit);
+    atomicOr(&idx[(size_t)h3 * stride + g], bit);
 }
 
 // The candidate list of a sparse pass, made by ONE 1024-thread block (the block of k_select
@@ -36,8 +39,11 @@ __device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t o
 struct CandArgs {
     const uint32_t *idx, *dirty;
     uint32_t *cand;
+    uint32_t stride;     // of the index rows (groups allocated)
     uint32_t T;
-    uint32_t enable;  // 0: this iteration's a != b pass is a dense one
+    uint32_t enable;     // 0: this iteration's a != b pass is a dense one
+    uint32_t tie_index;  // the index is live: block 0 of k_select breaks ties through it
+    uint32_t tie_window; // block 0 first looks through the first TIE_WIN slots by itself (experiment)
 };
 __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st, uint32_t a, uint32_t b) {
     __shared__ uint32_t s_wtot[16];
@@ -48,20 +54,25 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
     const bool all = st->gap != 0;  // short slots about: adjacency in slot numbers means nothing, visit everything
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nwords; base += 1024) {
-        const uint32_t w = base + threadIdx.x;
-        uint32_t m = 0;
-        if (w < nwords) {
-            if (all) {
-                m = 0xFFFFFFFFu;
-            } else {
-                const uint32_t *row = C.idx + (size_t)w * IDX_H;
-                m = (row[h1] & row[h2] & row[h3]) | C.dirty[w];
+    // two groups per thread per round (all their loads in flight together): 65536 slots a round
+    for (uint32_t base = 0; base < nwords; base += 2048) {
+        uint32_t m[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t w = base + 2 * threadIdx.x + u;
+            m[u] = 0;
+            if (w < nwords) {
+                if (all) {
+                    m[u] = 0xFFFFFFFFu;
+                } else {
+                    m[u] = (C.idx[(size_t)h1 * C.stride + w] & C.idx[(size_t)h2 * C.stride + w] &
+                            C.idx[(size_t)h3 * C.stride + w]) | C.dirty[w];
+                }
+                const uint32_t left = C.T - w * 32;
+                if (left < 32) m[u] &= (1u << left) - 1u;
             }
-            const uint32_t left = C.T - w * 32;
-            if (left < 32) m &= (1u << left) - 1u;
         }
-        const uint32_t c = (uint32_t)__popc(m);
+        const uint32_t c = (uint32_t)(__popc(m[0]) + __popc(m[1]));
         const uint32_t inc = wave_iscan_add(c);
         if (lane_id() == 63) s_wtot[wave_id()] = inc;
         __syncthreads();
@@ -71,9 +82,14 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
             if (v < wave_id()) off += x;
             tot += x;
         }
-        while (m) {
-            C.cand[off++] = w * 32 + (uint32_t)__ffs((int)m) - 1u;
-            m &= m - 1u;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t w = base + 2 * threadIdx.x + u;
+            uint32_t mm = m[u];
+            while (mm) {
+                C.cand[off++] = w * 32 + (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1u;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) s_base += tot;

@@ -90,24 +90,24 @@ __device__ __forceinline__ void view_slot(const SlotRefH &r, uint64_t, uint64_t 
 // several columns (ROWARG_MULTI) is scanned.
 __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
                                             const uint32_t *__restrict__ mat, uint32_t stride,
-                                            uint32_t vcur, DevState *st) {
+                                            uint32_t vcur, DevState *st, int32_t *s_tied, uint32_t *s_bits) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
-    __shared__ int32_t s_tied[2 * TIE_CAP];
-    const uint32_t *__restrict__ rowarg = rowmax + stride;
-    // every thread keeps its share of rowmax in registers: the second look (which rows attain the
+    // rowmax[2x] = maximum of row x, rowmax[2x + 1] = the column that attains it (same cache line);
+    // every thread keeps its share in registers: the second look (which rows attain the
     // maximum) needs no second trip to memory
+    const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
     constexpr int RPT = 32;  // 32 x 1024 rows in registers; rows beyond (vocab > 32768) are read twice
     uint32_t rm[RPT];
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         const uint32_t x = threadIdx.x + 1024u * i;
-        rm[i] = (x < vcur) ? rowmax[x] : 0u;
+        rm[i] = (x < vcur) ? rowma[x].x : 0u;
         m = max(m, rm[i]);
     }
-    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) m = max(m, rowmax[x]);
+    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) m = max(m, rowma[x].x);
     m = wave_max_u32(m);
     if (lane_id() == 0) s_red[wave_id()] = m;
     if (threadIdx.x == 0) {
@@ -131,8 +131,8 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
         }
         return;
     }
-    auto row_at_max = [&](uint32_t x) {
-        const uint32_t y = rowarg[x];
+    auto row_at_max = [&](uint32_t x, uint32_t y) {
+        atomicOr(&s_bits[x >> 5], 1u << (x & 31));  // (zeroed by the caller; read only if a tie is open)
         if (y != ROWARG_MULTI) {
             const uint32_t s = atomicAdd(&s_nt, 1u);
             if (s < TIE_CAP) {
@@ -146,9 +146,12 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
     };
 #pragma unroll
     for (int i = 0; i < RPT; i++)
-        if (rm[i] == M) row_at_max(threadIdx.x + 1024u * i);  // (M > 0, rows beyond vcur hold 0)
-    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024)
-        if (rowmax[x] == M) row_at_max(x);
+        if (rm[i] == M)  // (M > 0, rows beyond vcur hold 0; the column sits in the cache line just read)
+            row_at_max(threadIdx.x + 1024u * i, rowma[threadIdx.x + 1024u * i].y);
+    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) {
+        const uint2 v = rowma[x];
+        if (v.x == M) row_at_max(x, v.y);
+    }
     __syncthreads();
     const uint32_t nrows = s_nrows;
     if (nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
@@ -188,6 +191,176 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
     }
 }
 
+// Tie-break through the inverted slot index (second slotted form, index live, no short slots, at
+// most TIE_CAP tied pairs): block 0 finds the earliest occurrence of every tied pair by itself --
+// wave v takes pairs v, v + 16, ...: the filter rows of the pair's three hashes give the slots that
+// may hold it, in stream order; the wave scans each such slot (2048 words per round trip) until it
+// finds the pair -- and the lowest position wins.  No other block, no hand-off.  Returns
+// position << 7 | pair index (NOPOS: not found, the caller falls back to the sweep).
+__device__ __forceinline__ unsigned long long slot_find_pair(const SlotRefH &ref, uint32_t t, uint32_t x, uint32_t y) {
+    const int lane = lane_id();
+    // this slot's header and the next one's, issued together (the caller made sure no slot is
+    // short or empty: st->gap == 0, so the word after the slot is the next slot's first)
+    const uint32_t m = ref.hdr[t].meta;
+    const uint32_t after = (t + 1 < ref.T) ? ref.hdr[t + 1].w0 : INVALID_WORD;
+    const uint32_t len = m & 0x7FFFFFFFu;
+    if (len == 0) return NOPOS;
+    const uint32_t *src = ((m >> 31) ? ref.b1 : ref.b0) + (size_t)t * TILE;
+    constexpr int SB = 8;  // stripes of 256 words per batch
+    for (uint32_t base = 0; base < len; base += SB * 256) {
+        uint4 v[SB];
+        uint32_t nx[SB];
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+            const uint32_t q = base + j * 256 + lane * 4;
+            v[j] = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD);
+            nx[j] = INVALID_WORD;
+            if (q < len) {
+                v[j] = *reinterpret_cast<const uint4 *>(src + q);
+                if (q + 4 < len) nx[j] = src[q + 4];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+            const uint32_t q = base + j * 256 + lane * 4;
+            uint32_t w[5] = {v[j].x, v[j].y, v[j].z, v[j].w, nx[j]};
+            uint32_t hit = 4;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) {
+                if (q + k < len) {
+                    const uint32_t nxt = (q + k + 1 < len) ? w[k + 1] : after;
+                    if ((w[k] & IDMASK) == x && (nxt & NWMASK) == y) hit = k;
+                }
+            }
+            const unsigned long long bal = __ballot(hit < 4);
+            if (bal) {
+                const int fl = __ffsll((long long)bal) - 1;
+                const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)hit, fl);
+                return (unsigned long long)t * TILE + base + j * 256 + fl * 4 + hk;
+            }
+        }
+    }
+    return NOPOS;
+}
+
+__device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, const CandArgs &C,
+                                                          const int32_t *s_tied, uint32_t nt) {
+    __shared__ unsigned long long s_best;
+    if (threadIdx.x == 0) s_best = NOPOS;
+    __syncthreads();
+    const int lane = lane_id();
+    const uint32_t nwords = (C.T + 31) / 32;
+    for (uint32_t p = wave_id(); p < nt; p += 16) {
+        const uint32_t x = (uint32_t)s_tied[2 * p], y = (uint32_t)s_tied[2 * p + 1];
+        uint32_t h1, h2, h3;
+        pair_hash(x, y, h1, h2, h3);
+        unsigned long long found = NOPOS;
+        bool done = false;
+        for (uint32_t wb = 0; wb < nwords && !done; wb += 64) {
+            if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)wb * 32 * TILE) break;  // cannot win
+            const uint32_t w = wb + lane;
+            uint32_t mk = 0;
+            if (w < nwords) {
+                mk = (C.idx[(size_t)h1 * C.stride + w] & C.idx[(size_t)h2 * C.stride + w] &
+                      C.idx[(size_t)h3 * C.stride + w]) | C.dirty[w];
+                const uint32_t left = C.T - w * 32;
+                if (left < 32) mk &= (1u << left) - 1u;
+            }
+            unsigned long long bal = __ballot(mk != 0);
+            while (bal && !done) {
+                const int lw = __ffsll((long long)bal) - 1;
+                bal &= bal - 1;
+                uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mk, lw);
+                while (mm) {
+                    const uint32_t t = (wb + lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
+                    mm &= mm - 1u;
+                    if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)t * TILE) {
+                        done = true;  // another pair already occurs before this slot
+                        break;
+                    }
+                    const unsigned long long pos = slot_find_pair(ref, t, x, y);
+                    if (pos != NOPOS) {
+                        found = pos;
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+        if (found != NOPOS && lane == 0) atomicMin(&s_best, (found << 7) | p);  // (p < TIE_CAP <= 128)
+    }
+    __syncthreads();
+    return s_best;  // position << 7 | index of the pair in s_tied
+}
+// (the contiguous / first-form views have no index: never called)
+__device__ __forceinline__ unsigned long long tie_by_index(const SlotRef &, const CandArgs &, const int32_t *,
+                                                          uint32_t) {
+    return NOPOS;
+}
+
+// Tie-break, first resort: block 0 looks through the first TIE_WIN slots of the stream by itself.
+// With many pairs tied (late in training: dozens) one of them almost surely occurs that early,
+// and a hit inside the window is final -- every position beyond it is later.  One round trip for
+// the window's headers, one for its words (16-byte loads, all in flight together).  Returns
+// position << 32 | a << 16 | b  (NOPOS: no tied pair in the window).
+constexpr int TIE_WIN = 8;
+template <class Ref>
+__device__ __forceinline__ unsigned long long tie_window(const Ref &ref, uint64_t n, const uint32_t *s_bits,
+                                                         const int32_t *s_tied, uint32_t nt, uint32_t M,
+                                                         const uint32_t *__restrict__ mat, uint32_t stride) {
+    __shared__ unsigned long long s_win;
+    if (threadIdx.x == 0) s_win = NOPOS;
+    __syncthreads();
+    const uint32_t nslots = (uint32_t)min((uint64_t)TIE_WIN, view_slots(ref, n));
+    uint32_t len[TIE_WIN];
+    const uint32_t *src[TIE_WIN];
+#pragma unroll
+    for (int u = 0; u < TIE_WIN; u++) {
+        len[u] = 0;
+        src[u] = nullptr;
+        if ((uint32_t)u < nslots) view_slot(ref, n, (uint64_t)u, len[u], src[u]);
+    }
+    uint4 v[TIE_WIN];
+    uint32_t nx[TIE_WIN];
+    const uint32_t q = threadIdx.x * 4;
+#pragma unroll
+    for (int u = 0; u < TIE_WIN; u++) {
+        v[u] = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD);
+        nx[u] = INVALID_WORD;
+        if (q < len[u]) {
+            v[u] = *reinterpret_cast<const uint4 *>(src[u] + q);
+            if (q + 4 < len[u]) nx[u] = src[u][q + 4];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < TIE_WIN; u++) {
+        if (q >= len[u]) continue;
+        const uint32_t w[5] = {v[u].x, v[u].y, v[u].z, v[u].w, nx[u]};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (q + k >= len[u]) break;
+            uint32_t w1 = w[k + 1];
+            if (q + k + 1 >= len[u] && !slot_next(ref, n, (uint64_t)u * TILE + q + k, w1)) continue;  // (last word of the slot)
+            if (w1 & FLAG) continue;
+            const uint32_t x = w[k] & IDMASK, y = w1 & IDMASK;
+            if (!((s_bits[x >> 5] >> (x & 31)) & 1u)) continue;
+            bool hit = false;
+            if (nt <= TIE_CAP) {
+                for (uint32_t t = 0; t < nt; t++)
+                    hit |= (s_tied[2 * t] == (int32_t)x) & (s_tied[2 * t + 1] == (int32_t)y);
+            } else {
+                hit = mat[(size_t)x * stride + y] == M;
+            }
+            if (hit) {
+                atomicMin(&s_win, ((unsigned long long)((uint64_t)u * TILE + q + k) << 32) | (x << 16) | y);
+                break;  // (my later positions are later)
+            }
+        }
+    }
+    __syncthreads();
+    return s_win;
+}
+
 // K2 kernel.  Block 0 decides (select_body); the other blocks wait for its decision (one flag,
 // agent-scope release/acquire -- cdna_hip_programming.md G16) and, only if a tie is open, ALL
 // blocks sweep the stream front to back, slot by slot (block k takes slots k, k + grid, ...;
@@ -210,13 +383,61 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
             __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (st->status == 0) select_body(rowmax, mat, stride, vcur, st);
+        for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;
         __syncthreads();
+        if (st->status == 0) select_body(rowmax, mat, stride, vcur, st, s_tied, s_bits);
+        __syncthreads();
+        if (threadIdx.x == 0) {  // (thread 0 wrote these fields itself; the block gets them through LDS)
+            s_pair[0] = (!dist && st->status == 0 && st->sel_tie != 0);
+            s_pair[1] = st->ntied;
+            s_pair[2] = st->count;
+        }
+        __syncthreads();
+        if (s_pair[0] && C.tie_window) {
+            // a tie: the first slots of the stream, by this block alone
+            const unsigned long long key = tie_window(ref, st->n[par], s_bits, s_tied, s_pair[1], s_pair[2], mat, stride);
+            if (threadIdx.x == 0 && key != NOPOS) {
+                st->a = (int32_t)((key >> 16) & 0xFFFFu);
+                st->b = (int32_t)(key & 0xFFFFu);
+                st->fin_a = st->a;
+                st->fin_b = st->b;
+                st->firstpos = key >> 32;
+                st->found = 1;
+                st->sel_tie = 0;
+            }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&st->sel_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_pair[0] = (C.tie_index && !dist && st->status == 0 && st->sel_tie != 0 && st->ntied <= TIE_CAP &&
+                         st->gap == 0);
+            s_pair[1] = st->ntied;
+        }
+        __syncthreads();
+        if (s_pair[0]) {
+            const unsigned long long key = tie_by_index(ref, C, s_tied, s_pair[1]);
+            if (threadIdx.x == 0 && key != NOPOS) {
+                const uint32_t pi = (uint32_t)(key & 127u);
+                st->a = s_tied[2 * pi];
+                st->b = s_tied[2 * pi + 1];
+                st->fin_a = st->a;
+                st->fin_b = st->b;
+                st->firstpos = key >> 7;
+                st->found = 1;
+                st->sel_tie = 0;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
             s_go = (st->status == 0 && st->sel_tie != 0);
+            if (s_go) {
+                // the other blocks will read what this one wrote (tied list, count, firstpos): publish it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&st->sel_flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // nobody sweeps: the flag alone (high bit) tells the other blocks to leave
+                __hip_atomic_store(&st->sel_flag, epoch | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             s_pair[0] = (st->status == 0 && st->found != 0);
             s_pair[1] = (uint32_t)st->a;
             s_pair[2] = (uint32_t)st->b;
@@ -224,19 +445,25 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
         __syncthreads();
         if (C.enable && s_pair[0] && s_pair[1] != s_pair[2]) build_cand_list(C, st, s_pair[1], s_pair[2]);
     } else if (threadIdx.x == 0) {
-        bool ok = false;
+        bool ok = false, leave = false;
         for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
-            if (__hip_atomic_load(&st->sel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) {
+            const uint32_t f = __hip_atomic_load(&st->sel_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((f & 0x7FFFFFFFu) == (epoch & 0x7FFFFFFFu)) {
                 ok = true;
+                leave = (f >> 31) != 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(24);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // never sweep on a decision that was not seen: a block that silently skipped its share
-        // could leave a later tied position as "the earliest" (wrong merge, no error)
-        if (!ok) atomicExch(&st->status, ST_LOOKBACK);
-        s_go = (ok && st->status == 0 && st->sel_tie != 0);
+        if (leave) {
+            s_go = 0;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // never sweep on a decision that was not seen: a block that silently skipped its share
+            // could leave a later tied position as "the earliest" (wrong merge, no error)
+            if (!ok) atomicExch(&st->status, ST_LOOKBACK);
+            s_go = (ok && st->status == 0 && st->sel_tie != 0);
+        }
     }
     __syncthreads();
     if (!s_go) return;
@@ -250,7 +477,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
         for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;
         __syncthreads();
         for (uint32_t x = threadIdx.x; x < vcur; x += 1024)
-            if (rowmax[x] == M) atomicOr(&s_bits[x >> 5], 1u << (x & 31));
+            if (rowmax[2 * x] == M) atomicOr(&s_bits[x >> 5], 1u << (x & 31));
     }
     __syncthreads();
     const uint64_t n = st->n[par];

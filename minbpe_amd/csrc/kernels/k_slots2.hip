@@ -57,7 +57,8 @@ struct AbArgs {
     uint32_t newid;
     uint32_t *delta;          // [replica][4][vcap]
     uint32_t vcap;            // row stride | log2(replicas) << 24
-    uint32_t *idx;            // inverted index [slot / 32][IDX_H] (bit = slot % 32), or nullptr
+    uint32_t *idx;            // inverted index [IDX_H][istride] (word = slot / 32, bit = slot % 32), or nullptr
+    uint32_t istride;
     const uint32_t *cand;     // sparse: the slots to visit (st->ncand of them, from k_select)
     uint32_t *removed;        // [256] ids removed by this pass, spread over counters (t & 255): one
                               // counter would serialise every changed slot of a dense pass (~11 ns each)
@@ -69,6 +70,7 @@ struct alignas(16) AbLds {
     uint4 hdr[6];             // headers of slots t-1, t, t+1
     uint32_t ctx[8];          // slow path: halo0..2, prev2, prev1, index of the previous non-empty slot
     uint32_t wsum[MT / 64];
+    uint32_t wmin[MT / 64];   // per wave: output offset of its first site
 };
 
 __global__ void __launch_bounds__(256)
@@ -283,6 +285,19 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
         total += v;
     }
     // ---- (6) stage the compacted slot in LDS, then 16-byte stores back to its home -------------
+    // (everything before the first site keeps its place and value: only the rest is stored)
+    {
+        uint32_t fc = 0x7FFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            if (mb[j]) {
+                const uint32_t k0 = (uint32_t)__ffs((int)mb[j]) - 1u;
+                fc = min(fc, wbase + ex[j] + (uint32_t)__popc(kb[j] & ((1u << k0) - 1u)));
+            }
+        }
+        fc = (uint32_t)wave_min_i32((int)fc);
+        if (lane == 0) S.wmin[wave] = fc;
+    }
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         uint32_t o = wbase + ex[j];
@@ -297,7 +312,9 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
     __syncthreads();
     {
         uint32_t *dst = (buf ? A.b1 : A.b0) + (size_t)t * TILE;
-        for (uint32_t i = (uint32_t)tid * 4; i < total; i += MT * 4)
+        uint32_t first = 0;  // a dropped first word moves everything
+        if (!s) first = min(min(S.wmin[0], S.wmin[1]), min(S.wmin[2], S.wmin[3])) & ~3u;
+        for (uint32_t i = first + (uint32_t)tid * 4; i < total; i += MT * 4)
             *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(&S.out[i]);
     }
     if (tid == 0) {
@@ -379,8 +396,8 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
                     // that is another slot (a boundary pair is known to both slots it touches: the
                     // one that owns its site and the one that drops the site's second word)
                     if (INDEXED) {
-                        index_add(A.idx, t, L & IDMASK, A.newid);
-                        if (wrel + j * 256 + lane * 4 + k == 0) index_add(A.idx, tprev, L & IDMASK, A.newid);
+                        index_add(A.idx, A.istride, t, L & IDMASK, A.newid);
+                        if (wrel + j * 256 + lane * 4 + k == 0) index_add(A.idx, A.istride, tprev, L & IDMASK, A.newid);
                     }
                 }
             }
@@ -391,8 +408,8 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
                 else atomicAdd(&dr[R & IDMASK], wt);
                 if (INDEXED) {
                     const uint32_t y = rsite ? A.newid : (R & IDMASK);
-                    index_add(A.idx, t, A.newid, y);
-                    if (wrel + j * 256 + lane * 4 + k + 2 >= (int)len) index_add(A.idx, tnext, A.newid, y);
+                    index_add(A.idx, A.istride, t, A.newid, y);
+                    if (wrel + j * 256 + lane * 4 + k + 2 >= (int)len) index_add(A.idx, A.istride, tnext, A.newid, y);
                 }
             }
         }
@@ -657,8 +674,9 @@ k_merge_aa(AaArgs A) {
 
 // ---------------------------------------------------------------------------
 // Index build: one workgroup per group of 32 slots, the group's IDX_H x 32-bit filter in LDS
-// (128 KiB), two ds_or per pair, then one coalesced write; no global atomics.  Also clears the
-// group's `dirty` word.
+// (128 KiB), three ds_or per pair, then one coalesced write of the group's row into a
+// group-major scratch image; k_index_transpose turns that into the bucket-major index.  No global
+// atomics.  Also clears the group's `dirty` word.
 __global__ void __launch_bounds__(1024)
 k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, const SlotHdr *__restrict__ hdr,
               uint32_t T, uint32_t *__restrict__ idx, uint32_t *__restrict__ dirty) {
@@ -726,6 +744,26 @@ k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, 
     __syncthreads();
     uint32_t *row = idx + (size_t)g * IDX_H;
     for (uint32_t i = threadIdx.x; i < IDX_H; i += 1024) row[i] = s_mask[i];
+}
+
+// scratch[g][h] -> idx[h][g]  (32 x 32 tiles through LDS, both sides coalesced)
+__global__ void __launch_bounds__(256)
+k_index_transpose(const uint32_t *__restrict__ scratch, uint32_t ngroups, uint32_t *__restrict__ idx,
+                  uint32_t stride) {
+    __shared__ uint32_t tile[32][33];
+    const uint32_t g0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t g = g0 + ty + 8 * i;
+        tile[ty + 8 * i][tx] = (g < ngroups) ? scratch[(size_t)g * IDX_H + h0 + tx] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t h = h0 + ty + 8 * i, g = g0 + tx;
+        if (g < ngroups) idx[(size_t)h * stride + g] = tile[tx][ty + 8 * i];
+    }
 }
 
 // ---------------------------------------------------------------------------

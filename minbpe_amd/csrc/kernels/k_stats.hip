@@ -235,7 +235,7 @@ k_pair_count_bytes(const uint32_t *__restrict__ ids, const DevState *__restrict_
 // K2: pair = max(stats, key=stats.get)  (basic.py:35, regex.py:56)
 
 // one workgroup per row: rowmax[x] = max_y count[x][y], rowarg[x] = the column attaining it
-// (row_scan, k_table.hip; rowarg lives right behind rowmax: rowmax[stride + x])
+// (row_scan, k_table.hip; the two are interleaved: rowmax[2x] = maximum, rowmax[2x + 1] = column)
 __global__ void __launch_bounds__(256)
 k_rowmax_all(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, uint32_t *__restrict__ rowmax) {
     __shared__ unsigned long long s_red[8];
@@ -243,8 +243,7 @@ k_rowmax_all(uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, uint32_
     uint32_t m = 0, arg = 0;
     row_scan(mat + (size_t)x * stride, vcur, -1, s_red, m, arg);
     if (threadIdx.x == 0) {
-        rowmax[x] = m;
-        rowmax[stride + x] = arg;
+        reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
     }
 }
 

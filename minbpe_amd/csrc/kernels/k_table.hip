@@ -96,7 +96,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
     bool dirty = (t == a) | (t == b) | (t == Z);  // always recomputed
     if (dl) {
         const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], dl);
-        if (t != Z && old == rowmax[t]) dirty = true;
+        if (t != Z && old == rowmax[2 * t]) dirty = true;
     }
     if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
     if (il) atomicAdd(&mat[(size_t)t * stride + Z], il);
@@ -105,13 +105,11 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
         dirty_list[atomicAdd(dirty_n, 1u)] = t;
     } else if (il) {
         // column Z was empty before this iteration: it is the only entry of this row that grew
-        uint32_t *rowarg = rowmax + stride;
-        const uint32_t m = rowmax[t];
+        const uint32_t m = rowmax[2 * t];
         if (il > m) {
-            rowmax[t] = il;
-            rowarg[t] = Z;
+            reinterpret_cast<uint2 *>(rowmax)[t] = make_uint2(il, Z);
         } else if (il == m) {
-            rowarg[t] = ROWARG_MULTI;  // a second column attains the row maximum
+            rowmax[2 * t + 1] = ROWARG_MULTI;  // a second column attains the row maximum
         }
     }
 }
@@ -183,8 +181,7 @@ __device__ __forceinline__ void rowmax_body(uint32_t *__restrict__ mat, uint32_t
         uint32_t m = 0, arg = 0;
         row_scan(mat + (size_t)x * stride, vnew, x == a ? (int)b : -1, s_red, m, arg);
         if (threadIdx.x == 0) {
-            rowmax[x] = m;
-            rowmax[stride + x] = arg;
+            reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
         }
     }
 }
