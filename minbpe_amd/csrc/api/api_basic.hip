@@ -104,6 +104,11 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "sparse")) {
         if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "sparse must be 0 (never), 1 (auto) or 2 (always)");
         c->use_sparse = (int)value;
+    } else if (!strcmp(name, "rep_max")) {
+        if (value < 0 || value > 8) return fail(c, BPE_E_ARG, "rep_max must be 0..8");
+        c->rep_max = (int)value;
+    } else if (!strcmp(name, "exp_no_delta")) {
+        c->exp_no_delta = value != 0;
     } else if (!strcmp(name, "tie_window")) {
         c->tie_window = value != 0;
     } else if (!strcmp(name, "tie_index")) {

@@ -70,6 +70,8 @@ struct bpe_ctx {
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
+    int rep_max = 8;                          // log2 of the most delta-vector replicas a pass may use (experiments)
+    int exp_no_delta = 0;                     // experiment: a != b passes skip the pair-table bookkeeping (wrong results)
     int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
     int tie_index = 1;                        // break ties through the index when it is live (0: always sweep)
     int sparse_ratio = 2;                     // sparse pass when (count of the pair) * ratio < slots
@@ -84,6 +86,9 @@ struct bpe_ctx {
     uint32_t *d_dp_folded = nullptr, *d_dp_table = nullptr;
     long long *d_dp_key = nullptr;
     uint64_t dp_cur_len = 0;
+    bool dp_sparse = false;                   // second slotted form: this iteration's a != b pass is a sparse one
+    uint32_t dp_dl = 0;                       // ... and the delta layout its kernels used
+    std::vector<uint8_t> dp_flip;             // ... and which iterations flipped the header arrays
     int merge_impl = 0;  // 0 three-pass | 1 single-pass (two-level decoupled look-back)
     unsigned long long *d_desc = nullptr;   // look-back descriptors, one per tile
     unsigned long long *d_gdesc = nullptr;  // ... and one per group of 64 tiles
@@ -113,7 +118,7 @@ struct bpe_ctx {
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
     bool prof_active = false;
-    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache (8-byte slots) | 2 dense 16-bit LDS table for byte streams, 4-byte-slot LDS cache otherwise (weighted streams: as 1)
+    int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache (8-byte slots) | 2 = 1 + dense 16-bit LDS table for byte streams | 3 = 2 with the 4-byte-slot LDS cache for general unweighted streams (measured: no faster, both bound by L2 atomics on cold pairs)
     bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
 
     std::vector<ProfEv> prof_open;
@@ -367,7 +372,7 @@ int launch_pair_count(bpe_ctx *c, bool with_first) {
             hipLaunchKernelGGL(k_pair_count_bytes, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
                                dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
                                c->par, c->d_mat, c->vcap);
-        } else if (c->k1 >= 2 && !c->weighted && c->vcap <= 65536) {
+        } else if (c->k1 >= 3 && !c->weighted && c->vcap <= 65536) {
             // (4-byte LDS slots with 15-bit counts: unit increments, ids below 2^16)
             hipLaunchKernelGGL(k_pair_count_h32, dim3(grid_for(n, 4 * PC_THREADS, c->num_cus)),
                                dim3(PC_THREADS), PC_LDS_BYTES, c->stream, c->d_ids[c->par], c->d_st,
@@ -689,7 +694,7 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
     while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;
     const uint64_t cnt = c->last_count;
     const int want = cnt >= (1u << 20) ? 8 : (cnt >= (1u << 16) ? 5 : (cnt >= (1u << 12) ? 3 : 0));
-    return dstride | ((uint32_t)std::min(shift, want) << 24);
+    return dstride | ((uint32_t)std::min(std::min(shift, want), c->rep_max) << 24);
 }
 
 // Will this iteration's a != b pass be a sparse one?  It pays when the pair is rare enough that
@@ -711,14 +716,13 @@ int plan_pass2(bpe_ctx *c, bool *sparse_out) {
 // one merge pass of the second slotted form + table update.  The host does not know the pair
 // (it runs `depth` merges ahead): the a != b kernel and the a == b kernel are both launched and
 // the one the pair does not call for returns at once.
-int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse) {
+int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
         HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
         c->epoch++;
     }
     const uint32_t T = (uint32_t)c->slot_T;
-    const uint32_t dl = delta_layout(c, newid);
     AbArgs A;
     A.b0 = c->d_ids[0];
     A.b1 = c->d_ids[1];
@@ -729,7 +733,7 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     A.T = T;
     A.st = c->d_st;
     A.newid = newid;
-    A.delta = c->d_delta;
+    A.delta = c->exp_no_delta ? nullptr : c->d_delta;
     A.vcap = dl;
     A.idx = c->idx_live ? c->d_idx : nullptr;
     A.istride = (uint32_t)c->idx_cap_words;
@@ -765,15 +769,28 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     B.epoch = c->epoch;
     B.dirty = c->idx_live ? c->d_idx_dirty : nullptr;
     B.removed = c->d_removed;
-    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 2u * (unsigned)c->num_cus))), dim3(MT), 0,
+    // (a resident grid: 137 VGPRs admit three workgroups per CU; a slot may wait for its predecessor's carry)
+    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 3u * (unsigned)c->num_cus))), dim3(MT), 0,
                        c->stream, B);
     LAUNCHCHK(c, "k_merge_aa");
     TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// table update of the second slotted form (+ commit of staged headers, stream length, record);
+// folded: the delta comes from the all-reduced payload of sharded training
+int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse, uint32_t dl, bool folded) {
+    const uint32_t T = (uint32_t)c->slot_T;
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (newid + 1 + 31) / 32;
-    hipLaunchKernelGGL(k_apply2, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
-                       c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, na,
-                       c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
+    if (folded)
+        hipLaunchKernelGGL(k_apply2<true>, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_dp_folded,
+                           c->vcap, c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter,
+                           na, c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
+    else
+        hipLaunchKernelGGL(k_apply2<false>, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
+                           c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, na,
+                           c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
     LAUNCHCHK(c, "k_apply2");
     hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
                        c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
@@ -784,6 +801,12 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     c->stats_valid = false;
     c->stream_is_bytes = false;
     return BPE_OK;
+}
+
+int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse) {
+    const uint32_t dl = delta_layout(c, newid);
+    TRY(launch_passes2(c, newid, sparse, dl));
+    return launch_table2(c, newid, iter, rec, sparse, dl, false);
 }
 
 int read_state(bpe_ctx *c, DevState *out) {

@@ -18,7 +18,8 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
     if (c->d_dp_folded) (void)hipFree(c->d_dp_folded);
     c->d_dp_folded = nullptr;
-    HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, (size_t)c->vcap * 4 * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, ((size_t)c->vcap * 4 + 64) * sizeof(uint32_t)));
+    HIPCHK(c, hipMemsetAsync(c->d_dp_folded, 0, ((size_t)c->vcap * 4 + 64) * sizeof(uint32_t), c->stream));
     if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
     if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 3 * sizeof(long long)));
     TRY(start_from_bytes(c));
@@ -30,7 +31,12 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     c->dp_cur_len = c->n;
     c->dp_enq = c->dp_done = 0;
     c->rep_shift = 5;
-    if (c->use_slots) TRY(slots_enter(c));
+    c->idx_live = false;
+    c->idx_rebuild = false;
+    c->last_count = ~0ull;
+    c->n_sparse = c->n_dense = c->n_index_builds = 0;
+    c->dp_flip.assign((size_t)std::max(num_merges, 1), 0);
+    if (c->use_slots) TRY(c->use_slots == 2 ? slots2_enter(c) : slots_enter(c));
     return BPE_OK;
 }
 
@@ -40,7 +46,7 @@ extern "C" int bpe_dp_buffers(bpe_ctx *c, void **table, uint64_t *table_count, v
     if (table) *table = c->d_dp_table;
     if (table_count) *table_count = 256 * 256;
     if (delta) *delta = c->d_dp_folded;
-    if (delta_count) *delta_count = (uint64_t)c->vcap * 4;
+    if (delta_count) *delta_count = (uint64_t)c->vcap * 4 + 64;  // four vectors + the format-B adj word (padded)
     if (tiekey) *tiekey = c->d_dp_key;
     return BPE_OK;
 }
@@ -61,14 +67,25 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     c->vcur = 256u + (uint32_t)iter;
-    if (c->slotted && c->slot_T > 64 &&
-        c->n * REPACK_DEN < c->slot_T * (uint64_t)TILE * (REPACK_DEN - 1)) {
-        TRY(slots_leave(c));
-        TRY(slots_enter(c));
+    const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
+    if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE * (den - 1)) {
+        if (c->slot2) {
+            TRY(slots2_leave(c));
+            TRY(slots2_enter(c));
+        } else {
+            TRY(slots_leave(c));
+            TRY(slots_enter(c));
+        }
     }
+    c->dp_sparse = false;
+    if (c->slotted && c->slot2) TRY(plan_pass2(c, &c->dp_sparse));  // (counts are global: every rank decides alike)
     TRY(launch_select(c, false));
-    hipLaunchKernelGGL(k_dp_key, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st,
-                       (unsigned long long)c->dp_rank, c->d_dp_key);
+    if (c->slotted && c->slot2)
+        hipLaunchKernelGGL(k_dp_key<SlotRefH>, dim3(1), dim3(64), 0, c->stream, stream_ref_h(c), c->par, c->d_st,
+                           (unsigned long long)c->dp_rank, c->d_dp_key);
+    else
+        hipLaunchKernelGGL(k_dp_key<SlotRef>, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st,
+                           (unsigned long long)c->dp_rank, c->d_dp_key);
     LAUNCHCHK(c, "k_dp_key");
     return BPE_OK;
 }
@@ -79,6 +96,27 @@ extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
     hipLaunchKernelGGL(k_dp_resolve, dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
     LAUNCHCHK(c, "k_dp_resolve");
     c->dp_enq = iter + 1;
+    if (c->slotted && c->slot2) {
+        const uint32_t Z = 256u + (uint32_t)iter;
+        if (c->dp_sparse) {
+            CandArgs C;
+            C.idx = c->d_idx;
+            C.dirty = c->d_idx_dirty;
+            C.cand = c->d_cand;
+            C.stride = (uint32_t)c->idx_cap_words;
+            C.T = (uint32_t)c->slot_T;
+            C.enable = 1;
+            C.tie_index = C.tie_window = 0;
+            hipLaunchKernelGGL(k_dp_cand, dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
+            LAUNCHCHK(c, "k_dp_cand");
+        }
+        c->dp_dl = delta_layout(c, Z);
+        TRY(launch_passes2(c, Z, c->dp_sparse, c->dp_dl));
+        hipLaunchKernelGGL(k_dp_fold2, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta, c->dp_dl, Z,
+                           c->d_dp_folded, c->vcap, c->d_st);
+        LAUNCHCHK(c, "k_dp_fold2");
+        return BPE_OK;
+    }
     if (c->slotted) return launch_merge_slot(c, 256u + (uint32_t)iter, iter, c->h_rec);
     const int saved = c->merge_impl;
     c->merge_impl = 0;  // the three-pass form finalises the pair before the rewrite
@@ -91,6 +129,12 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t Z = 256u + (uint32_t)iter;
+    if (c->slotted && c->slot2) {
+        const int mq0 = c->mq;
+        TRY(launch_table2(c, Z, iter, c->h_rec, c->dp_sparse, c->dp_dl, true));
+        if ((size_t)iter < c->dp_flip.size()) c->dp_flip[(size_t)iter] = (uint8_t)(c->mq != mq0);
+        return BPE_OK;
+    }
     if (c->slotted)  // the slotted pass leaves length/record bookkeeping to the table update
         TRY(launch_table_update<true>(c, c->d_dp_folded, Z, c->par ^ 1, c->h_rec, iter, 1));
     else
@@ -117,6 +161,8 @@ extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uin
     if (status) *status = (r->status == ST_OK) ? BPE_OK : (r->status == ST_EMPTY ? BPE_E_EMPTY_STATS : BPE_E_INTERNAL);
     if (r->status == ST_OK) {
         if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
+        c->last_count = r->count;  // (global count: the same on every rank)
+        if (r->a == r->b && c->idx_live) c->idx_rebuild = true;
         c->dp_cur_len = r->new_len;
         c->n = r->new_len;  // tighter launch bound
         c->dp_done = iter + 1;
@@ -131,12 +177,15 @@ extern "C" int bpe_dp_end(bpe_ctx *c) {
     if (c->slotted) {
         // iterations enqueued after the last reported one (an early stop) did nothing on the
         // device: undo their parity flips, then hand back a contiguous stream
-        if ((c->dp_enq - c->dp_done) & 1) {
-            c->par ^= 1;
+        if ((c->dp_enq - c->dp_done) & 1) c->par ^= 1;
+        if (c->slot2) {
+            for (int j = c->dp_done; j < c->dp_enq; j++)
+                if ((size_t)j < c->dp_flip.size() && c->dp_flip[(size_t)j]) c->mq ^= 1;
+        } else if ((c->dp_enq - c->dp_done) & 1) {
             c->mq ^= 1;
         }
         hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
-        TRY(slots_leave(c));
+        TRY(c->slot2 ? slots2_leave(c) : slots_leave(c));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->n = c->dp_cur_len;
     } else if ((c->dp_enq - c->dp_done) & 1) {

@@ -141,7 +141,7 @@ extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, 
         if (host_rc == BPE_OK) keep(bpe_dp_select(c, i));
         keep(allreduce(c->d_dp_key, 3, RCCL_INT64, RCCL_MIN));
         if (host_rc == BPE_OK) keep(bpe_dp_merge(c, i));
-        keep(allreduce(c->d_dp_folded, (size_t)c->vcap * 4, RCCL_INT32, RCCL_SUM));
+        keep(allreduce(c->d_dp_folded, (size_t)c->vcap * 4 + 64, RCCL_INT32, RCCL_SUM));
         if (host_rc == BPE_OK) keep(bpe_dp_apply(c, i));
         if (host_rc == BPE_OK && !stop && i - consumed >= c->depth) {
             keep(consume(consumed));

@@ -6,6 +6,7 @@
 
 #include "../bpe_device.h"
 #include "k_select.hip"
+#include "k_index.hip"
 
 namespace bpe {
 
@@ -20,7 +21,8 @@ namespace bpe {
 // element-wise MIN all-reduce of (w0, w1) returns the pair of the winning rank,
 // because the keys are distinct per rank.  No tie: every rank sends key 0 and
 // the same pair.  No local occurrence: INT64_MAX.
-__global__ void k_dp_key(SlotRef ref, int par, const DevState *__restrict__ st,
+template <class Ref>
+__global__ void k_dp_key(Ref ref, int par, const DevState *__restrict__ st,
                          unsigned long long rank, long long *__restrict__ key) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long w0 = 0x7FFFFFFFFFFFFFFFll, w1 = 0x7FFFFFFFFFFFFFFFll;
@@ -58,7 +60,38 @@ __global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
     }
     st->a = (int32_t)(key[0] & 0xFFFF);
     st->b = (int32_t)(key[1] & 0xFFFF);
+    st->fin_a = st->a;
+    st->fin_b = st->b;
     st->found = 1;
+}
+// second slotted form, sharded: the pair is known only now (after the MIN all-reduce), so the
+// candidate list of a sparse pass is made here instead of inside k_select (one 1024-thread block)
+__global__ void __launch_bounds__(1024)
+k_dp_cand(DevState *st, CandArgs C) {
+    if (st->status || !st->found || st->a == st->b) return;
+    build_cand_list(C, st, (uint32_t)st->a, (uint32_t)st->b);
+}
+// ... and the fold of its replicated delta vectors (stride / replica count packed in `dl` as for
+// the merge kernels) into the all-reduce payload [4][vcap] + adj (format B fills vectors 0 and 1)
+__global__ void __launch_bounds__(256)
+k_dp_fold2(uint32_t *__restrict__ delta, uint32_t dl, uint32_t Z, uint32_t *__restrict__ folded, uint32_t vcap,
+           const DevState *__restrict__ st) {
+    const uint32_t nrep = 1u << (dl >> 24), ds = dl & 0xFFFFFFu;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) folded[4 * (size_t)vcap] = st->status ? 0u : st->adj;
+    if (t >= vcap) return;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        uint32_t acc = 0;
+        if (t <= Z && t < ds) {
+            for (uint32_t r = 0; r < nrep; r++) {
+                const uint32_t x = delta[((size_t)r * 4 + v) * ds + t];
+                if (x) delta[((size_t)r * 4 + v) * ds + t] = 0;
+                acc += x;
+            }
+        }
+        folded[(size_t)v * vcap + t] = acc;
+    }
 }
 // fold the replicated delta vectors into one compact 4 x vcap buffer (the SUM all-reduce payload)
 __global__ void __launch_bounds__(256)

@@ -341,6 +341,7 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
     }
     // ---- (7) pair-table delta of my sites (format B); their new pairs enter the index -----------
     if (!sites) return;  // carry only: the site belongs to the previous slot
+    if (!A.delta) return;  // (experiment "exp_no_delta": time the pass without its table bookkeeping; results are wrong)
     const uint32_t nrep = 1u << (A.vcap >> 24);
     const uint32_t vc = A.vcap & 0xFFFFFFu;
     uint32_t *dl = A.delta + (size_t)(t & (nrep - 1)) * 4 * vc;  // SL

@@ -22,7 +22,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
                                            uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z,
                                            uint32_t *__restrict__ dirty_list,
                                            uint32_t *__restrict__ dirty_n, int par, IterRec *rec, int iter,
-                                           int slot_finish) {
+                                           int slot_finish, const uint32_t *adj_ptr = nullptr) {
     if (slot_finish && blockIdx.x == 0 && threadIdx.x == 0) {
         // slotted pass: new stream length and this iteration's record
         const unsigned long long n = st->n[par];
@@ -86,7 +86,7 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
         acc4[v] += (uint32_t)__shfl_xor((int)acc4[v], 4);
     }
     if (fmtb) {
-        const uint32_t adj = st->adj;  // (reset by the next k_select)
+        const uint32_t adj = adj_ptr ? *adj_ptr : st->adj;  // (st->adj is reset by the next k_select; sharded: the global sum)
         acc4[2] = acc4[0];
         acc4[3] = acc4[1] + (t == Z ? adj : 0u);
         acc4[1] += (t == a ? adj : 0u);
@@ -235,6 +235,7 @@ k_apply_delta(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 
 // Table update of the second slotted form: blocks [0, na) apply the delta vectors (format B for
 // a != b), blocks [na, grid) commit the headers a sparse merge pass staged (k_slots2.hip).
+template <bool FOLDED>
 __global__ void __launch_bounds__(256)
 k_apply2(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
          uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z, uint32_t *__restrict__ dirty_list,
@@ -254,7 +255,9 @@ k_apply2(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ del
         if (threadIdx.x == 0) st->removed = v;  // read by this same thread in apply_body
     }
     if (blockIdx.x < na) {
-        apply_body<false, true>(mat, stride, delta, vcap, rowmax, st, Z, dirty_list, dirty_n, par, rec, iter, 1);
+        // FOLDED (sharded training): `delta` is the all-reduced payload [4][vcap] + the global adj word
+        apply_body<FOLDED, true>(mat, stride, delta, vcap, rowmax, st, Z, dirty_list, dirty_n, par, rec, iter, 1,
+                                 FOLDED ? delta + 4 * (size_t)(vcap & 0xFFFFFFu) : nullptr);
         return;
     }
     if (st->status) return;

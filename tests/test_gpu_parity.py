@@ -350,7 +350,7 @@ def _space_chunks(text: bytes):
     return [c for c in re.findall(rb" ?[^ ]+| +", text) if c]
 
 
-def _lockstep(native, chunks, nm, world, slots=1, dedup=False):
+def _lockstep(native, chunks, nm, world, slots=2, dedup=False, sparse=1):
     """Drive `world` ctxs through the dist.py protocol in lock-step; reductions done by hand."""
     import torch
     from minbpe_amd.dist import GpuShard, shard_chunks
@@ -360,6 +360,7 @@ def _lockstep(native, chunks, nm, world, slots=1, dedup=False):
         mine = chunks[lo:hi]
         eng = native.Engine(0)
         eng.set_option("slots", slots)
+        eng.set_option("sparse", sparse)
         data = b"".join(mine)
         offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
         if dedup:  # every rank de-duplicates its own shard
@@ -405,15 +406,16 @@ def _lockstep(native, chunks, nm, world, slots=1, dedup=False):
     return pairs, counts, lens
 
 
-@pytest.mark.parametrize("world,slots", [(1, 1), (2, 1), (3, 1), (2, 0)])
-def test_dp_lockstep_matches_oracle(native, world, slots):
+@pytest.mark.parametrize("world,slots,sparse", [(1, 1, 1), (2, 1, 1), (3, 1, 1), (2, 0, 1), (1, 2, 1), (2, 2, 1),
+                                                (3, 2, 2), (2, 2, 2)])
+def test_dp_lockstep_matches_oracle(native, world, slots, sparse):
     torch = pytest.importorskip("torch")
     chunks = _space_chunks(native.synth_text(1_500_000, 51))
     nm = 300
     data = b"".join(chunks)
     offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
     exp = oracle.train(data, nm, offs)
-    got = _lockstep(native, chunks, nm, world, slots)
+    got = _lockstep(native, chunks, nm, world, slots, sparse=sparse)
     assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2]
 
 
@@ -424,8 +426,9 @@ def test_dp_lockstep_ties_and_exhaustion(native):
     data = b"".join(chunks)
     offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
     exp = oracle.train(data, 400, offs, raise_on_empty=False)
-    got = _lockstep(native, chunks, 400, 3)
-    assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2]
+    for slots, sparse in ((1, 1), (2, 1), (2, 2)):
+        got = _lockstep(native, chunks, 400, 3, slots, sparse=sparse)
+        assert got[0] == exp[0] and got[1] == exp[1] and got[2] == exp[2], (slots, sparse)
     assert len(exp[0]) < 400  # the table ran empty: every rank stopped at the same merge
 
 

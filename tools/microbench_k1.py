@@ -17,7 +17,8 @@ out = []
 def measure(label):
     ref = None
     for k1, name in ((0, "one L2 atomic per position"), (1, "LDS cache, 16 Ki 8-byte slots, 4 probes"),
-                     (2, "default (dense 16-bit LDS table on bytes, else 32 Ki 4-byte slots)")):
+                     (2, "default (dense 16-bit LDS table on bytes, else as k1=1)"),
+                     (3, "as 2, 32 Ki exact 4-byte slots for general streams")):
         eng.set_option("k1", k1)
         ts = []
         for r in range(reps):
