@@ -65,12 +65,13 @@ struct bpe_ctx {
     uint32_t *d_idx = nullptr;                // inverted slot index [IDX_H][idx_cap_words] (bucket-major)
     uint32_t *d_idx_tmp = nullptr;            // group-major image the build kernel writes, transposed into d_idx
     uint32_t *d_idx_dirty = nullptr;          // [slot / 32]: slots rewritten by a == b passes since the last build
-    uint32_t *d_removed = nullptr;            // [256] removal counters of a merge pass
+    uint32_t *d_removed = nullptr;            // [256 * REMOVED_STRIDE] removal counters of a merge pass
     uint64_t idx_cap_words = 0;               // index groups allocated
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
     int rep_max = 8;                          // log2 of the most delta-vector replicas a pass may use (experiments)
+    int lds_delta = 1;                        // option "lds_delta": a != b passes aggregate their delta in LDS while ids < LDSD_CAP
     int exp_no_delta = 0;                     // experiment: a != b passes skip the pair-table bookkeeping (wrong results)
     int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
     int tie_index = 1;                        // break ties through the index when it is live (0: always sweep)
@@ -203,6 +204,7 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         c->cap_ids = need;
     }
     const uint64_t nt = ntiles_of(n) + 1;
+    const uint64_t nt2 = (TILE / TILE2) * nt + 4;  // slots of the second slotted form (TILE2 ids each)
     if (nt > c->cap_tiles) {
         TRY(dev_realloc(c, c->d_tsum, nt));
         TRY(dev_realloc(c, c->d_tile_off, nt));
@@ -211,18 +213,18 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_meta[1], nt));
         TRY(dev_realloc(c, c->d_hdr[0], nt));
         TRY(dev_realloc(c, c->d_hdr[1], nt));
-        TRY(dev_realloc(c, c->d_hdr2[0], nt));
-        TRY(dev_realloc(c, c->d_hdr2[1], nt));
-        TRY(dev_realloc(c, c->d_stage, nt));
-        TRY(dev_realloc(c, c->d_smask, nt / 32 + 2));
-        TRY(dev_realloc(c, c->d_cand, nt));
-        HIPCHK(c, hipMemsetAsync(c->d_smask, 0, (nt / 32 + 2) * sizeof(uint32_t), c->stream));
-        TRY(dev_realloc(c, c->d_slot_lens, nt));
-        TRY(dev_realloc(c, c->d_slot_off, nt + 1));
-        TRY(dev_realloc(c, c->d_slot_bsum, nt / SCAN_TILE + 2));
-        TRY(dev_realloc(c, c->d_desc, nt));
+        TRY(dev_realloc(c, c->d_hdr2[0], nt2));
+        TRY(dev_realloc(c, c->d_hdr2[1], nt2));
+        TRY(dev_realloc(c, c->d_stage, nt2));
+        TRY(dev_realloc(c, c->d_smask, nt2 / 32 + 2));
+        TRY(dev_realloc(c, c->d_cand, nt2));
+        HIPCHK(c, hipMemsetAsync(c->d_smask, 0, (nt2 / 32 + 2) * sizeof(uint32_t), c->stream));
+        TRY(dev_realloc(c, c->d_slot_lens, nt2));
+        TRY(dev_realloc(c, c->d_slot_off, nt2 + 1));
+        TRY(dev_realloc(c, c->d_slot_bsum, nt2 / SCAN_TILE + 2));
+        TRY(dev_realloc(c, c->d_desc, nt2));
         TRY(dev_realloc(c, c->d_gdesc, nt / 64 + 2));
-        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, nt2 * sizeof(unsigned long long), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_gdesc, 0, (nt / 64 + 2) * sizeof(unsigned long long), c->stream));
         c->cap_tiles = nt;
     }
@@ -236,14 +238,14 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
     TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
     TRY(dev_realloc(c, c->d_rowmax, (size_t)nv * 2));  // rowmax[nv] | rowarg[nv]
-    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL));
+    TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL + 256 * DELTA_SKEW));  // (+ the skew of up to 256 replicas)
     TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
     if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
     if (!c->d_removed) {
-        HIPCHK(c, hipMalloc((void **)&c->d_removed, 256 * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(c->d_removed, 0, 256 * sizeof(uint32_t), c->stream));
+        HIPCHK(c, hipMalloc((void **)&c->d_removed, 256 * REMOVED_STRIDE * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_removed, 0, 256 * REMOVED_STRIDE * sizeof(uint32_t), c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, (size_t)nv * 4 * DELTA_REPL * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, ((size_t)nv * 4 * DELTA_REPL + 256 * DELTA_SKEW) * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
     if (c->d_first) {
         HIPCHK(c, hipFree(c->d_first));
@@ -610,15 +612,15 @@ int launch_merge_slot(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec) {
 }
 
 // ---- slotted stream, second form (k_slots2.hip) -------------------------------------------------
-constexpr unsigned SPARSE_GRID = 1024;      // resident workgroups of a sparse pass (4 per CU)
+constexpr unsigned SPARSE_GRID = 1024;      // resident workgroups of a sparse pass (4 per CU, four waves = four slots each)
 
 int index_build(bpe_ctx *c) {
     const uint64_t nwords = (c->slot_T + 31) / 32;
-    if (nwords > c->idx_cap_words) {
+    if (nwords + 4 > c->idx_cap_words) {
         if (c->d_idx) HIPCHK(c, hipFree(c->d_idx));
         if (c->d_idx_dirty) HIPCHK(c, hipFree(c->d_idx_dirty));
         c->d_idx = c->d_idx_dirty = nullptr;
-        const uint64_t cap = nwords + 1;
+        const uint64_t cap = (nwords + 4 + 63) / 64 * 64;  // row stride: 16-byte aligned rows, a padded tail
         if (c->d_idx_tmp) HIPCHK(c, hipFree(c->d_idx_tmp));
         c->d_idx_tmp = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * IDX_H * sizeof(uint32_t)));
@@ -629,7 +631,7 @@ int index_build(bpe_ctx *c) {
     if (nwords) {
         hipLaunchKernelGGL(k_index_build, dim3((unsigned)nwords), dim3(1024), (size_t)IDX_H * 4, c->stream,
                            c->d_ids[0], c->d_ids[1], c->d_hdr2[c->mq], (uint32_t)c->slot_T, c->d_idx_tmp,
-                           c->d_idx_dirty);
+                           c->d_idx_dirty, c->d_st);
         LAUNCHCHK(c, "k_index_build");
         hipLaunchKernelGGL(k_index_transpose, dim3((unsigned)((nwords + 31) / 32), IDX_H / 32), dim3(256), 0,
                            c->stream, c->d_idx_tmp, (uint32_t)nwords, c->d_idx, (uint32_t)c->idx_cap_words);
@@ -642,7 +644,7 @@ int index_build(bpe_ctx *c) {
 }
 
 int slots2_enter(bpe_ctx *c) {
-    c->slot_T = ntiles_of(c->n);
+    c->slot_T = (c->n + TILE2 - 1) / TILE2;
     c->mq = 0;
     hipLaunchKernelGGL(k_slot2_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
                        dim3(256), 0, c->stream, c->d_hdr2[0], c->slot_T, c->d_st, c->par, (uint32_t)c->par,
@@ -669,8 +671,8 @@ int slots2_leave(bpe_ctx *c) {
                            c->d_scratch + 3);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
                            c->d_slot_bsum, c->d_slot_off);
-        hipLaunchKernelGGL(k_slot2_compact, dim3((unsigned)T), dim3(256), 0, c->stream, c->d_ids[0],
-                           c->d_ids[1], c->d_hdr2[c->mq], c->d_slot_off, c->d_ids2);
+        hipLaunchKernelGGL(k_slot2_compact, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, c->stream, c->d_ids[0],
+                           c->d_ids[1], c->d_hdr2[c->mq], T, c->d_slot_off, c->d_ids2);
         LAUNCHCHK(c, "k_slot2_compact");
     }
     std::swap(c->d_ids[0], c->d_ids2);
@@ -691,7 +693,7 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
     const uint32_t dstride = std::min<uint32_t>(c->vcap, ((Z + 1 + 63) / 64) * 64);
     const uint64_t buf_words = (uint64_t)c->vcap * 4 * DELTA_REPL;
     int shift = 0;
-    while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;
+    while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;  // (the skew has its own room)
     const uint64_t cnt = c->last_count;
     const int want = cnt >= (1u << 20) ? 8 : (cnt >= (1u << 16) ? 5 : (cnt >= (1u << 12) ? 3 : 0));
     return dstride | ((uint32_t)std::min(std::min(shift, want), c->rep_max) << 24);
@@ -703,7 +705,7 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
 // sparse one -- tests drive the sparse kernel and the index through streams of a few slots.)
 int plan_pass2(bpe_ctx *c, bool *sparse_out) {
     const uint32_t T = (uint32_t)c->slot_T;
-    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 4 * SPARSE_GRID);
+    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 16 * SPARSE_GRID);
     const bool sparse = can_index && (c->use_sparse == 2 || (c->last_count != ~0ull &&
                                                              c->last_count * (uint64_t)c->sparse_ratio < T));
     // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
@@ -719,7 +721,7 @@ int plan_pass2(bpe_ctx *c, bool *sparse_out) {
 int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
-        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, c->cap_tiles * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, ((TILE / TILE2) * c->cap_tiles + 4) * sizeof(unsigned long long), c->stream));
         c->epoch++;
     }
     const uint32_t T = (uint32_t)c->slot_T;
@@ -740,14 +742,25 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     A.cand = c->d_cand;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
+    // every id the pass can meet is below newid: small enough for the LDS delta tables?
+    const bool ldsd = c->lds_delta && newid + 1 <= (uint32_t)LDSD_CAP;
     if (sparse) {
-        hipLaunchKernelGGL(k_merge_ab_sparse, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
+        if (ldsd)
+            hipLaunchKernelGGL(k_merge_ab_sparse<true>, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
+        else
+            hipLaunchKernelGGL(k_merge_ab_sparse<false>, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
         c->n_sparse++;
     } else {
-        if (A.idx)
-            hipLaunchKernelGGL(k_merge_ab_dense<true>, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
+        const unsigned g = std::max((T + MT / 64 - 1) / (MT / 64), 1u);  // one wave per slot
+        const unsigned ge = std::min(g, 5u * (unsigned)c->num_cus);       // ... or a resident grid
+        if (ldsd && A.idx)
+            hipLaunchKernelGGL(k_merge_ab_dense_early<true>, dim3(ge), dim3(MT), 0, c->stream, A);
+        else if (ldsd)
+            hipLaunchKernelGGL(k_merge_ab_dense_early<false>, dim3(ge), dim3(MT), 0, c->stream, A);
+        else if (A.idx)
+            hipLaunchKernelGGL(k_merge_ab_dense<true>, dim3(g), dim3(MT), 0, c->stream, A);
         else
-            hipLaunchKernelGGL(k_merge_ab_dense<false>, dim3(std::max(T, 1u)), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(k_merge_ab_dense<false>, dim3(g), dim3(MT), 0, c->stream, A);
         c->n_dense++;
     }
     LAUNCHCHK(c, "k_merge_ab");
@@ -769,8 +782,9 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     B.epoch = c->epoch;
     B.dirty = c->idx_live ? c->d_idx_dirty : nullptr;
     B.removed = c->d_removed;
-    // (a resident grid: 137 VGPRs admit three workgroups per CU; a slot may wait for its predecessor's carry)
-    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 3u * (unsigned)c->num_cus))), dim3(MT), 0,
+    // (a resident grid of single-wave workgroups -- a slot may wait for its predecessor's carry:
+    // ~140 VGPRs admit three waves per SIMD, twelve per CU; eight are launched)
+    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 8u * (unsigned)c->num_cus))), dim3(64), 0,
                        c->stream, B);
     LAUNCHCHK(c, "k_merge_aa");
     TRY(prof_end(c));

@@ -68,7 +68,7 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     HIPCHK(c, hipSetDevice(c->device));
     c->vcur = 256u + (uint32_t)iter;
     const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-    if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE * (den - 1)) {
+    if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)(c->slot2 ? TILE2 : TILE) * (den - 1)) {
         if (c->slot2) {
             TRY(slots2_leave(c));
             TRY(slots2_enter(c));

@@ -109,7 +109,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             // (with the inverted index live most passes skip most slots, and a re-packing also costs
             // an index build: re-pack at 7/8 there)
             const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-            if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE * (den - 1)) {
+            if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)(c->slot2 ? TILE2 : TILE) * (den - 1)) {
                 if (c->slot2) {
                     TRY(slots2_leave(c));
                     TRY(slots2_enter(c));

@@ -38,6 +38,20 @@ constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches al
 constexpr int TIE_BLOCKS = 256;     // k_select blocks: block 0 decides, all of them sweep the stream on a tie
 constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
 constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
+// Device-scope atomics execute at the memory channel that owns the address, ~11 ns apiece and ONE AT
+// A TIME per channel (measured: a pass whose atomics fall on few channels runs at a fraction of the
+// ~10 G atomics/s the whole chip sustains).  Replica r of the delta vectors starts at
+// r * (4 * stride + DELTA_SKEW) words: the skew of one 256-byte line walks the replicas of one hot
+// token over all the channels instead of the few a power-of-two stride lands on; the removal
+// counters of a merge pass sit one per 256-byte line for the same reason.
+constexpr int DELTA_SKEW = 64;
+constexpr int REMOVED_STRIDE = 64;  // words between the 256 removal counters
+// While every id is below LDSD_CAP (the first ~1700 merges, where passes have millions of sites)
+// the a != b kernels add their delta into LDS tables and flush them once per workgroup.
+constexpr int LDSD_CAP = 1920;
+__host__ __device__ inline size_t delta_rep_off(uint32_t r, uint32_t stride) {
+    return (size_t)r * (4 * (size_t)stride + DELTA_SKEW);
+}
 
 // encode: one chunk per lane, token lists in lane-private LDS columns
 constexpr int ENC_THREADS = 256;
@@ -57,6 +71,12 @@ struct SlotRef {
     const uint32_t *meta;
     unsigned long long T;
 };
+
+// Slot size of the second slotted form: what ONE WAVE holds (4 stripes x 64 lanes x 4 ids).  A slot
+// is read, compacted and written back by a single wave -- no barrier anywhere in the pass -- and a
+// merge that touches one id of a slot moves 4 KiB, not 16.
+constexpr int TILE2 = WAVE_SPAN;
+static_assert(TILE2 == 1024, "k_slots2.hip assumes 1024-id slots");
 
 // Slotted stream, second form (the training loop's default, k_slots2.hip): one 32-byte header
 // per slot instead of a meta word + a 16-byte header, so that a workgroup gets everything it
@@ -98,7 +118,9 @@ struct DevState {
     uint32_t adj;                 // delta format B: sites whose right neighbour starts another site
     uint32_t ncand;               // slots in the candidate list of this iteration's sparse pass (k_select)
     uint32_t gap;                 // some slot other than the last holds < 3 ids: sparse passes visit every slot
-    uint32_t pad_[3];
+    uint32_t tlive;               // slots [tlive, T) were empty when the stream was last re-packed, and stay so: the host
+                                  // sizes T from a length that is `depth` merges old, and nobody should walk that tail
+    uint32_t pad_[2];
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -85,8 +85,8 @@ k_dp_fold2(uint32_t *__restrict__ delta, uint32_t dl, uint32_t Z, uint32_t *__re
         uint32_t acc = 0;
         if (t <= Z && t < ds) {
             for (uint32_t r = 0; r < nrep; r++) {
-                const uint32_t x = delta[((size_t)r * 4 + v) * ds + t];
-                if (x) delta[((size_t)r * 4 + v) * ds + t] = 0;
+                const uint32_t x = delta[delta_rep_off(r, ds) + (size_t)v * ds + t];
+                if (x) delta[delta_rep_off(r, ds) + (size_t)v * ds + t] = 0;
                 acc += x;
             }
         }
@@ -105,8 +105,8 @@ k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__r
         uint32_t acc = 0;
         if (t <= Z) {
             for (uint32_t r = 0; r < nrep; r++) {
-                const uint32_t x = delta[((size_t)r * 4 + v) * vcap + t];
-                if (x) delta[((size_t)r * 4 + v) * vcap + t] = 0;
+                const uint32_t x = delta[delta_rep_off(r, vcap) + (size_t)v * vcap + t];
+                if (x) delta[delta_rep_off(r, vcap) + (size_t)v * vcap + t] = 0;
                 acc += x;
             }
         }

@@ -17,11 +17,13 @@ namespace bpe {
 // Layout: bucket-major, idx[h * stride + g].  A query reads the three bucket rows of one pair --
 // contiguous, so that the single block that lists a pass's candidates (below) or breaks a tie
 // (k_select) streams a few KB instead of touching one cache line per group.
-constexpr uint32_t IDX_H = 32768;
+// (16 Ki buckets for the ~1000 pairs of a 1024-id slot: about 16 % of a slot's bits set with three
+// hashes, false positives around 0.4 %)
+constexpr uint32_t IDX_H = 16384;
 __device__ __forceinline__ void pair_hash(uint32_t x, uint32_t y, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
-    h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> 17;
-    h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> 17;
-    h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> 17;
+    h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> 18;
+    h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> 18;
+    h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> 18;
 }
 __device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t stride, uint32_t owner, uint32_t x,
                                           uint32_t y) {
@@ -54,25 +56,35 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
     const bool all = st->gap != 0;  // short slots about: adjacency in slot numbers means nothing, visit everything
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    // two groups per thread per round (all their loads in flight together): 65536 slots a round
-    for (uint32_t base = 0; base < nwords; base += 2048) {
-        uint32_t m[2];
+    // four groups per thread per round (all their loads in flight together): 131072 slots a round
+    constexpr int GP = 4;
+    for (uint32_t base = 0; base < nwords; base += GP * 1024) {
+        uint32_t m[GP] = {0, 0, 0, 0};
+        uint32_t c = 0;
+        const uint32_t w4 = base + GP * threadIdx.x;
+        if (w4 < nwords && !all) {
+            // (rows are 16-byte aligned and padded: the stride is a multiple of 4 groups)
+            const uint4 r1 = *reinterpret_cast<const uint4 *>(C.idx + (size_t)h1 * C.stride + w4);
+            const uint4 r2 = *reinterpret_cast<const uint4 *>(C.idx + (size_t)h2 * C.stride + w4);
+            const uint4 r3 = *reinterpret_cast<const uint4 *>(C.idx + (size_t)h3 * C.stride + w4);
+            const uint4 d = *reinterpret_cast<const uint4 *>(C.dirty + w4);
+            m[0] = (r1.x & r2.x & r3.x) | d.x;
+            m[1] = (r1.y & r2.y & r3.y) | d.y;
+            m[2] = (r1.z & r2.z & r3.z) | d.z;
+            m[3] = (r1.w & r2.w & r3.w) | d.w;
+        }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t w = base + 2 * threadIdx.x + u;
-            m[u] = 0;
+        for (int u = 0; u < GP; u++) {
+            const uint32_t w = w4 + u;
             if (w < nwords) {
-                if (all) {
-                    m[u] = 0xFFFFFFFFu;
-                } else {
-                    m[u] = (C.idx[(size_t)h1 * C.stride + w] & C.idx[(size_t)h2 * C.stride + w] &
-                            C.idx[(size_t)h3 * C.stride + w]) | C.dirty[w];
-                }
+                if (all) m[u] = 0xFFFFFFFFu;
                 const uint32_t left = C.T - w * 32;
                 if (left < 32) m[u] &= (1u << left) - 1u;
+            } else {
+                m[u] = 0;
             }
+            c += (uint32_t)__popc(m[u]);
         }
-        const uint32_t c = (uint32_t)(__popc(m[0]) + __popc(m[1]));
         const uint32_t inc = wave_iscan_add(c);
         if (lane_id() == 63) s_wtot[wave_id()] = inc;
         __syncthreads();
@@ -83,8 +95,8 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
             tot += x;
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const uint32_t w = base + 2 * threadIdx.x + u;
+        for (int u = 0; u < GP; u++) {
+            const uint32_t w = base + GP * threadIdx.x + u;
             uint32_t mm = m[u];
             while (mm) {
                 C.cand[off++] = w * 32 + (uint32_t)__ffs((int)mm) - 1u;

@@ -477,7 +477,7 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
         // same-address atomics serialise (~11 ns each): spread them over replicas
         const uint32_t nrep = 1u << (vcap >> 24);  // host packs log2(replicas) above the stride
         vcap &= 0xFFFFFFu;
-        delta += (size_t)(blockIdx.x & (nrep - 1)) * 4 * vcap;
+        delta += delta_rep_off(blockIdx.x & (nrep - 1), vcap);
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             const uint32_t nb_m = lane_next(mb[j], 0);

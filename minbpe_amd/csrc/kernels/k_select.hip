@@ -57,16 +57,16 @@ __device__ __forceinline__ void view_slot(const SlotRef &r, uint64_t n, uint64_t
 }
 
 __device__ __forceinline__ bool slot_get(const SlotRefH &r, uint64_t, uint64_t p, uint32_t &w) {
-    const uint64_t t = p / TILE;
+    const uint64_t t = p / TILE2;
     if (t >= r.T) return false;
     const uint32_t m = r.hdr[t].meta;
-    if ((uint32_t)(p % TILE) >= (m & 0x7FFFFFFFu)) return false;
+    if ((uint32_t)(p % TILE2) >= (m & 0x7FFFFFFFu)) return false;
     w = ((m >> 31) ? r.b1 : r.b0)[p];
     return true;
 }
 __device__ __forceinline__ bool slot_next(const SlotRefH &r, uint64_t n, uint64_t p, uint32_t &w) {
-    uint64_t t = p / TILE;
-    if ((uint32_t)(p % TILE) + 1 < (r.hdr[t].meta & 0x7FFFFFFFu)) return slot_get(r, n, p + 1, w);
+    uint64_t t = p / TILE2;
+    if ((uint32_t)(p % TILE2) + 1 < (r.hdr[t].meta & 0x7FFFFFFFu)) return slot_get(r, n, p + 1, w);
     for (t = t + 1; t < r.T; t++) {
         if (r.hdr[t].meta & 0x7FFFFFFFu) {
             w = r.hdr[t].w0;
@@ -75,14 +75,17 @@ __device__ __forceinline__ bool slot_next(const SlotRefH &r, uint64_t n, uint64_
     }
     return false;
 }
-__device__ __forceinline__ uint64_t slot_space(const SlotRefH &r, uint64_t) { return r.T * (uint64_t)TILE; }
+__device__ __forceinline__ uint64_t slot_space(const SlotRefH &r, uint64_t) { return r.T * (uint64_t)TILE2; }
 __device__ __forceinline__ uint64_t view_slots(const SlotRefH &r, uint64_t) { return r.T; }
 __device__ __forceinline__ void view_slot(const SlotRefH &r, uint64_t, uint64_t u, uint32_t &len,
                                           const uint32_t *&src) {
     const uint32_t m = r.hdr[u].meta;
     len = m & 0x7FFFFFFFu;
-    src = ((m >> 31) ? r.b1 : r.b0) + u * TILE;
+    src = ((m >> 31) ? r.b1 : r.b0) + u * TILE2;
 }
+// slot-space positions: slot u starts at u * view_tile
+__device__ __forceinline__ uint64_t view_tile(const SlotRef &) { return TILE; }
+__device__ __forceinline__ uint64_t view_tile(const SlotRefH &) { return TILE2; }
 
 // K2, block 0: global max over rowmax, then every pair that attains it (the candidates of the
 // reference's first-occurrence tie-break, F3).  rowarg[x] names the column that attains row x's
@@ -205,8 +208,8 @@ __device__ __forceinline__ unsigned long long slot_find_pair(const SlotRefH &ref
     const uint32_t after = (t + 1 < ref.T) ? ref.hdr[t + 1].w0 : INVALID_WORD;
     const uint32_t len = m & 0x7FFFFFFFu;
     if (len == 0) return NOPOS;
-    const uint32_t *src = ((m >> 31) ? ref.b1 : ref.b0) + (size_t)t * TILE;
-    constexpr int SB = 8;  // stripes of 256 words per batch
+    const uint32_t *src = ((m >> 31) ? ref.b1 : ref.b0) + (size_t)t * TILE2;
+    constexpr int SB = TILE2 / 256;  // the whole slot in one batch: 4 stripes of 256 words
     for (uint32_t base = 0; base < len; base += SB * 256) {
         uint4 v[SB];
         uint32_t nx[SB];
@@ -236,7 +239,7 @@ __device__ __forceinline__ unsigned long long slot_find_pair(const SlotRefH &ref
             if (bal) {
                 const int fl = __ffsll((long long)bal) - 1;
                 const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)hit, fl);
-                return (unsigned long long)t * TILE + base + j * 256 + fl * 4 + hk;
+                return (unsigned long long)t * TILE2 + base + j * 256 + fl * 4 + hk;
             }
         }
     }
@@ -257,7 +260,7 @@ __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, 
         unsigned long long found = NOPOS;
         bool done = false;
         for (uint32_t wb = 0; wb < nwords && !done; wb += 64) {
-            if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)wb * 32 * TILE) break;  // cannot win
+            if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)wb * 32 * TILE2) break;  // cannot win
             const uint32_t w = wb + lane;
             uint32_t mk = 0;
             if (w < nwords) {
@@ -274,7 +277,7 @@ __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, 
                 while (mm) {
                     const uint32_t t = (wb + lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
                     mm &= mm - 1u;
-                    if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)t * TILE) {
+                    if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)t * TILE2) {
                         done = true;  // another pair already occurs before this slot
                         break;
                     }
@@ -340,7 +343,7 @@ __device__ __forceinline__ unsigned long long tie_window(const Ref &ref, uint64_
         for (int k = 0; k < 4; k++) {
             if (q + k >= len[u]) break;
             uint32_t w1 = w[k + 1];
-            if (q + k + 1 >= len[u] && !slot_next(ref, n, (uint64_t)u * TILE + q + k, w1)) continue;  // (last word of the slot)
+            if (q + k + 1 >= len[u] && !slot_next(ref, n, (uint64_t)u * view_tile(ref) + q + k, w1)) continue;  // (last word of the slot)
             if (w1 & FLAG) continue;
             const uint32_t x = w[k] & IDMASK, y = w1 & IDMASK;
             if (!((s_bits[x >> 5] >> (x & 31)) & 1u)) continue;
@@ -352,7 +355,7 @@ __device__ __forceinline__ unsigned long long tie_window(const Ref &ref, uint64_
                 hit = mat[(size_t)x * stride + y] == M;
             }
             if (hit) {
-                atomicMin(&s_win, ((unsigned long long)((uint64_t)u * TILE + q + k) << 32) | (x << 16) | y);
+                atomicMin(&s_win, ((unsigned long long)((uint64_t)u * view_tile(ref) + q + k) << 32) | (x << 16) | y);
                 break;  // (my later positions are later)
             }
         }
@@ -483,7 +486,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     const uint64_t n = st->n[par];
     const uint64_t nslots = view_slots(ref, n);
     for (uint64_t u = blockIdx.x; u < nslots; u += gridDim.x) {
-        if (__hip_atomic_load(&st->firstpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < u * TILE) break;
+        if (__hip_atomic_load(&st->firstpos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < u * view_tile(ref)) break;
         uint32_t len;
         const uint32_t *src;
         view_slot(ref, n, u, len, src);
@@ -491,7 +494,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             const uint32_t w0 = src[q];
             uint32_t w1;
             if (q + 1 < len) w1 = src[q + 1];
-            else if (!slot_next(ref, n, u * TILE + q, w1)) continue;
+            else if (!slot_next(ref, n, u * view_tile(ref) + q, w1)) continue;
             if (w1 & FLAG) continue;
             const uint32_t x = w0 & IDMASK, y = w1 & IDMASK;
             bool hit = false;
@@ -502,7 +505,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
                 hit = mat[(size_t)x * stride + y] == M;
             }
             if (hit) {
-                atomicMin(&st->firstpos, (unsigned long long)(u * TILE + q));
+                atomicMin(&st->firstpos, (unsigned long long)(u * view_tile(ref) + q));
                 break;  // later positions of this thread cannot be earlier
             }
         }

@@ -13,9 +13,13 @@
 namespace bpe {
 
 // ---------------------------------------------------------------------------
-// The stream is a sequence of T slots of TILE words; slot t holds `len` ids at the start of
-// its TILE-word home in buffer 0 or 1 (SlotHdr.meta = len | buffer << 31).  Stream order is slot
-// order, so first-occurrence order (F3) is that of slot-space positions t * TILE + offset.
+// The stream is a sequence of T slots of TILE2 = 1024 words; slot t holds `len` ids at the start
+// of its home in buffer 0 or 1 (SlotHdr.meta = len | buffer << 31).  Stream order is slot order,
+// so first-occurrence order (F3) is that of slot-space positions t * TILE2 + offset.
+//
+// ONE WAVE owns a slot: lane l holds ids [4l, 4l+4) of each of four 256-id stripes (every global
+// access a full 1 KiB wave access), all cross-lane traffic is DPP / readlane, and there is no
+// barrier anywhere in an a != b pass.
 //
 // A merge of (a, b), a != b, touches a slot only where `a` is directly followed by `b`:
 //   * the slot that owns the `a` of a site gets the new token there, and OWES the whole
@@ -24,14 +28,13 @@ namespace bpe {
 //     neighbours' headers;
 //   * a slot whose first word is the `b` of a site that started in the previous slot drops it.
 // Every other slot is untouched and owes nothing.  A changed slot is compacted IN PLACE: the
-// workgroup holds all 4096 words in registers before it stores, the output is staged in LDS and
-// written back with 16-byte stores; nobody else reads a slot's words during an a != b pass
-// (neighbours read HEADERS, which are double-buffered or staged).
-//   * dense pass (k_merge_ab_dense): one workgroup per slot, headers ping-pong between two arrays;
-//   * sparse pass (k_merge_ab_sparse): a resident grid; each workgroup owns a contiguous range
-//     of slots and visits only those the inverted index cannot rule out; new headers go to a
-//     staging list that the table-update kernel commits (the header array must stay intact
-//     while neighbours read it).
+// wave holds all 1024 words in registers before it stores, the output is staged in LDS and
+// written back with 16-byte stores, from the first changed word on; nobody else reads a slot's
+// words during an a != b pass (neighbours read HEADERS, which are double-buffered or staged).
+//   * dense pass (k_merge_ab_dense): one wave per slot, headers ping-pong between two arrays;
+//   * sparse pass (k_merge_ab_sparse): a resident grid whose waves work through the candidate
+//     list k_select made from the inverted index; new headers go to a staging area that the
+//     table-update kernel commits (the header array must stay intact while neighbours read it).
 // a == b needs the parity of runs of `a` across slot boundaries (F2): k_merge_aa keeps the
 // first form's out-of-place scheme (write the other buffer, flip the slot's buffer bit; a run
 // is walked back through the previous slots' words, which are not overwritten in that pass).
@@ -65,23 +68,18 @@ struct AbArgs {
     uint32_t *dirty_n;        // reset here for the table update that follows
 };
 
-struct alignas(16) AbLds {
-    uint32_t out[TILE];       // the compacted slot, staged for 16-byte stores (16-byte aligned)
-    uint4 hdr[6];             // headers of slots t-1, t, t+1
-    uint32_t ctx[8];          // slow path: halo0..2, prev2, prev1, index of the previous non-empty slot
-    uint32_t wsum[MT / 64];
-    uint32_t wmin[MT / 64];   // per wave: output offset of its first site
-};
-
 __global__ void __launch_bounds__(256)
 k_slot2_init(SlotHdr *__restrict__ hdr, uint64_t T, DevState *st, int par, uint32_t which,
              const uint32_t *__restrict__ ids) {
     const uint64_t n = st->n[par];
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->gap = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->gap = 0;
+        st->tlive = (uint32_t)min(T, (n + TILE2 - 1) / TILE2);
+    }
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride) {
-        const uint64_t b0 = t * TILE;
-        const uint32_t len = b0 >= n ? 0u : (uint32_t)min((uint64_t)TILE, n - b0);
+        const uint64_t b0 = t * TILE2;
+        const uint32_t len = b0 >= n ? 0u : (uint32_t)min((uint64_t)TILE2, n - b0);
         SlotHdr h;
         h.w0 = len > 0 ? ids[b0] : INVALID_WORD;
         h.w1 = len > 1 ? ids[b0 + 1] : INVALID_WORD;
@@ -95,7 +93,7 @@ k_slot2_init(SlotHdr *__restrict__ hdr, uint64_t T, DevState *st, int par, uint3
 }
 
 // the three words after slot t and the two before it, from headers only (any run of short or
-// empty neighbours; rare)
+// empty neighbours; rare); also which slots they come from
 __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hdr, uint32_t t, uint32_t T,
                                                   uint32_t *ctx) {
     uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
@@ -136,71 +134,66 @@ __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hd
     ctx[6] = tn;
 }
 
-// One slot of an a != b pass, by one 256-thread workgroup.  Returns to the caller in every case
-// (the sparse pass loops over slots); ends with all LDS reads of this slot done only after the
-// caller's next __syncthreads().
+__device__ __forceinline__ uint32_t bcast(uint32_t v, int srclane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, srclane);
+}
+
+// One slot of an a != b pass, by ONE WAVE.  `out` = this wave's 1024 words of LDS staging.
 // INDEXED: the inverted slot index is live and learns the pairs this pass creates (costs ~10
 // VGPRs; the early dense passes, which run before the index exists, use the variant without).
-template <bool SPARSE, bool INDEXED>
-__device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const AbArgs &A, const uint32_t a,
-                                              const uint32_t b) {
-    const int lane = lane_id(), wave = wave_id(), tid = threadIdx.x;
-    const int wrel = wave * WAVE_SPAN;
+// LDSD: every id is below LDSD_CAP and the delta goes into the workgroup's LDS tables `sd`
+// (SL[LDSD_CAP] | SR[LDSD_CAP] | adj | removed), flushed by the kernel when its slots are done.
+template <bool SPARSE, bool INDEXED, bool LDSD>
+__device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t,
+                                              const AbArgs &A, const uint32_t a, const uint32_t b) {
+    const int lane = lane_id();
+    const uint32_t Tl = min(A.T, A.st->tlive);  // no slot from here on holds anything
     // ---- (1) every load that does not depend on another one -------------------------------
     // the slot itself, speculatively from buffer 0 (a slot lives in buffer 1 only between an
-    // a == b pass that rewrote it and the next re-packing), all TILE words whatever its length
-    const uint32_t *src = A.b0 + (size_t)t * TILE;
+    // a == b pass that rewrote it and the next re-packing), all TILE2 words whatever its length;
+    // the headers of slots t-1, t, t+1: six 16-byte pieces, lanes 0..5
+    const uint32_t *src = A.b0 + (size_t)t * TILE2;
     uint4 rv[MJ];
-    uint32_t rt[3], rh[2];  // words after / before this wave's span (wave-uniform addresses)
 #pragma unroll
-    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + wrel + j * 256 + lane * 4);
-#pragma unroll
-    for (int i = 0; i < 3; i++) rt[i] = (wave < MT / 64 - 1) ? src[wrel + WAVE_SPAN + i] : 0u;
-#pragma unroll
-    for (int i = 0; i < 2; i++) rh[i] = (wave > 0) ? src[wrel - 2 + i] : 0u;
-    if (tid < 6) {
-        const long long hi = 2ll * (long long)t - 2 + tid;
-        uint4 v = (tid & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
-                            : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
-        if (hi >= 0 && hi < 2ll * (long long)A.T) v = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
-        S.hdr[tid] = v;
+    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
+    uint4 hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
+                          : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    {
+        const long long hi = 2ll * (long long)t - 2 + lane;
+        if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
     }
-    __syncthreads();
-    const uint4 me0 = S.hdr[2], me1 = S.hdr[3];
-    const uint32_t len = me0.w & 0x7FFFFFFFu, buf = me0.w >> 31;
+    const uint32_t meta = bcast(hv.w, 2);
+    const uint32_t len = meta & 0x7FFFFFFFu, buf = meta >> 31;
+    auto keep_header = [&]() {  // dense: the slot stays as it is (lanes 2 and 3 hold its header)
+        if (!SPARSE && (lane == 2 || lane == 3)) reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + (lane - 2)] = hv;
+    };
     if (len == 0) {
-        if (!SPARSE && tid == 0) {
-            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = me0;
-            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = me1;
-        }
+        keep_header();
         return;
     }
     if (buf) {  // (uniform) the slot lives in the other buffer: load again
-        src = A.b1 + (size_t)t * TILE;
+        src = A.b1 + (size_t)t * TILE2;
 #pragma unroll
-        for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + wrel + j * 256 + lane * 4);
-#pragma unroll
-        for (int i = 0; i < 3; i++) rt[i] = (wave < MT / 64 - 1) ? src[wrel + WAVE_SPAN + i] : 0u;
-#pragma unroll
-        for (int i = 0; i < 2; i++) rh[i] = (wave > 0) ? src[wrel - 2 + i] : 0u;
+        for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
     }
     // ---- (2) context: three words after the slot, two before it ----------------------------
-    uint32_t halo0 = S.hdr[4].x, halo1 = S.hdr[4].y, halo2 = S.hdr[4].z;
-    uint32_t prev2 = S.hdr[1].x, prev1 = S.hdr[1].y;
+    const uint32_t first = bcast(hv.x, 2);
+    uint32_t halo0 = bcast(hv.x, 4), halo1 = bcast(hv.y, 4), halo2 = bcast(hv.z, 4);
+    uint32_t prev2 = bcast(hv.x, 1), prev1 = bcast(hv.y, 1);
     uint32_t tprev = t - 1;  // the slot that owns the word before mine (t == 0: none, and prev1 is invalid)
     uint32_t tnext = t + 1;  // ... and the words after mine
     {
-        const uint32_t nlen = S.hdr[4].w & 0x7FFFFFFFu, plen = S.hdr[0].w & 0x7FFFFFFFu;
-        if ((t + 1 < A.T && nlen < 3) || (t > 0 && plen < 2)) {  // (uniform, rare)
-            if (tid == 0) slot_context_walk(A.hdr_in, t, A.T, S.ctx);
-            __syncthreads();
-            halo0 = S.ctx[0];
-            halo1 = S.ctx[1];
-            halo2 = S.ctx[2];
-            prev2 = S.ctx[3];
-            prev1 = S.ctx[4];
-            tprev = S.ctx[5];
-            tnext = S.ctx[6];
+        const uint32_t nlen = bcast(hv.w, 4) & 0x7FFFFFFFu, plen = bcast(hv.w, 0) & 0x7FFFFFFFu;
+        if ((t + 1 < Tl && nlen < 3) || (t > 0 && plen < 2)) {  // (uniform, rare)
+            uint32_t ctx[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (lane == 0) slot_context_walk(A.hdr_in, t, Tl, ctx);
+            halo0 = bcast(ctx[0], 0);
+            halo1 = bcast(ctx[1], 0);
+            halo2 = bcast(ctx[2], 0);
+            prev2 = bcast(ctx[3], 0);
+            prev1 = bcast(ctx[4], 0);
+            tprev = bcast(ctx[5], 0);
+            tnext = bcast(ctx[6], 0);
         }
     }
     // ---- (3) my words: positions >= len come from the halo, then nothing -------------------
@@ -211,17 +204,15 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
     uint32_t x[MJ][4];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        const int q0 = wrel + j * 256 + lane * 4;
+        const int q0 = j * 256 + lane * 4;
         x[j][0] = at(q0 + 0, rv[j].x);
         x[j][1] = at(q0 + 1, rv[j].y);
         x[j][2] = at(q0 + 2, rv[j].z);
         x[j][3] = at(q0 + 3, rv[j].w);
     }
-    uint32_t tail[3], head[2];
+    uint32_t tail[3];  // positions TILE2 .. TILE2+2: beyond any slot's own words
 #pragma unroll
-    for (int i = 0; i < 3; i++) tail[i] = at(wrel + WAVE_SPAN + i, rt[i]);
-    head[0] = wave > 0 ? at(wrel - 2, rh[0]) : prev2;
-    head[1] = wave > 0 ? at(wrel - 1, rh[1]) : prev1;
+    for (int i = 0; i < 3; i++) tail[i] = at(TILE2 + i, 0u);
     // ---- (4) r bits: r[q] = 1 iff (word[q], word[q+1]) is the pair; a != b, so m = r ----------
     uint32_t rb[MJ], valid[MJ];
     uint32_t anyr = 0;
@@ -235,34 +226,27 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
             const uint32_t nxt = (k < 3) ? x[j][k + 1] : nx;
             r |= (uint32_t)(((x[j][k] & IDMASK) == a) & ((nxt & NWMASK) == b)) << k;
         }
-        const int nb = (int)len - (wrel + j * 256 + lane * 4);
+        const int nb = (int)len - (j * 256 + lane * 4);
         valid[j] = nb >= 4 ? 0xFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
         rb[j] = r;
         anyr |= r & valid[j];
     }
     // carry: my first word is the `b` of a site that starts at the previous slot's last word
-    const uint32_t s = (uint32_t)((prev1 != INVALID_WORD) & ((prev1 & IDMASK) == a) & ((me0.x & NWMASK) == b));
-    const bool sites = __syncthreads_or((int)(anyr != 0)) != 0;
-    if (!sites && !s) {
-        // nothing in this slot changes and it owes no table update
-        if (!SPARSE && tid == 0) {
-            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = me0;
-            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = me1;
-        }
+    const uint32_t s = (uint32_t)((prev1 != INVALID_WORD) & ((prev1 & IDMASK) == a) & ((first & NWMASK) == b));
+    const bool sites = __any(anyr != 0) != 0;
+    if (!sites && !s) {  // nothing in this slot changes and it owes no table update
+        keep_header();
         return;
     }
     // ---- (5) kept flags, output offsets -------------------------------------------------------
-    uint32_t mb[MJ], kb[MJ], ex[MJ];
-    const uint32_t rhead = wave > 0 ? (uint32_t)(((head[1] & IDMASK) == a) & ((x[0][0] & NWMASK) == b)) : s;
-    uint32_t cnt[MJ];
+    uint32_t mb[MJ], kb[MJ], ex[MJ], cnt[MJ];
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         mb[j] = rb[j] & valid[j];
         // r of the position before my group: the previous lane's bit 3, the previous stripe's
-        // last lane, or (first group of the wave) the word before the wave's span
-        const uint32_t upr = (j > 0) ? ((lane_last(rb[(j + MJ - 1) % MJ]) >> 3) & 1u) : rhead;
-        const uint32_t mprev = (uint32_t)dpp_mov<0x138>((int)upr, (int)((rb[j] >> 3) & 1u));  // wave_shr:1
-        const uint32_t mp = (lane == 0) ? upr : mprev;
+        // last lane, or (first group of the slot) the carry
+        const uint32_t upr = (j > 0) ? ((lane_last(rb[(j + MJ - 1) % MJ]) >> 3) & 1u) : s;
+        const uint32_t mp = (uint32_t)dpp_mov<0x138>((int)upr, (int)((rb[j] >> 3) & 1u));  // wave_shr:1, lane 0 keeps upr
         kb[j] = ~((mb[j] << 1) | mp) & valid[j] & 0xFu;
         cnt[j] = (uint32_t)__popc(kb[j]);
     }
@@ -275,56 +259,49 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
     ex[1] = tot0 + (i01 >> 16) - cnt[1];
     ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
     ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
-    if (lane == 0) S.wsum[wave] = tot0 + tot1 + tot2 + tot3;
-    __syncthreads();
-    uint32_t wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < MT / 64; w++) {
-        const uint32_t v = S.wsum[w];
-        if (w < wave) wbase += v;
-        total += v;
-    }
+    const uint32_t total = tot0 + tot1 + tot2 + tot3;
     // ---- (6) stage the compacted slot in LDS, then 16-byte stores back to its home -------------
     // (everything before the first site keeps its place and value: only the rest is stored)
-    {
+    uint32_t fstore = 0;  // a dropped first word moves everything
+    if (!s) {
         uint32_t fc = 0x7FFFFFFFu;
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             if (mb[j]) {
                 const uint32_t k0 = (uint32_t)__ffs((int)mb[j]) - 1u;
-                fc = min(fc, wbase + ex[j] + (uint32_t)__popc(kb[j] & ((1u << k0) - 1u)));
+                fc = min(fc, ex[j] + (uint32_t)__popc(kb[j] & ((1u << k0) - 1u)));
             }
         }
-        fc = (uint32_t)wave_min_i32((int)fc);
-        if (lane == 0) S.wmin[wave] = fc;
+        fstore = (uint32_t)wave_min_i32((int)fc) & ~3u;
     }
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        uint32_t o = wbase + ex[j];
+        uint32_t o = ex[j];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if ((kb[j] >> k) & 1u) {
                 const uint32_t w = x[j][k];
-                S.out[o++] = ((mb[j] >> k) & 1u) ? (A.newid | (w & (FLAG | WMASK))) : w;
+                out[o++] = ((mb[j] >> k) & 1u) ? (A.newid | (w & (FLAG | WMASK))) : w;
             }
         }
     }
-    __syncthreads();
+    // (the wave's LDS operations complete in issue order: its own reads below see these writes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-        uint32_t *dst = (buf ? A.b1 : A.b0) + (size_t)t * TILE;
-        uint32_t first = 0;  // a dropped first word moves everything
-        if (!s) first = min(min(S.wmin[0], S.wmin[1]), min(S.wmin[2], S.wmin[3])) & ~3u;
-        for (uint32_t i = first + (uint32_t)tid * 4; i < total; i += MT * 4)
-            *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(&S.out[i]);
+        uint32_t *dst = (buf ? A.b1 : A.b0) + (size_t)t * TILE2;
+        for (uint32_t i = fstore + (uint32_t)lane * 4; i < total; i += 256)
+            *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(&out[i]);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         uint32_t h[8];
-        h[0] = total > 0 ? S.out[0] : INVALID_WORD;
-        h[1] = total > 1 ? S.out[1] : INVALID_WORD;
-        h[2] = total > 2 ? S.out[2] : INVALID_WORD;
+        h[0] = total > 0 ? out[0] : INVALID_WORD;
+        h[1] = total > 1 ? out[1] : INVALID_WORD;
+        h[2] = total > 2 ? out[2] : INVALID_WORD;
         h[3] = total | (buf << 31);
-        h[4] = total > 1 ? S.out[total - 2] : INVALID_WORD;
-        h[5] = total > 0 ? S.out[total - 1] : INVALID_WORD;
+        h[4] = total > 1 ? out[total - 2] : INVALID_WORD;
+        h[5] = total > 0 ? out[total - 1] : INVALID_WORD;
         h[6] = h[7] = 0;
         if (!SPARSE) {
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
@@ -336,28 +313,29 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
             for (int i = 0; i < 8; i++) r->h[i] = h[i];
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
-        atomicAdd(&A.removed[t & 255u], len - total);
-        if (total < 3 && t + 1 < A.T) A.st->gap = 1;
+        if (LDSD) atomicAdd(&sd[2 * LDSD_CAP + 1], len - total);
+        else atomicAdd(&A.removed[(t & 255u) * REMOVED_STRIDE], len - total);
+        if (total < 3 && t + 1 < Tl) A.st->gap = 1;
     }
     // ---- (7) pair-table delta of my sites (format B); their new pairs enter the index -----------
     if (!sites) return;  // carry only: the site belongs to the previous slot
     if (!A.delta) return;  // (experiment "exp_no_delta": time the pass without its table bookkeeping; results are wrong)
     const uint32_t nrep = 1u << (A.vcap >> 24);
     const uint32_t vc = A.vcap & 0xFFFFFFu;
-    uint32_t *dl = A.delta + (size_t)(t & (nrep - 1)) * 4 * vc;  // SL
-    uint32_t *dr = dl + vc;                                                        // SR
+    uint32_t *dl = A.delta + delta_rep_off(t & (nrep - 1), vc);  // SL
+    uint32_t *dr = dl + vc;                                      // SR
     uint32_t adj = 0;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
-        if (!__any(mb[j] != 0)) continue;  // (uniform per wave) no site in this stripe
+        if (!__any(mb[j] != 0)) continue;  // (uniform) no site in this stripe
         // two words before my group, three after it
         uint32_t upm2, upm1, dn0, dn1, dn2;
         if (j > 0) {
             upm2 = lane_last(x[(j + MJ - 1) % MJ][2]);
             upm1 = lane_last(x[(j + MJ - 1) % MJ][3]);
         } else {
-            upm2 = head[0];
-            upm1 = head[1];
+            upm2 = prev2;
+            upm1 = prev1;
         }
         if (j < MJ - 1) {
             dn0 = lane_first(x[(j + 1) % MJ][0]);
@@ -369,12 +347,8 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
             dn2 = tail[2];
         }
         uint32_t W[9];
-        {
-            const uint32_t pm2 = (uint32_t)dpp_mov<0x138>((int)upm2, (int)x[j][2]);
-            const uint32_t pm1 = (uint32_t)dpp_mov<0x138>((int)upm1, (int)x[j][3]);
-            W[0] = lane == 0 ? upm2 : pm2;
-            W[1] = lane == 0 ? upm1 : pm1;
-        }
+        W[0] = (uint32_t)dpp_mov<0x138>((int)upm2, (int)x[j][2]);  // (lane 0 keeps upm2 / upm1)
+        W[1] = (uint32_t)dpp_mov<0x138>((int)upm1, (int)x[j][3]);
         W[2] = x[j][0];
         W[3] = x[j][1];
         W[4] = x[j][2];
@@ -386,19 +360,21 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (!((mb[j] >> k) & 1u)) continue;
+            const int q = j * 256 + lane * 4 + k;
             const uint32_t wa = W[k + 2];
             const uint32_t wt = word_weight(wa);
-            const uint32_t L = W[k + 1], LL = W[k];
-            if (!(wa & FLAG) && L != INVALID_WORD) {
-                const bool ltail = ((LL & IDMASK) == a) & ((L & NWMASK) == b);
+            const uint32_t Lw = W[k + 1], LL = W[k];
+            if (!(wa & FLAG) && Lw != INVALID_WORD) {
+                const bool ltail = ((LL & IDMASK) == a) & ((Lw & NWMASK) == b);
                 if (!ltail) {
-                    atomicAdd(&dl[L & IDMASK], wt);
+                    if (LDSD) atomicAdd(&sd[Lw & IDMASK], wt);
+                    else atomicAdd(&dl[Lw & IDMASK], wt);
                     // the new pair (L, Z) enters the filter of the slot that holds L, and mine too if
                     // that is another slot (a boundary pair is known to both slots it touches: the
                     // one that owns its site and the one that drops the site's second word)
                     if (INDEXED) {
-                        index_add(A.idx, A.istride, t, L & IDMASK, A.newid);
-                        if (wrel + j * 256 + lane * 4 + k == 0) index_add(A.idx, A.istride, tprev, L & IDMASK, A.newid);
+                        index_add(A.idx, A.istride, t, Lw & IDMASK, A.newid);
+                        if (q == 0) index_add(A.idx, A.istride, tprev, Lw & IDMASK, A.newid);
                     }
                 }
             }
@@ -406,48 +382,102 @@ __device__ __forceinline__ void merge_ab_tile(AbLds &S, const uint32_t t, const 
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
                 const bool rsite = ((R & IDMASK) == a) & ((RR & NWMASK) == b);
                 if (rsite) adj += wt;
+                else if (LDSD) atomicAdd(&sd[LDSD_CAP + (R & IDMASK)], wt);
                 else atomicAdd(&dr[R & IDMASK], wt);
                 if (INDEXED) {
                     const uint32_t y = rsite ? A.newid : (R & IDMASK);
                     index_add(A.idx, A.istride, t, A.newid, y);
-                    if (wrel + j * 256 + lane * 4 + k + 2 >= (int)len) index_add(A.idx, A.istride, tnext, A.newid, y);
+                    if (q + 2 >= (int)len) index_add(A.idx, A.istride, tnext, A.newid, y);
                 }
             }
         }
     }
     if (__any(adj != 0)) {
         adj = wave_sum_u32(adj);
-        if (lane == 0) atomicAdd(&A.st->adj, adj);
+        if (lane == 0) {
+            if (LDSD) atomicAdd(&sd[2 * LDSD_CAP], adj);
+            else atomicAdd(&A.st->adj, adj);
+        }
     }
 }
 
-// dense a != b pass: one workgroup per slot
+// LDSD kernels: clear the tables / add them to this workgroup's replica of the delta vectors
+__device__ __forceinline__ void ldsd_clear(uint32_t *sd) {
+    for (uint32_t i = threadIdx.x; i < 2 * LDSD_CAP + 2; i += MT) sd[i] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void ldsd_flush(const uint32_t *sd, const AbArgs &A) {
+    __syncthreads();
+    const uint32_t nrep = 1u << (A.vcap >> 24);
+    const uint32_t vc = A.vcap & 0xFFFFFFu;
+    if (A.delta) {
+        uint32_t *g = A.delta + delta_rep_off(blockIdx.x & (nrep - 1), vc);
+        const uint32_t lim = min(vc, (uint32_t)LDSD_CAP);
+        for (uint32_t i = threadIdx.x; i < lim; i += MT) {
+            const uint32_t l = sd[i], r = sd[LDSD_CAP + i];
+            if (l) atomicAdd(&g[i], l);
+            if (r) atomicAdd(&g[vc + i], r);
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
+        if (adj) atomicAdd(&A.st->adj, adj);
+        if (rem) atomicAdd(&A.removed[(blockIdx.x & 255u) * REMOVED_STRIDE], rem);
+    }
+}
+
+// dense a != b pass: one wave per slot (four per workgroup)
 template <bool INDEXED>
 __global__ void __launch_bounds__(MT, INDEXED ? 5 : 7)
 k_merge_ab_dense(AbArgs A) {
-    __shared__ AbLds S;
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
     const DevState *st = A.st;
     if (blockIdx.x == 0 && threadIdx.x == 0) *A.dirty_n = 0;
-    if (blockIdx.x >= A.T || st->status) return;
+    const uint32_t t = blockIdx.x * (MT / 64) + wave_id();
+    if (t >= A.T || st->status) return;
+    if (!st->found) {
+        if (t == 0 && lane_id() == 0) A.st->status = ST_INTERNAL;
+        return;
+    }
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    if (a == b) return;  // k_merge_aa's pass
+    merge_ab_wave<false, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+}
+// ... while every id is below LDSD_CAP: a resident grid (five workgroups per CU), wave w of the
+// grid takes slots w, w + waves, ...; the delta goes through LDS
+template <bool INDEXED>
+__global__ void __launch_bounds__(MT, 5)
+k_merge_ab_dense_early(AbArgs A) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
+    __shared__ uint32_t s_delta[2 * LDSD_CAP + 2];
+    const DevState *st = A.st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *A.dirty_n = 0;
+    if (st->status) return;
     if (!st->found) {
         if (blockIdx.x == 0 && threadIdx.x == 0) A.st->status = ST_INTERNAL;
         return;
     }
     const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
-    if (a == b) return;  // k_merge_aa's pass
-    merge_ab_tile<false, INDEXED>(S, blockIdx.x, A, a, b);
+    if (a == b) return;
+    ldsd_clear(s_delta);
+    const uint32_t nw = gridDim.x * (MT / 64);
+    for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
+        merge_ab_wave<false, INDEXED, true>(s_out[wave_id()], s_delta, t, A, a, b);
+    ldsd_flush(s_delta, A);
 }
 
-// sparse a != b pass: a resident grid works through the candidate list that the deciding block of
-// k_select made from the index (st->ncand slots in A.cand: every slot whose filter admits the
-// pair, plus the slots an a == b pass rewrote since the index was built; all slots while
-// st->gap is up) -- evenly dealt, so the pass ends when ceil(ncand / grid) tiles are done.
+// sparse a != b pass: a resident grid whose waves work through the candidate list that the
+// deciding block of k_select made from the index (st->ncand slots in A.cand: every slot whose
+// filter admits the pair, plus the slots an a == b pass rewrote since the index was built; all
+// slots while st->gap is up) -- evenly dealt, wave by wave.
 #ifndef AB_SPARSE_WAVES
 #define AB_SPARSE_WAVES 4
 #endif
+template <bool LDSD>
 __global__ void __launch_bounds__(MT, AB_SPARSE_WAVES)
 k_merge_ab_sparse(AbArgs A) {
-    __shared__ AbLds S;
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
+    __shared__ uint32_t s_delta[LDSD ? 2 * LDSD_CAP + 2 : 1];
     const DevState *st = A.st;
     if (blockIdx.x == 0 && threadIdx.x == 0) *A.dirty_n = 0;
     if (st->status) return;
@@ -458,17 +488,22 @@ k_merge_ab_sparse(AbArgs A) {
     const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
     if (a == b) return;
     const uint32_t n = st->ncand;
-    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        merge_ab_tile<true, true>(S, A.cand[i], A, a, b);
-        __syncthreads();
+    const uint32_t nw = gridDim.x * (MT / 64);
+    if (LDSD) {
+        if (blockIdx.x * (MT / 64) >= n) return;  // (uniform) none of my waves has a slot
+        ldsd_clear(s_delta);
     }
+    for (uint32_t i = blockIdx.x * (MT / 64) + wave_id(); i < n; i += nw)
+        merge_ab_wave<true, true, LDSD>(s_out[wave_id()], s_delta, A.cand[i], A, a, b);
+    if (LDSD) ldsd_flush(s_delta, A);
 }
 
 // ---------------------------------------------------------------------------
-// a == b pass (runs only when the decided pair has a == b; a resident grid striding over ALL
-// slots).  The first form's algorithm (k_slots.hip: run-parity carry found by walking the run
-// back through the previous slots, out-of-place rewrite, format A delta, every pair charged to
-// its left element) on the 32-byte headers.
+// a == b pass (runs only when the decided pair has a == b; a resident grid of single-wave
+// workgroups striding over ALL slots).  The first form's algorithm (k_slots.hip: run-parity carry
+// found by walking the run back through the previous slots, out-of-place rewrite, format A delta,
+// every pair charged to its left element) on the 32-byte headers and one-wave slots: the tile
+// helpers of k_merge.hip with a single wave (its span IS the slot).
 struct AaArgs {
     const uint32_t *b0, *b1;
     uint32_t *w0, *w1;
@@ -509,15 +544,20 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
         return;
     }
     const uint32_t cur = mi >> 31;
-    const uint32_t *src = (cur ? A.b1 : A.b0) + (size_t)t * TILE;
+    const uint32_t *src = (cur ? A.b1 : A.b0) + (size_t)t * TILE2;
     if (threadIdx.x == 0) {
-        slot_context_walk(A.hdr_in, t, A.T, s_ctx);
+        slot_context_walk(A.hdr_in, t, min(A.T, A.st->tlive), s_ctx);
         s_hdr[0] = hme.w0;
         s_hdr[1] = hme.w1;
         s_hdr[2] = hme.w2;
         s_hdr[3] = hme.meta;
         s_hdr[4] = hme.l0;
         s_hdr[5] = hme.l1;
+    }
+    // (the tile helpers exchange per-wave values of a 4-wave workgroup through these: one wave here)
+    if (threadIdx.x < MT / 64) {
+        s_wave[threadIdx.x] = -1;
+        s_wsum[threadIdx.x] = 0;
     }
     SlotRaw raw;
     slot_raw_load(raw, src, len);
@@ -547,7 +587,7 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
                     if (mu & 0x7FFFFFFFu) break;
                 }
                 const int lu = (int)(mu & 0x7FFFFFFFu);
-                const uint32_t *pu = ((mu >> 31) ? A.b1 : A.b0) + (size_t)u * TILE;
+                const uint32_t *pu = ((mu >> 31) ? A.b1 : A.b0) + (size_t)u * TILE2;
                 int ones = 0;       // r-ones counted so far, walking back from the last id
                 bool open = true;   // no zero met yet
                 uint32_t nextw = s_first_word;  // the word after the current position
@@ -599,7 +639,7 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
     // fast path: no match at any owned position, none at the first word after the slot, no carry
     {
         uint32_t anyr = s;
-        const int qw = wave_id() * WAVE_SPAN + lane_id() * 4;
+        const int qw = lane_id() * 4;
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
             const int q0 = qw + j * 256;
@@ -607,8 +647,8 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
             const uint32_t keep = nb >= 4 ? 0xFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
             anyr |= tl.rb[j] & keep;
         }
-        if (len == TILE && wave_id() == MT / 64 - 1)
-            anyr |= (uint32_t)(((tl.tail[0] & IDMASK) == a) & ((tl.tail[1] & NWMASK) == b));
+        // a full slot: the word after it is the wave's tail, not one of my registers
+        if (len == TILE2) anyr |= (uint32_t)(((tl.tail[0] & IDMASK) == a) & ((tl.tail[1] & NWMASK) == b));
         if (!__syncthreads_or((int)(anyr != 0))) {
             if (threadIdx.x == 0) keep_header();
             return;
@@ -617,7 +657,7 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
     tile_lzscan(tl, s_wave);
     uint32_t kept = 0;
     bool changed = false;
-    uint32_t *dst = (cur ? A.w0 : A.w1) + (size_t)t * TILE;  // the OTHER buffer
+    uint32_t *dst = (cur ? A.w0 : A.w1) + (size_t)t * TILE2;  // the OTHER buffer
     tile_rewrite<true, true, 1>(tl, s, a, b, A.newid, dst, s_wsum, A.delta, A.vcap, len, &kept, &changed, s_hdr);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -641,8 +681,8 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
                 r->h[5] = s_hdr[5];
                 r->h[6] = r->h[7] = 0;
             }
-            atomicAdd(&A.removed[t & 255u], (uint32_t)len - kept);
-            if (kept < 3 && t + 1 < A.T) A.st->gap = 1;
+            atomicAdd(&A.removed[(t & 255u) * REMOVED_STRIDE], (uint32_t)len - kept);
+            if (kept < 3 && t + 1 < min(A.T, A.st->tlive)) A.st->gap = 1;
             if (A.dirty) {
                 // its pairs changed, and so did the boundary pairs it shares with both neighbours:
                 // none of that is in the index until the next build
@@ -656,15 +696,11 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
     }
 }
 
-__global__ void __launch_bounds__(MT)
+__global__ void __launch_bounds__(64)
 k_merge_aa(AaArgs A) {
     const DevState *st = A.st;
-    // (one thread reads the status for the whole workgroup: another workgroup may raise it while
-    // this one starts, and a barrier-laden tile must be entered by all waves or by none)
-    __shared__ uint32_t s_run;
-    if (threadIdx.x == 0) s_run = (st->status == 0 && st->found != 0);  // (a missing decision is reported by the a != b kernel)
-    __syncthreads();
-    if (!s_run) return;
+    // (one wave per workgroup: every thread reads the same values, and barriers are wave-local)
+    if (st->status || !st->found) return;  // (a missing decision is reported by the a != b kernel)
     const uint32_t a = (uint32_t)st->a;
     if (a != (uint32_t)st->b) return;
     for (uint32_t t = blockIdx.x; t < A.T; t += gridDim.x) {
@@ -675,24 +711,28 @@ k_merge_aa(AaArgs A) {
 
 // ---------------------------------------------------------------------------
 // Index build: one workgroup per group of 32 slots, the group's IDX_H x 32-bit filter in LDS
-// (128 KiB), three ds_or per pair, then one coalesced write of the group's row into a
+// (64 KiB), three ds_or per pair, then one coalesced write of the group's row into a
 // group-major scratch image; k_index_transpose turns that into the bucket-major index.  No global
 // atomics.  Also clears the group's `dirty` word.
 __global__ void __launch_bounds__(1024)
 k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, const SlotHdr *__restrict__ hdr,
-              uint32_t T, uint32_t *__restrict__ idx, uint32_t *__restrict__ dirty) {
+              uint32_t T, uint32_t *__restrict__ scratch, uint32_t *__restrict__ dirty,
+              const DevState *__restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mask[];
     const uint32_t g = blockIdx.x;
+    const uint32_t Tl = min(T, st->tlive);  // (the walk below must not run down an empty tail)
     for (uint32_t i = threadIdx.x; i < IDX_H; i += 1024) s_mask[i] = 0;
     if (threadIdx.x == 0) dirty[g] = 0;
     __syncthreads();
-    for (uint32_t sl = 0; sl < 32; sl++) {
+    // 1024 threads x 4 words = four slots per round, eight rounds
+    for (uint32_t it = 0; it < 8; it++) {
+        const uint32_t sl = it * 4 + (threadIdx.x >> 8);
         const uint32_t t = g * 32 + sl;
-        if (t >= T) break;
+        if (t >= T) continue;
         const uint32_t m = hdr[t].meta;
         const uint32_t len = m & 0x7FFFFFFFu;
-        const uint32_t *src = ((m >> 31) ? b1 : b0) + (size_t)t * TILE;
-        const uint32_t q = threadIdx.x * 4;
+        const uint32_t *src = ((m >> 31) ? b1 : b0) + (size_t)t * TILE2;
+        const uint32_t q = (threadIdx.x & 255u) * 4;
         if (q >= len) continue;
         const uint4 v = *reinterpret_cast<const uint4 *>(src + q);
         uint32_t x[5] = {v.x, v.y, v.z, v.w, INVALID_WORD};
@@ -701,7 +741,7 @@ k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, 
         } else {
             // the word after the slot: first word of the next non-empty slot (headers)
             uint32_t nxt = INVALID_WORD;
-            for (uint32_t u = t + 1; u < T; u++) {
+            for (uint32_t u = t + 1; u < Tl; u++) {
                 if (hdr[u].meta & 0x7FFFFFFFu) {
                     nxt = hdr[u].w0;
                     break;
@@ -743,7 +783,7 @@ k_index_build(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1, 
         }
     }
     __syncthreads();
-    uint32_t *row = idx + (size_t)g * IDX_H;
+    uint32_t *row = scratch + (size_t)g * IDX_H;
     for (uint32_t i = threadIdx.x; i < IDX_H; i += 1024) row[i] = s_mask[i];
 }
 
@@ -775,16 +815,18 @@ k_slot2_lens(const SlotHdr *__restrict__ hdr, uint64_t T, uint32_t *__restrict__
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += stride)
         lens[t] = hdr[t].meta & 0x7FFFFFFFu;
 }
+// (one wave per slot, four slots per workgroup)
 __global__ void __launch_bounds__(256)
 k_slot2_compact(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1,
-                const SlotHdr *__restrict__ hdr, const unsigned long long *__restrict__ off,
+                const SlotHdr *__restrict__ hdr, uint64_t T, const unsigned long long *__restrict__ off,
                 uint32_t *__restrict__ out) {
-    const uint64_t t = blockIdx.x;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + wave_id();
+    if (t >= T) return;
     const uint32_t m = hdr[t].meta;
     const uint32_t len = m & 0x7FFFFFFFu;
-    const uint32_t *src = ((m >> 31) ? b1 : b0) + t * TILE;
+    const uint32_t *src = ((m >> 31) ? b1 : b0) + t * TILE2;
     uint32_t *dst = out + off[t];
-    for (uint32_t i = threadIdx.x; i < len; i += 256) dst[i] = src[i];
+    for (uint32_t i = lane_id(); i < len; i += 64) dst[i] = src[i];
 }
 
 }  // namespace bpe

@@ -68,13 +68,13 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
                     const uint32_t r = r0 + 8u * k;
-                    x[k][v] = (r < nrep && v < nv) ? delta[((size_t)r * 4 + v) * vcap + t] : 0u;
+                    x[k][v] = (r < nrep && v < nv) ? delta[delta_rep_off(r, vcap) + (size_t)v * vcap + t] : 0u;
                 }
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    if (x[k][v]) delta[((size_t)(r0 + 8u * k) * 4 + v) * vcap + t] = 0;
+                    if (x[k][v]) delta[delta_rep_off(r0 + 8u * k, vcap) + (size_t)v * vcap + t] = 0;
                     acc4[v] += x[k][v];
                 }
         }
@@ -243,12 +243,12 @@ k_apply2(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ del
          SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage, uint32_t *__restrict__ removed,
          uint32_t *__restrict__ smask, uint32_t nwords) {
     if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // ids removed by the merge pass: 256 counters (one would serialise every changed slot)
+        // ids removed by the merge pass: 256 counters, one per 256-byte line (see DELTA_SKEW)
         uint32_t v = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t x = removed[threadIdx.x * 4 + i];
-            if (x) removed[threadIdx.x * 4 + i] = 0;
+            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
             v += x;
         }
         v = wave_sum_u32(v);

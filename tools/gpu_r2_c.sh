@@ -5,7 +5,8 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 exec </dev/null
 timeout -k 5 900 python -X faulthandler -m pytest tests -m gpu -q --maxfail=${MAXFAIL:-12} -k "not cfg2_all and not cfg3_shape ${PYTEST_K}" > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest rc=$?"; tail -30 gpurun_out/pytest_gpu.log | cut -c1-300
+RC=$?; echo "pytest rc=$RC"; tail -30 gpurun_out/pytest_gpu.log | cut -c1-300
+if [ $RC -ne 0 ]; then echo "tests failed: stopping here"; exit 1; fi
 timeout -k 5 300 python tools/iter_profile.py regex1g ${ITER_OPTS} > gpurun_out/iter_regex1g_c.json 2> gpurun_out/iter_regex1g_c.err; echo "iter rc=$?"; tail -12 gpurun_out/iter_regex1g_c.err | cut -c1-250
 python -c "
 import json; d=json.load(open('gpurun_out/iter_regex1g_c.json')); print(d['passes'], d['total_ms'], d['device_ms_by_class'])"

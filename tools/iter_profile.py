@@ -18,13 +18,13 @@ from minbpe_amd import Engine  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "regex1g"
 wl = dict(bench.WORKLOADS[name])
 data, offs, prep = bench.make_input(wl)
-nm = wl["vocab"] - 256
+nm = int(os.environ.get("ITERS", wl["vocab"] - 256))
 eng = Engine(0)
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     eng.set_option(k, int(v))
 eng.load_bytes(data, offs)
-eng.train(64)
+eng.train(min(64, nm))
 eng.set_option("profile", 2)
 eng.prof_reset()
 res = eng.train(nm)
@@ -37,7 +37,8 @@ lens = np.array(res["lens"])
 same = np.array([a == b for a, b in res["pairs"]])
 out = {"workload": name, "options": sys.argv[2:], "total_ms": round(float(ms.sum()) / 1e3, 1),
        "a_eq_b_merges": int(same.sum()), "passes": eng.train_stats(),
-       "device_ms_by_class": {k: round(v["ms"], 1) for k, v in bd.items() if v["ms"]}, "bins": []}
+       "device_ms_by_class": {k: round(v["ms"], 1) for k, v in bd.items() if v["ms"]}, "bins": [],
+       "first_iters": [[int(round(float(m))), int(c), int(l)] for m, c, l in zip(ms[:160], cnt[:160], lens[:160])]}
 edges = [0, 10, 100, 300, 1000, 2000, 4000, 8000, 16000, 24000, nm]
 for lo, hi in zip(edges[:-1], edges[1:]):
     if lo >= nm:
