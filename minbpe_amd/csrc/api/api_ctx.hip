@@ -71,6 +71,8 @@ struct bpe_ctx {
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
     int rep_max = 8;                          // log2 of the most delta-vector replicas a pass may use (experiments)
+    int rep_min = 4;                          // option "rep_min": log2 of the fewest delta replicas a pass uses (a hot token's
+                                              // atomics queue ~11 ns apiece per replica: 16 replicas beat 1 by ~2 us per late pass)
     int lds_delta = 1;                        // option "lds_delta": a != b passes aggregate their delta in LDS while ids < LDSD_CAP
     int exp_no_delta = 0;                     // experiment: a != b passes skip the pair-table bookkeeping (wrong results)
     int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
@@ -696,7 +698,7 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
     while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;  // (the skew has its own room)
     const uint64_t cnt = c->last_count;
     const int want = cnt >= (1u << 20) ? 8 : (cnt >= (1u << 16) ? 5 : (cnt >= (1u << 12) ? 3 : 0));
-    return dstride | ((uint32_t)std::min(std::min(shift, want), c->rep_max) << 24);
+    return dstride | ((uint32_t)std::min(std::min(shift, std::max(want, c->rep_min)), c->rep_max) << 24);
 }
 
 // Will this iteration's a != b pass be a sparse one?  It pays when the pair is rare enough that
