@@ -46,7 +46,13 @@ const char *bpe_last_error(bpe_ctx *ctx); /* ctx may be NULL: last create error 
 int bpe_set_stream(bpe_ctx *ctx, void *hip_stream);
 /* Knobs: "mode" = 0 recount (get_stats every iteration, the literal reference
  * loop) | 1 delta (pair table kept current by the merge pass).  "profile" =
- * 1 records hipEvents around every hot kernel.  Unknown names -> BPE_E_ARG. */
+ * 1 records hipEvents around every hot kernel.  Unknown names -> BPE_E_ARG.
+ * Variants of the training loop, all producing identical merges (kept for
+ * cross-checks and measurement; the defaults are the fast ones):
+ *   "slots"  0 contiguous stream | 1 4096-id slots | 2 one-wave slots, in place (default)
+ *   "sparse" 0 every pass visits every slot | 1 auto (default) | 2 always through the index
+ *   "sparse_ratio" (2), "tie_index" (1), "rep_min" (4), "rep_max" (8: log2 of delta replicas),
+ *   "lds_delta" (1), "depth" (8: iterations the host runs ahead), "merge", "k1", "lb_tune". */
 int bpe_set_option(bpe_ctx *ctx, const char *name, int64_t value);
 
 /* ---- input ----------------------------------------------------------------- */
