@@ -477,12 +477,39 @@ def main():
             step = lambda: train_sharded(shard, comm, num_merges)
         for _ in range(args.warmup):
             step()
+        try:  # hipEvents around this rank's merge passes during the timed steps (as at N = 1)
+            eng.set_option("profile", 1)
+            eng.prof_reset()
+        except Exception:
+            pass
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             res = step()
         barrier()
         dt = reduce_max(time.perf_counter() - t0)
+        roofline = None
+        try:
+            mg = eng.prof_read()["merge"]
+            eng.set_option("profile", 0)
+            n0 = torch.tensor([len(data)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(n0, op=dist.ReduceOp.SUM)
+            lens = [int(n0.item())] + [int(x) for x in res["lens"]]  # GLOBAL stream lengths
+            alg = sum(4 * (2 * lens[i] + lens[i + 1]) for i in range(len(lens) - 1)) * args.steps / world
+            if mg["ms"] > 0 and mg["launches"]:
+                ach = alg / (mg["ms"] * 1e-3) / 1e9
+                roofline = {
+                    "bound": "hbm", "kernel": "merge pass of rank 0 (k_merge_ab_* + k_merge_aa) on its shard",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "launches": mg["launches"], "avg_launch_ms": round(mg["ms"] / mg["launches"], 5),
+                    "alg_bytes_per_launch": int(alg // mg["launches"]),
+                    "note": "per GPU: the job's algorithmic bytes (4(2N_i + N_{i+1}) on GLOBAL lengths) / world, over "
+                            "the hipEvent time of rank 0's merge passes; no PMC traffic for sharded runs",
+                }
+        except Exception as e:
+            roofline = None
+            line["roofline_error"] = f"{type(e).__name__}: {e}"
         digest = int.from_bytes(hashlib.sha256(repr((res["pairs"], res["counts"], res["lens"])).encode())
                                 .digest()[:7], "big")
         lo = torch.tensor([digest], dtype=torch.int64, device="cuda")
@@ -515,7 +542,7 @@ def main():
                        "parallelism": f"dp{world} (per-merge all-reduce of tie key + table deltas; "
                                       f"collectives via {dist_path})"},
             "value_definition": "merges per second of the ONE sharded job (not summed over ranks)",
-            "sharded_check": dp_check, "roofline": None, "cpu_baseline": None,
+            "sharded_check": dp_check, "roofline": roofline, "cpu_baseline": None,
         })
 
     if rank == 0:
