@@ -17,7 +17,7 @@ tie-break, merge, pair-table update)):
   encode   BASELINE.json configs[4] shape: batch encode of documents (own vocabulary).
 
 The headline workload is timed for --steps; the --secondary workloads (default
-basic1g,cfg2 at N=1) run --secondary-steps each after it and are reported under
+basic1g,cfg2,regex1g_dedup at N=1) run --secondary-steps each after it and are reported under
 "secondary".  N > 1: the chunk list of regex1g is sharded (contiguous chunk ranges,
 --bytes per GPU = cfg4 shape, weak scaling); `value` is the rate of the ONE sharded job.
 
@@ -47,6 +47,10 @@ WORKLOADS = {
                     desc="RegexTokenizer.train (GPT-4 split pattern, no de-duplication)"),
     "basic1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=False, desc="BasicTokenizer.train"),
     "cfg2": dict(bytes=100_000_000, seed=1, vocab=4096, chunked=False, desc="BasicTokenizer.train"),
+    # the headline input trained on its DISTINCT chunks with multiplicities (RegexTokenizer.dedup):
+    # same merges and counts, reported next to the headline, never instead of it
+    "regex1g_dedup": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=True, dedup=True,
+                          desc="RegexTokenizer.train (GPT-4 split pattern) on de-duplicated chunks"),
 }
 
 
@@ -241,6 +245,40 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     return out, data, offs, res
 
 
+def run_dedup_workload(wl, eng, steps, barrier, ref):
+    """Chunk de-duplication on the host (bpe_dedup_chunks), weighted upload, `steps` timed trains.
+    ref = (pairs, counts) of the plain run on the same input, when the headline produced them."""
+    from minbpe_amd import _native
+    data, offs, prep_s = make_input(wl)
+    num_merges = wl["vocab"] - 256
+    t0 = time.perf_counter()
+    d2, o2, w, nd = _native.dedup_chunks(data, offs)
+    dedup_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.load_bytes(d2, o2, w)
+    upload_s = time.perf_counter() - t0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = eng.train(num_merges)
+    barrier()
+    dt = (time.perf_counter() - t0) / steps
+    same = None
+    if ref is not None:
+        same = bool(res["pairs"] == ref[0] and res["counts"] == ref[1])
+    return {
+        "workload": f"{wl['desc']}, {wl['bytes']} B synthetic UTF-8 (seed {wl['seed']}), vocab {wl['vocab']} "
+                    f"({num_merges} merges): {len(offs)} chunks -> {nd} distinct -> {len(o2)} weighted chunks, "
+                    f"{len(d2)} B on the device",
+        "steps": steps, "ms_per_step": round(dt * 1e3, 3), "merges_per_s": round(num_merges / dt, 2),
+        "dedup_host_s": round(dedup_s, 3), "upload_s": round(upload_s, 3), "host_prep_s": round(prep_s, 2),
+        "end_to_end_merges_per_s": round(num_merges / (dt + dedup_s + upload_s), 2),
+        "same_merges_and_counts_as_plain_run": same,
+        "counts_monotone": bool(all(res["counts"][i] >= res["counts"][i + 1] for i in range(len(res["counts"]) - 1))),
+        "merge_passes": eng.train_stats(),
+    }
+
+
 def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters):
     """The oracle (C port of the reference loop, one thread) on the first `cpu_bytes` of the same input
     for `cpu_iters` iterations; the rate is scaled linearly in N to the full size (the reference loop is
@@ -423,6 +461,8 @@ def main():
         return
 
     wl = dict(WORKLOADS[name])
+    if wl.get("dedup"):
+        raise SystemExit(f"{name} is a secondary figure: python bench.py --secondary {name}")
     for k in ("bytes", "vocab", "seed"):
         if getattr(args, k) is not None:
             wl[k] = getattr(args, k)
@@ -444,13 +484,19 @@ def main():
             "roofline": r.pop("roofline"), "cpu_baseline": cpu,
         })
         line.update({k: v for k, v in r.items() if k not in ("workload", "merges_per_s", "ms_per_step", "steps")})
+        plain_ref = (res["pairs"], res["counts"]) if (name == "regex1g" and wl == WORKLOADS["regex1g"]) else None
         del data, offs, res
         sec = args.secondary
         if sec is None:
-            sec = "basic1g,cfg2" if (args.workload is None and args.bytes is None and args.vocab is None) else "none"
+            sec = ("basic1g,cfg2,regex1g_dedup"
+                   if (args.workload is None and args.bytes is None and args.vocab is None) else "none")
         secondary = {}
         for sname in [s for s in sec.split(",") if s and s != "none"]:
             try:
+                if WORKLOADS[sname].get("dedup"):
+                    secondary[sname] = run_dedup_workload(dict(WORKLOADS[sname]), eng, args.secondary_steps,
+                                                          barrier, plain_ref)
+                    continue
                 sr, _d, _o, _r = run_train_workload(sname, dict(WORKLOADS[sname]), eng, args.secondary_steps, 0,
                                                     barrier, reduce_max, args.mode)
                 del _d, _o, _r

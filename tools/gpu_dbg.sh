@@ -3,4 +3,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 exec </dev/null
-BENCH_FORCE_DP=1 BENCH_DP_CHECK=0 timeout -k 5 300 python bench.py --steps 1 --warmup 0 --secondary none --cpu-iters 0 > gpurun_out/bench_dp1b.json 2> gpurun_out/bench_dp1b.err; echo "dp bench rc=$?"; cut -c1-2500 gpurun_out/bench_dp1b.json; grep -v "amdgpu.ids\|socket.cpp" gpurun_out/bench_dp1b.err | tail -5 | cut -c1-300
+timeout -k 5 300 python bench.py --steps 1 --warmup 0 --cpu-iters 0 --secondary regex1g_dedup > gpurun_out/bench_dedup.json 2> gpurun_out/bench_dedup.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/bench_dedup.json"))
+print(d["value"], d["ms_per_step"], d["roofline"]["frac_physical"])
+print(d["secondary"])
+PY
+grep -v "amdgpu.ids" gpurun_out/bench_dedup.err | tail -5 | cut -c1-300
