@@ -1,0 +1,66 @@
+"""CPU: the pure helpers bench.py builds its line from -- the full-length invariants, the comparison
+with committed oracle digests, the library source hash that gates the PMC traffic file."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from helpers import checkpoint_digests  # noqa: E402
+
+
+def _res(pairs, counts, lens):
+    return {"pairs": pairs, "counts": counts, "lens": lens}
+
+
+def test_invariants_accept_a_consistent_run_and_reject_broken_ones():
+    good = _res([(1, 2), (3, 3), (4, 5)], [10, 8, 8], [90, 85, 77])  # a == b removes <= count
+    assert bench.invariants(good, 100)["len_drop_equals_count_and_counts_monotone"]
+    assert not bench.invariants(_res([(1, 2)], [10], [91]), 100)["len_drop_equals_count_and_counts_monotone"]
+    assert not bench.invariants(_res([(1, 2), (3, 4)], [5, 6], [95, 89]), 100)["len_drop_equals_count_and_counts_monotone"]
+    assert not bench.invariants(_res([(3, 3)], [4], [95]), 100)["len_drop_equals_count_and_counts_monotone"]
+
+
+def test_parity_report_against_committed_digests(monkeypatch):
+    pairs = [(i, i + 1) for i in range(40)]
+    counts = [100 - i for i in range(40)]
+    lens = [1000 - 10 * i for i in range(40)]
+    digs = checkpoint_digests(pairs, counts, lens, 8)
+    entry = {"bytes": 123, "seed": 9, "data_sha256": "ab", "done": 40, "step": 8,
+             "digests": [list(d) for d in digs]}
+    monkeypatch.setattr(bench, "golden_entry", lambda name: entry)
+    wl = {"bytes": 123, "seed": 9}
+    rep = bench.parity_report("x", wl, "ab", None, _res(pairs, counts, lens))
+    assert rep["equal"] is True and rep["merges_checked"] == 40
+    bad_counts = list(counts)
+    bad_counts[20] += 1
+    rep = bench.parity_report("x", wl, "ab", None, _res(pairs, bad_counts, lens))
+    assert rep["equal"] is False and rep["first_bad_checkpoint"] == 24
+    # another input (sha differs): nothing is claimed
+    rep = bench.parity_report("x", wl, "cd", None, _res(pairs, counts, lens))
+    assert rep["golden"] is None and rep["equal"] is None
+
+
+def test_pmc_profile_is_tied_to_library_sources():
+    """bench.py attaches profiles/r2_<workload>_pmc.json only when its recorded hash equals the hash of
+    the sources being run; the file must carry what that needs."""
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    with open(os.path.join(ROOT, "profiles", "r2_regex1g_pmc.json")) as f:
+        pmc = json.load(f)
+    assert pmc["workload"] == "regex1g" and pmc["launches"] > 0 and pmc["hbm_bytes_total"] > 0
+    assert len(pmc["source_hash"]) == 16
+    cal = pmc["calibration_k_widen"]  # reads n bytes, writes 4n: the x2 fetch correction holds
+    n = cal["n_input_bytes"] * cal["calls"]
+    assert abs(cal["fetch_bytes_x2"] / n - 1.0) < 0.02 and abs(cal["write_bytes"] / (4 * n) - 1.0) < 0.03
+
+
+def test_workloads_name_the_baseline_configs():
+    w = bench.WORKLOADS
+    assert w["regex1g"]["bytes"] == 1_000_000_000 and w["regex1g"]["vocab"] == 32000 and w["regex1g"]["chunked"]
+    assert w["basic1g"]["bytes"] == 1_000_000_000 and not w["basic1g"]["chunked"]
+    assert w["cfg2"]["bytes"] == 100_000_000 and w["cfg2"]["vocab"] == 4096
+    assert w["regex1g_dedup"]["dedup"] and w["regex1g_dedup"]["seed"] == w["regex1g"]["seed"]
