@@ -9,7 +9,7 @@ timeout -k 5 900 python -X faulthandler -m pytest tests -m gpu -q --maxfail=12 >
 RC=$?; echo "pytest rc=$RC"; tail -6 gpurun_out/pytest_gpu.log | cut -c1-300
 if [ $RC -ne 0 ]; then echo "tests failed: stopping here"; exit 1; fi
 bash tools/gpu_pmc.sh regex1g
-exit 0
+
 rm -rf gpurun_out/prof_enc
 timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_enc -o run -- python bench.py --workload encode --steps 2 --warmup 1 --cpu-iters 0 > gpurun_out/prof_enc.log 2>&1; echo "enc rc=$?"
 DB=$(find gpurun_out/prof_enc -name "*.db" | head -1)
