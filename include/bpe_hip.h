@@ -201,6 +201,10 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
  * is visited), out[1] = sparse passes (only the slots the inverted slot index cannot rule out),
  * out[2] = builds of that index, out[3] = slots of the stream at the end. */
 int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
+/* The same, extended: out[4] = lean iterations among the passes above (three launches per merge, the
+ * pair table updated at the merge sites themselves; option "lean"), out[5] = iterations a lean pass
+ * handed back to the general path (pairs with a == b).  Writes min(n, 6) values. */
+int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */
 /* regex.findall(pattern, text) for the two GPT split patterns (regex.py:18-19, 41, 114),

@@ -93,6 +93,7 @@ _SIGS = {
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
     "bpe_train_stats": (C.c_int, [_p, _p]),
+    "bpe_train_stats_ex": (C.c_int, [_p, _p, C.c_int]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_dedup_chunks": (C.c_int, [_p, _u64, _p, _u64, _p, _p, _p, C.POINTER(_u64), C.POINTER(_u64),
                                   C.POINTER(_u64), C.c_int]),
@@ -449,10 +450,11 @@ class Engine:
         self._check(_lib.bpe_prof_reset(self._h))
 
     def train_stats(self):
-        """dict(dense, sparse, index_builds, slots) of the last train() (bpe_train_stats)."""
-        out = np.zeros(4, np.uint64)
-        self._check(_lib.bpe_train_stats(self._h, _ptr(out)))
-        return dict(dense=int(out[0]), sparse=int(out[1]), index_builds=int(out[2]), slots=int(out[3]))
+        """dict(dense, sparse, index_builds, slots, lean, deferred) of the last train() (bpe_train_stats_ex)."""
+        out = np.zeros(6, np.uint64)
+        self._check(_lib.bpe_train_stats_ex(self._h, _ptr(out), 6))
+        return dict(dense=int(out[0]), sparse=int(out[1]), index_builds=int(out[2]), slots=int(out[3]),
+                    lean=int(out[4]), deferred=int(out[5]))
 
     def prof_read(self):
         k = len(PROF_KINDS)

@@ -121,6 +121,18 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "sparse_ratio")) {
         if (value < 1 || value > 64) return fail(c, BPE_E_ARG, "sparse_ratio must be 1..64");
         c->sparse_ratio = (int)value;
+    } else if (!strcmp(name, "lean")) {
+        if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "lean must be 0 (never), 1 (auto) or 2 (always)");
+        c->lean = (int)value;
+    } else if (!strcmp(name, "lean_count")) {
+        if (value < 0) return fail(c, BPE_E_ARG, "lean_count must be >= 0");
+        c->lean_count = value;
+    } else if (!strcmp(name, "lean_grid")) {
+        if (value < 1 || value > 65535) return fail(c, BPE_E_ARG, "lean_grid must be 1..65535");
+        c->lean_grid = (int)value;
+    } else if (!strcmp(name, "lean_scan")) {
+        if (value < 1 || value > 1024) return fail(c, BPE_E_ARG, "lean_scan must be 1..1024");
+        c->lean_scan = (int)value;
     } else if (!strcmp(name, "depth")) {
         if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
         c->depth = (int)value;

@@ -80,6 +80,11 @@ struct bpe_ctx {
     int sparse_ratio = 2;                     // sparse pass when (count of the pair) * ratio < slots
     uint64_t last_count = ~0ull;              // count of the last merge the host has seen: an upper bound of the next ones
     uint64_t n_sparse = 0, n_dense = 0, n_index_builds = 0;  // passes of the last train() (bpe_train_stats)
+    uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
+    int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
+    int64_t lean_count = 24576;               // option "lean_count"
+    int lean_grid = 512;                      // option "lean_grid": most workgroups of a lean merge pass
+    int lean_scan = 16;                       // option "lean_scan": workgroups that re-scan rows in k_finish_lean
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
@@ -421,7 +426,7 @@ SlotRefH stream_ref_h(const bpe_ctx *c) {
 
 // K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
 // this rank's candidate)
-int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
+int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false, bool lean_next = false) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     if (rowmax_all) {
         hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
@@ -439,6 +444,7 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     C.enable = sparse_next ? 1u : 0u;  // the block that makes the pair final lists the slots a sparse pass visits
     C.tie_index = (c->slotted && c->slot2 && c->idx_live && c->tie_index) ? 1u : 0u;
     C.tie_window = c->tie_window ? 1u : 0u;
+    C.dirty_n = lean_next ? c->d_dirty_n : nullptr;
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
@@ -744,6 +750,10 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     A.cand = c->d_cand;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
+    A.mat = nullptr;  // (lean passes only)
+    A.mstride = 0;
+    A.rowmax = nullptr;
+    A.dirty_list = nullptr;
     // every id the pass can meet is below newid: small enough for the LDS delta tables?
     const bool ldsd = c->lds_delta && newid + 1 <= (uint32_t)LDSD_CAP;
     if (sparse) {
@@ -823,6 +833,57 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     const uint32_t dl = delta_layout(c, newid);
     TRY(launch_passes2(c, newid, sparse, dl));
     return launch_table2(c, newid, iter, rec, sparse, dl, false);
+}
+
+// A lean iteration (k_lean.hip) after k_select: the merge pass with the table update at its sites,
+// then row maxima + staged headers + stream length + record.  use_index: candidates come from the
+// inverted index (it is live); otherwise every live slot is visited.
+int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_index) {
+    const uint32_t T = (uint32_t)c->slot_T;
+    AbArgs A;
+    A.b0 = c->d_ids[0];
+    A.b1 = c->d_ids[1];
+    A.hdr_in = c->d_hdr2[c->mq];
+    A.hdr_out = nullptr;
+    A.stage = c->d_stage;
+    A.smask = c->d_smask;
+    A.T = T;
+    A.st = c->d_st;
+    A.newid = newid;
+    A.delta = nullptr;
+    A.vcap = c->vcap;
+    A.idx = c->idx_live ? c->d_idx : nullptr;
+    A.istride = (uint32_t)c->idx_cap_words;
+    A.cand = nullptr;
+    A.removed = c->d_removed;
+    A.dirty_n = c->d_dirty_n;
+    A.mat = c->d_mat;
+    A.mstride = c->vcap;
+    A.rowmax = c->d_rowmax;
+    A.dirty_list = c->d_dirty_list;
+    const uint32_t nwords = (T + 31) / 32;
+    const unsigned g = std::max(1u, std::min((nwords + 31) / 32, (unsigned)c->lean_grid));
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    if (c->idx_live)
+        hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(MT), 0, c->stream, A, c->d_idx_dirty,
+                           use_index ? 1u : 0u);
+    else
+        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u);
+    LAUNCHCHK(c, "k_merge_ab_lean");
+    TRY(prof_end(c));
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    const unsigned nscan = (unsigned)c->lean_scan;
+    hipLaunchKernelGGL(k_finish_lean, dim3(nscan + 8), dim3(1024), 0, c->stream, c->d_mat, c->vcap, c->d_rowmax,
+                       c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, c->d_hdr2[c->mq], c->d_stage,
+                       c->d_removed, c->d_smask, nwords, nscan);
+    LAUNCHCHK(c, "k_finish_lean");
+    TRY(prof_end(c));
+    c->par ^= 1;  // (a sparse-style pass: staged headers, the header arrays do not flip)
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    c->n_lean++;
+    if (use_index) c->n_sparse++; else c->n_dense++;
+    return BPE_OK;
 }
 
 int read_state(bpe_ctx *c, DevState *out) {

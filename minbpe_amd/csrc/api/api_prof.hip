@@ -34,4 +34,11 @@ int bpe_train_stats(bpe_ctx *c, uint64_t *out4) {
     return BPE_OK;
 }
 
+int bpe_train_stats_ex(bpe_ctx *c, uint64_t *out, int n) {
+    if (!c || !out || n < 0) return BPE_E_ARG;
+    const uint64_t v[6] = {c->n_dense, c->n_sparse, c->n_index_builds, c->slot_T, c->n_lean, c->n_deferred};
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    return BPE_OK;
+}
+
 }  // extern "C"

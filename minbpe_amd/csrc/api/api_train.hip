@@ -24,6 +24,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     // statistics of the initial byte stream (iteration 0 of both modes)
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
+    // (a pass that a device status cut short in an earlier call may have left partial sums behind)
+    HIPCHK(c, hipMemsetAsync(c->d_delta, 0, ((size_t)c->vcap * 4 * DELTA_REPL + 256 * DELTA_SKEW) * sizeof(uint32_t), c->stream));
     TRY(prof_end(c));
     if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[0], c->stream));
     const uint64_t n0 = c->n;
@@ -39,6 +41,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     c->idx_rebuild = false;
     c->last_count = ~0ull;
     c->n_sparse = c->n_dense = c->n_index_builds = 0;
+    c->n_lean = c->n_deferred = 0;
+    // lean iterations (k_lean.hip): which ones were enqueued that way (1: candidates from the index, 2: every
+    // slot), the iteration that reported ST_DEFER, and the one iteration that must take the general path
+    std::vector<uint8_t> lean_kind(form2 ? (size_t)num_merges : 0, 0);
+    int deferred = -1, force_general = -1;
+    bool lean_on = false;  // latched: the general path's kernels do not know a deferred iteration
     // second form: which iterations flipped the header arrays (a sparse pass does not), so that an
     // early stop can undo the flips of the no-op iterations enqueued behind the failing one
     std::vector<uint8_t> hdr_flip(form2 ? (size_t)num_merges : 0, 0);
@@ -54,6 +62,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
         }
         __sync_synchronize();
+        if (r->status == ST_DEFER) {  // a == b: the lean path hands the merge back (handled by the loop below)
+            deferred = j;
+            return BPE_OK;
+        }
         if (r->status == ST_EMPTY) {
             stop = true;
             rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
@@ -120,21 +132,49 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             }
             bool sparse = false;
             if (c->slotted && c->slot2) TRY(plan_pass2(c, &sparse));
+            const bool lean = c->slotted && c->slot2 && c->lean && i != force_general &&
+                              (lean_on || c->lean == 2 || (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count));
+            if (lean) {
+                lean_on = true;
+                TRY(launch_select(c, full_rowmax, false, true));
+                TRY(launch_lean(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
+                hdr_flip[(size_t)i] = 0;
+                lean_kind[(size_t)i] = sparse ? 1 : 2;
+            } else {
             TRY(launch_select(c, full_rowmax, sparse));
             if (c->slotted && c->slot2) {
                 const int mq0 = c->mq;
                 TRY(launch_merge2(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = (uint8_t)(c->mq != mq0);
+                lean_kind[(size_t)i] = 0;
             } else if (c->slotted)
                 TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));
             else
                 TRY(launch_merge(c, 256u + (uint32_t)i, i, c->h_rec, delta));
+            }
             if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[(size_t)i + 1], c->stream));
             i++;
         }
         if (consumed < i && (i - consumed > c->depth || i == num_merges)) {
             TRY(consume(consumed));
-            if (!stop) consumed++;
+            if (deferred >= 0) {
+                // Iterations [deferred, i) did nothing on the device (all of them lean ones, all no-ops
+                // behind the deferred one): undo what enqueueing them changed on the host, then run
+                // iteration `deferred` through the general path and go on from there.
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                for (int j = deferred; j < i; j++) {
+                    c->par ^= 1;
+                    c->n_lean--;
+                    if (lean_kind[(size_t)j] == 1) c->n_sparse--; else c->n_dense--;
+                    c->h_rec[j].seq = 0;
+                }
+                hipLaunchKernelGGL(k_clear_defer, dim3(1), dim3(1), 0, c->stream, c->d_st);
+                LAUNCHCHK(c, "k_clear_defer");
+                c->n_deferred++;
+                force_general = deferred;
+                i = deferred;
+                deferred = -1;
+            } else if (!stop) consumed++;
         }
         if (consumed >= num_merges) break;
     }

@@ -59,6 +59,7 @@ constexpr int ENC_LMAX = 32;  // longer chunks take the stream-wide path
 constexpr int SCAN_TILE = 4096;
 
 constexpr uint32_t ST_OK = 0, ST_EMPTY = 1, ST_INTERNAL = 2, ST_LOOKBACK = 3;
+constexpr uint32_t ST_DEFER = 4;  // IterRec only: a lean iteration handed the merge back to the general path
 constexpr uint32_t EPOCH_MASK = 0xFFFFFu;  // look-back descriptors carry a 20-bit launch tag
 constexpr uint32_t LOOKBACK_SPINS = 1u << 20;  // bounded wait for a predecessor tile
 
@@ -120,7 +121,9 @@ struct DevState {
     uint32_t gap;                 // some slot other than the last holds < 3 ids: sparse passes visit every slot
     uint32_t tlive;               // slots [tlive, T) were empty when the stream was last re-packed, and stay so: the host
                                   // sizes T from a length that is `depth` merges old, and nobody should walk that tail
-    uint32_t pad_[2];
+    uint32_t defer;               // lean iterations (k_lean.hip): the decided pair needs the general path (a == b): this
+                                  // iteration and everything enqueued behind it do nothing until the host has re-run it there
+    uint32_t pad_[1];
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -1,0 +1,210 @@
+// k_lean.hip -- the training iteration once a merged pair has few sites ("lean" iterations: the
+// last ~29,000 of the 31,744 merges of a 1 GB / vocab-32000 run, where a pass rewrites a few
+// hundred slots and nothing is bound by bytes any more, only by the number of dependent memory
+// round trips and launches).  Three launches instead of five, no delta vectors, no sweep over the
+// vocabulary:
+//   k_select            (k_select.hip)  the pair
+//   k_merge_ab_lean     every wave finds its own candidate slots in the inverted index (the three
+//                       filter rows of the pair, 1024 slots per step -- no candidate list, no
+//                       single block building one) and rewrites them; each site updates the pair
+//                       table itself (merge_ab_wave<DIRECT>, k_slots2.hip) and queues row L when
+//                       its maximum may have dropped
+//   k_finish_lean       re-scans rows a, b, Z and the queued rows (one workgroup per row, the whole
+//                       row in flight at once), commits the staged headers, new stream length, record
+// A pair with a == b is not merged here: the pass is DEFERRED -- the iteration reports ST_DEFER,
+// everything enqueued behind it is a no-op, and the host re-runs the iteration through the general
+// path (k_merge_aa).  75 of 31,744 merges.
+// Part of bpe_kernels.hip, which includes the parts in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../bpe_device.h"
+#include "k_index.hip"
+#include "k_slots2.hip"
+#include "k_table.hip"
+
+namespace bpe {
+
+// use_index == 0: no index (small streams) -- every live slot is visited
+template <bool INDEXED>
+__global__ void __launch_bounds__(MT, 4)
+k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
+    DevState *st = A.st;
+    if (st->status || st->defer) return;
+    if (!st->found) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
+        return;
+    }
+    const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+    if (a == b) {  // the general path's pass (k_merge_aa): the host re-runs this iteration there
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->defer = 1;
+        return;
+    }
+    const int lane = lane_id();
+    const uint32_t Tl = min(A.T, st->tlive);
+    // short slots about: adjacency in slot numbers means nothing, visit everything (k_index.hip)
+    const bool all = !use_index || st->gap != 0;
+    const uint32_t nwords = (Tl + 31) / 32;
+    const uint32_t nchunks = (nwords + 31) / 32;
+    uint32_t h1, h2, h3;
+    pair_hash(a, b, h1, h2, h3);
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        // the candidate mask of 1024 slots: one 32-slot word per lane (lanes 0..31), every wave
+        // of the workgroup computes the same one and takes every fourth candidate
+        const uint32_t w = c * 32 + (uint32_t)lane;
+        uint32_t mk = 0;
+        if (lane < 32 && w < nwords) {
+            if (all) {
+                mk = 0xFFFFFFFFu;
+            } else {
+                mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
+                      A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
+            }
+            const uint32_t left = Tl - w * 32;
+            if (left < 32) mk &= (1u << left) - 1u;
+        }
+        unsigned long long bal = __ballot(mk != 0);
+        uint32_t k = 0;
+        while (bal) {
+            const int lw = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mk, lw);
+            while (mm) {
+                const uint32_t t = (c * 32 + (uint32_t)lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1u;
+                if ((k++ & (MT / 64 - 1)) == (uint32_t)wave_id())
+                    merge_ab_wave<true, INDEXED, false, true>(s_out[wave_id()], nullptr, t, A, a, b);
+            }
+        }
+    }
+}
+
+// One row of the table by a 1024-thread workgroup, every load of the row in flight at once
+// (vocab 32000: 8 x 16 bytes per thread); otherwise row_scan (k_table.hip).
+__device__ __forceinline__ void row_scan_wide(uint32_t *__restrict__ row, uint32_t ncols, int zero_col,
+                                              unsigned long long *s_red, uint32_t &m_out, uint32_t &arg_out) {
+    unsigned long long kf = 0, kl = 0;  // count << 32 | ~column  and  count << 32 | column
+    const uint32_t n4 = (ncols + 3) & ~3u;
+    constexpr int U = 8;
+    for (uint32_t base = 0; base < n4; base += U * 4096) {
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
+            q[u] = (y < n4) ? *reinterpret_cast<const uint4 *>(row + y) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
+            uint32_t v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+            if (zero_col >= 0 && (uint32_t)zero_col - y < 4u && y < n4) {
+                v[(uint32_t)zero_col - y] = 0;
+                row[zero_col] = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (v[k]) {
+                    const unsigned long long hi = (unsigned long long)v[k] << 32;
+                    const unsigned long long f = hi | (0xFFFFFFFFu - (y + k)), l = hi | (y + k);
+                    kf = f > kf ? f : kf;
+                    kl = l > kl ? l : kl;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long of = __shfl_xor(kf, d), ol = __shfl_xor(kl, d);
+        kf = of > kf ? of : kf;
+        kl = ol > kl ? ol : kl;
+    }
+    __syncthreads();  // s_red may still be read by the previous row's thread 0
+    if (lane_id() == 0) {
+        s_red[2 * wave_id()] = kf;
+        s_red[2 * wave_id() + 1] = kl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) {
+            kf = s_red[2 * w] > kf ? s_red[2 * w] : kf;
+            kl = s_red[2 * w + 1] > kl ? s_red[2 * w + 1] : kl;
+        }
+        m_out = (uint32_t)(kf >> 32);
+        const uint32_t cf = 0xFFFFFFFFu - (uint32_t)kf, cl = (uint32_t)kl;
+        arg_out = (m_out == 0) ? 0u : (cf == cl ? cf : ROWARG_MULTI);
+    }
+}
+
+// Workgroups [0, nscan): row maxima.  Workgroup nscan: stream length + the iteration's record.
+// Workgroups [nscan, grid): commit the headers the pass staged.
+__global__ void __launch_bounds__(1024)
+k_finish_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, DevState *st,
+              uint32_t Z, const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n, int par,
+              IterRec *rec, int iter, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
+              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint32_t nscan) {
+    __shared__ unsigned long long s_red[32];
+    if (blockIdx.x < nscan) {
+        if (st->status || st->defer) return;
+        const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
+        const uint32_t nd = *dirty_n;
+        for (uint32_t i = blockIdx.x; i < 3 + nd; i += nscan) {
+            const uint32_t x = i == 0 ? a : (i == 1 ? b : (i == 2 ? Z : dirty_list[i - 3]));
+            uint32_t m = 0, arg = 0;
+            // (a,b) is retired on the way: no (a,b) survives the merge (F2)
+            row_scan_wide(mat + (size_t)x * stride, Z + 1, x == a ? (int)b : -1, s_red, m, arg);
+            if (threadIdx.x == 0) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+        }
+        return;
+    }
+    if (blockIdx.x == nscan && threadIdx.x < 64) {
+        // ids removed by the merge pass: 256 counters, one per 256-byte line (see DELTA_SKEW)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
+            v += x;
+        }
+        v = wave_sum_u32(v);
+        if (threadIdx.x == 0) {
+            const uint32_t status = st->status, defer = st->defer;
+            const unsigned long long n = st->n[par];
+            unsigned long long nn = n;
+            if (status == 0 && !defer) {
+                nn = n - v;
+                st->n[par ^ 1] = nn;
+            }
+            st->removed = 0;
+            rec[iter].a = st->a;
+            rec[iter].b = st->b;
+            rec[iter].count = st->count;
+            rec[iter].status = status ? status : (defer ? ST_DEFER : ST_OK);
+            rec[iter].new_len = nn;
+            __threadfence_system();
+            rec[iter].seq = (unsigned long long)iter + 1;
+        }
+    }
+    if (st->status || st->defer) return;
+    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
+    const uint32_t step = (gridDim.x - nscan) * blockDim.x;
+    for (uint32_t w = (blockIdx.x - nscan) * blockDim.x + threadIdx.x; w < nwords; w += step) {
+        uint32_t m = smask[w];
+        if (!m) continue;
+        smask[w] = 0;
+        while (m) {
+            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const StageRec r = stage[t];
+            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
+            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
+            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+        }
+    }
+}
+
+// host: a deferred iteration is about to be re-run through the general path
+__global__ void k_clear_defer(DevState *st) { st->defer = 0; }
+
+}  // namespace bpe

@@ -84,6 +84,7 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->adj = 0;
     st->ncand = 0;
     st->gap = 0;
+    st->defer = 0;
 }
 
 }  // namespace bpe

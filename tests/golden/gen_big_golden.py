@@ -6,7 +6,10 @@ consumed by tests/test_gpu_big.py and bench.py.
 
     python tests/golden/gen_big_golden.py cfg2      # Basic, 100 MB, 3840 merges
     python tests/golden/gen_big_golden.py cfg3s     # GPT-4 split, 150 MB, 8192 merges
-    python tests/golden/gen_big_golden.py basic1g   # Basic, 1 GB, first 64 merges (bench spot check)
+    python tests/golden/gen_big_golden.py basic1g   # Basic, 1 GB, first 1024 merges
+    python tests/golden/gen_big_golden.py regex1g   # GPT-4 split, 1 GB, first 1024 merges (the headline input)
+    python tests/golden/gen_big_golden.py full16r   # GPT-4 split, 16 MB, ALL 31,744 merges of vocab 32000
+    python tests/golden/gen_big_golden.py full12b   # Basic, 12 MB, ALL 31,744 merges
 
 The GPT-4 split of `cfg3s` is done here with the `regex` module exactly as the
 reference does (regex.py:19,41), NOT with the native splitter: the digest of the
@@ -37,9 +40,14 @@ CASES = {
     # name: (bytes, seed, merges, chunked)
     "cfg2": (100_000_000, 1, 3840, False),
     "cfg3s": (150_000_000, 2, 8192, True),
-    "basic1g": (1_000_000_000, 2, 64, False),
-    "regex1g": (1_000_000_000, 2, 48, True),
+    "basic1g": (1_000_000_000, 2, 1024, False),
+    "regex1g": (1_000_000_000, 2, 1024, True),
+    # the WHOLE vocab range of the headline (31,744 merges) on inputs the oracle finishes in
+    # under an hour: mass low-count ties, V > 8448, every select/apply path above merge 8192
+    "full16r": (16_000_000, 11, 31744, True),
+    "full12b": (12_000_000, 12, 31744, False),
 }
+STEP = {"basic1g": 16, "regex1g": 16}
 
 
 def regex_offsets(data: bytes) -> np.ndarray:
@@ -77,15 +85,19 @@ def main():
     entry["first"] = [list(p) for p in pairs[:4]]
     entry["last"] = [list(p) for p in pairs[-2:]]
     entry["final_len"] = lens[-1]
-    entry["step"] = 256 if merges >= 256 else 16
+    entry["step"] = STEP.get(name, 256 if merges >= 256 else 16)
     entry["digests"] = checkpoint_digests(pairs, counts, lens, entry["step"])
-    allg = {}
-    if os.path.exists(OUT):
-        with open(OUT) as f:
-            allg = json.load(f)
-    allg[name] = entry
-    with open(OUT, "w") as f:
-        json.dump(allg, f, indent=1)
+    import fcntl
+    with open(OUT + ".lock", "w") as lk:          # several cases may be generated side by side
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        allg = {}
+        if os.path.exists(OUT):
+            with open(OUT) as f:
+                allg = json.load(f)
+        allg[name] = entry
+        with open(OUT + ".tmp", "w") as f:
+            json.dump(allg, f, indent=1)
+        os.replace(OUT + ".tmp", OUT)
     print(f"{name}: {len(pairs)} merges, oracle {entry['oracle_seconds']}s, final digest "
           f"{entry['digests'][-1][1]}", flush=True)
 

@@ -114,31 +114,34 @@ def test_train_golden_cases(golden, engine, native):
         assert [list(p) for p in res["pairs"]] == case["merges"], case["name"]
 
 
-# engine variants: (mode, merge impl, slots, sparse) -- slots 2 = the second slotted form (default);
-# sparse 2 = every a != b pass goes through the inverted index and the sparse kernel
-VARIANTS = [(0, 0, 0, 1), (1, 0, 1, 1), (1, 0, 0, 1), (1, 1, 0, 1), (0, 1, 0, 1), (1, 0, 2, 1), (1, 0, 2, 2),
-            (1, 0, 2, 0)]
+# engine variants: (mode, merge impl, slots, sparse, lean) -- slots 2 = the second slotted form (default);
+# sparse 2 = every a != b pass goes through the inverted index and the sparse kernel; lean 1 (default) =
+# lean iterations (k_lean.hip: three launches, table updated at the merge sites, a == b deferred to the
+# general path) once the host has seen a count <= lean_count, 2 = from the first merge on, 0 = never
+VARIANTS = [(0, 0, 0, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 1), (1, 1, 0, 1, 1), (0, 1, 0, 1, 1), (1, 0, 2, 1, 1),
+            (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2)]
 
 
-def set_variant(engine, mode, mimpl, slots, sparse):
+def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
     engine.set_option("slots", slots)
     engine.set_option("sparse", sparse)
+    engine.set_option("lean", lean)
 
 
 def reset_variant(engine):
-    set_variant(engine, 1, 0, 2, 1)
+    set_variant(engine, 1, 0, 2, 1, 1)
     engine.set_option("depth", 8)
 
 
-@pytest.mark.parametrize("mode,mimpl,slots,sparse", VARIANTS)
+@pytest.mark.parametrize("mode,mimpl,slots,sparse,lean", VARIANTS)
 @pytest.mark.parametrize("k,n,nm", [(2, 3000, 40), (4, 50000, 120), (16, 200000, 150), (3, 9000, 300),
                                     (1, 70000, 20), (2, 4096 * 3 + 1, 64)])
-def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, sparse, k, n, nm):
+def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, sparse, lean, k, n, nm):
     rng = random.Random(k * 1000 + n)
     data = bytes(97 + rng.randrange(k) for _ in range(n))
-    set_variant(engine, mode, mimpl, slots, sparse)
+    set_variant(engine, mode, mimpl, slots, sparse, lean)
     try:
         engine.load_bytes(data)
         exp = oracle.train(data, nm, raise_on_empty=False)
@@ -160,9 +163,9 @@ def test_train_tie_heavy_vs_oracle(engine, mode, mimpl, slots, sparse, k, n, nm)
         reset_variant(engine)
 
 
-@pytest.mark.parametrize("mode,mimpl,slots,sparse", [v for v in VARIANTS if v != (0, 1, 0, 1)])
+@pytest.mark.parametrize("mode,mimpl,slots,sparse,lean", [v for v in VARIANTS if v != (0, 1, 0, 1, 1)])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, sparse):
+def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, sparse, lean):
     text = native.synth_text(2_000_000, 11)
     if kind == "basic":
         data, offs = text, None
@@ -170,12 +173,21 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
         data, offs = split_chunks(text.decode())
     nm = 400
     exp = oracle.train(data, nm, offs)
-    set_variant(engine, mode, mimpl, slots, sparse)
+    set_variant(engine, mode, mimpl, slots, sparse, lean)
     try:
         engine.load_bytes(data, offs)
         res = engine.train(nm)
+        stats = engine.train_stats()
         if sparse == 2:
-            assert engine.train_stats()["sparse"] == nm
+            assert stats["sparse"] == nm
+        if slots == 2 and mode == 1:
+            n_same = sum(a == b for a, b in exp[0])
+            if lean == 0:
+                assert stats["lean"] == 0 and stats["deferred"] == 0
+            elif lean == 2:  # every a != b merge is a lean iteration, every a == b one was handed back
+                assert stats["lean"] == nm - n_same and stats["deferred"] == n_same
+            else:
+                assert stats["lean"] > 0
         assert res["pairs"] == exp[0]
         assert res["counts"] == exp[1]
         assert res["lens"] == exp[2]
