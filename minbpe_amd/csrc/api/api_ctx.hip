@@ -84,7 +84,7 @@ struct bpe_ctx {
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 24576;               // option "lean_count"
     int lean_grid = 512;                      // option "lean_grid": most workgroups of a lean merge pass
-    int lean_scan = 16;                       // option "lean_scan": workgroups that re-scan rows in k_finish_lean
+    int lean_scan = 16;                       // option "lean_scan": workgroups of k_rowmax_lean
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
@@ -244,7 +244,7 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     uint32_t nv = std::max<uint32_t>(v, 256);
     nv = (nv + 63) & ~63u;  // rows stay 256 B aligned
     TRY(dev_realloc(c, c->d_mat, (size_t)nv * nv));
-    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv * 2));  // rowmax[nv] | rowarg[nv]
+    TRY(dev_realloc(c, c->d_rowmax, (size_t)nv * 2));  // interleaved: rowmax[2x] = max of row x, rowmax[2x + 1] = its column (or ROWARG_MULTI)
     TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL + 256 * DELTA_SKEW));  // (+ the skew of up to 256 replicas)
     TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
     if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
@@ -254,6 +254,9 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     }
     HIPCHK(c, hipMemsetAsync(c->d_delta, 0, ((size_t)nv * 4 * DELTA_REPL + 256 * DELTA_SKEW) * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_dirty_n, 0, sizeof(uint32_t), c->stream));
+    // rows beyond the ids in use read as "no pair" (a deferred lean iteration's no-op successors run
+    // k_select with a vocabulary the table has not reached yet)
+    HIPCHK(c, hipMemsetAsync(c->d_rowmax, 0, (size_t)nv * 2 * sizeof(uint32_t), c->stream));
     if (c->d_first) {
         HIPCHK(c, hipFree(c->d_first));
         c->d_first = nullptr;
@@ -426,7 +429,7 @@ SlotRefH stream_ref_h(const bpe_ctx *c) {
 
 // K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
 // this rank's candidate)
-int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false, bool lean_next = false) {
+int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     if (rowmax_all) {
         hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
@@ -444,7 +447,6 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false, bool le
     C.enable = sparse_next ? 1u : 0u;  // the block that makes the pair final lists the slots a sparse pass visits
     C.tie_index = (c->slotted && c->slot2 && c->idx_live && c->tie_index) ? 1u : 0u;
     C.tie_window = c->tie_window ? 1u : 0u;
-    C.dirty_n = lean_next ? c->d_dirty_n : nullptr;
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
@@ -750,10 +752,6 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     A.cand = c->d_cand;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
-    A.mat = nullptr;  // (lean passes only)
-    A.mstride = 0;
-    A.rowmax = nullptr;
-    A.dirty_list = nullptr;
     // every id the pass can meet is below newid: small enough for the LDS delta tables?
     const bool ldsd = c->lds_delta && newid + 1 <= (uint32_t)LDSD_CAP;
     if (sparse) {
@@ -805,7 +803,8 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
 
 // table update of the second slotted form (+ commit of staged headers, stream length, record);
 // folded: the delta comes from the all-reduced payload of sharded training
-int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse, uint32_t dl, bool folded) {
+int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse, uint32_t dl, bool folded,
+                  bool lean = false) {
     const uint32_t T = (uint32_t)c->slot_T;
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (newid + 1 + 31) / 32;
@@ -818,8 +817,12 @@ int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
                            c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, na,
                            c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
     LAUNCHCHK(c, "k_apply2");
-    hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
-                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    if (lean)
+        hipLaunchKernelGGL(k_rowmax_lean, dim3((unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_mat, c->vcap,
+                           c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n);
+    else
+        hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
+                           c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
     LAUNCHCHK(c, "k_rowmax_list");
     TRY(prof_end(c));
     c->par ^= 1;
@@ -835,11 +838,12 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     return launch_table2(c, newid, iter, rec, sparse, dl, false);
 }
 
-// A lean iteration (k_lean.hip) after k_select: the merge pass with the table update at its sites,
-// then row maxima + staged headers + stream length + record.  use_index: candidates come from the
-// inverted index (it is live); otherwise every live slot is visited.
+// A lean iteration (k_lean.hip) after k_select: the merge pass (waves find their own candidates),
+// then the table update with the wide row scans.  use_index: candidates come from the inverted
+// index (it is live); otherwise every live slot is visited.
 int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_index) {
     const uint32_t T = (uint32_t)c->slot_T;
+    const uint32_t dl = delta_layout(c, newid);
     AbArgs A;
     A.b0 = c->d_ids[0];
     A.b1 = c->d_ids[1];
@@ -850,17 +854,13 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     A.T = T;
     A.st = c->d_st;
     A.newid = newid;
-    A.delta = nullptr;
-    A.vcap = c->vcap;
+    A.delta = c->d_delta;
+    A.vcap = dl;
     A.idx = c->idx_live ? c->d_idx : nullptr;
     A.istride = (uint32_t)c->idx_cap_words;
     A.cand = nullptr;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
-    A.mat = c->d_mat;
-    A.mstride = c->vcap;
-    A.rowmax = c->d_rowmax;
-    A.dirty_list = c->d_dirty_list;
     const uint32_t nwords = (T + 31) / 32;
     const unsigned g = std::max(1u, std::min((nwords + 31) / 32, (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
@@ -871,16 +871,7 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
         hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u);
     LAUNCHCHK(c, "k_merge_ab_lean");
     TRY(prof_end(c));
-    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-    const unsigned nscan = (unsigned)c->lean_scan;
-    hipLaunchKernelGGL(k_finish_lean, dim3(nscan + 8), dim3(1024), 0, c->stream, c->d_mat, c->vcap, c->d_rowmax,
-                       c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, c->d_hdr2[c->mq], c->d_stage,
-                       c->d_removed, c->d_smask, nwords, nscan);
-    LAUNCHCHK(c, "k_finish_lean");
-    TRY(prof_end(c));
-    c->par ^= 1;  // (a sparse-style pass: staged headers, the header arrays do not flip)
-    c->stats_valid = false;
-    c->stream_is_bytes = false;
+    TRY(launch_table2(c, newid, iter, rec, /*sparse (staged headers)=*/true, dl, false, /*lean=*/true));
     c->n_lean++;
     if (use_index) c->n_sparse++; else c->n_dense++;
     return BPE_OK;

@@ -136,7 +136,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                               (lean_on || c->lean == 2 || (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count));
             if (lean) {
                 lean_on = true;
-                TRY(launch_select(c, full_rowmax, false, true));
+                TRY(launch_select(c, full_rowmax, false));
                 TRY(launch_lean(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = 0;
                 lean_kind[(size_t)i] = sparse ? 1 : 2;
@@ -158,12 +158,13 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         if (consumed < i && (i - consumed > c->depth || i == num_merges)) {
             TRY(consume(consumed));
             if (deferred >= 0) {
-                // Iterations [deferred, i) did nothing on the device (all of them lean ones, all no-ops
-                // behind the deferred one): undo what enqueueing them changed on the host, then run
-                // iteration `deferred` through the general path and go on from there.
+                // Iterations [deferred, i) merged nothing on the device (all of them lean ones, all no-ops
+                // behind the deferred one); they did carry the stream length forward, so the ping-pong
+                // parity (and any re-packing enqueued among them) stands as the host has it.  Take their
+                // passes out of the statistics, run iteration `deferred` through the general path and go
+                // on from there.
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 for (int j = deferred; j < i; j++) {
-                    c->par ^= 1;
                     c->n_lean--;
                     if (lean_kind[(size_t)j] == 1) c->n_sparse--; else c->n_dense--;
                     c->h_rec[j].seq = 0;

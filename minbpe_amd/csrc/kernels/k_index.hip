@@ -46,7 +46,6 @@ struct CandArgs {
     uint32_t enable;     // 0: this iteration's a != b pass is a dense one
     uint32_t tie_index;  // the index is live: block 0 of k_select breaks ties through it
     uint32_t tie_window; // block 0 first looks through the first TIE_WIN slots by itself (experiment)
-    uint32_t *dirty_n;   // lean iterations: the queue of rows to re-scan is emptied here, for the pass that follows
 };
 __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st, uint32_t a, uint32_t b) {
     __shared__ uint32_t s_wtot[16];

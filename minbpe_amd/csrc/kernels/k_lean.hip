@@ -1,19 +1,18 @@
 // k_lean.hip -- the training iteration once a merged pair has few sites ("lean" iterations: the
 // last ~29,000 of the 31,744 merges of a 1 GB / vocab-32000 run, where a pass rewrites a few
-// hundred slots and nothing is bound by bytes any more, only by the number of dependent memory
-// round trips and launches).  Three launches instead of five, no delta vectors, no sweep over the
-// vocabulary:
-//   k_select            (k_select.hip)  the pair
+// hundred slots and nothing is bound by bytes any more, only by the number of launches and of
+// dependent memory round trips inside them).  Four launches instead of five, shorter ones:
+//   k_select            (k_select.hip)  the pair -- and no candidate list
 //   k_merge_ab_lean     every wave finds its own candidate slots in the inverted index (the three
-//                       filter rows of the pair, 1024 slots per step -- no candidate list, no
-//                       single block building one) and rewrites them; each site updates the pair
-//                       table itself (merge_ab_wave<DIRECT>, k_slots2.hip) and queues row L when
-//                       its maximum may have dropped
-//   k_finish_lean       re-scans rows a, b, Z and the queued rows (one workgroup per row, the whole
-//                       row in flight at once), commits the staged headers, new stream length, record
+//                       filter rows of the pair, 1024 slots per step: no list, no single block
+//                       building one) and rewrites them (merge_ab_wave, k_slots2.hip; delta format B)
+//   k_apply2            (k_table.hip)   folds the delta into the pair table, staged headers, length, record
+//   k_rowmax_lean       rows a, b, Z and the queued rows, one workgroup per row, the whole row in
+//                       flight at once (k_rowmax_list walks a row 16 KB at a time)
 // A pair with a == b is not merged here: the pass is DEFERRED -- the iteration reports ST_DEFER,
-// everything enqueued behind it is a no-op, and the host re-runs the iteration through the general
-// path (k_merge_aa).  75 of 31,744 merges.
+// everything enqueued behind it is a no-op that only carries the stream length forward, and the
+// host re-runs the iteration through the general path (k_merge_aa).  75 of 31,744 merges; the
+// general path pays a k_merge_aa launch in every iteration for them.
 // Part of bpe_kernels.hip, which includes the parts in order.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -32,6 +31,7 @@ __global__ void __launch_bounds__(MT, 4)
 k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
     DevState *st = A.st;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *A.dirty_n = 0;  // (for the table update that follows)
     if (st->status || st->defer) return;
     if (!st->found) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
@@ -75,7 +75,7 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
                 const uint32_t t = (c * 32 + (uint32_t)lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
                 mm &= mm - 1u;
                 if ((k++ & (MT / 64 - 1)) == (uint32_t)wave_id())
-                    merge_ab_wave<true, INDEXED, false, true>(s_out[wave_id()], nullptr, t, A, a, b);
+                    merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
             }
         }
     }
@@ -137,70 +137,31 @@ __device__ __forceinline__ void row_scan_wide(uint32_t *__restrict__ row, uint32
     }
 }
 
-// Workgroups [0, nscan): row maxima.  Workgroup nscan: stream length + the iteration's record.
-// Workgroups [nscan, grid): commit the headers the pass staged.
+// Row maxima after k_apply2: workgroups 0, 1, 2 take rows a, b, Z (always re-scanned; (a,b) is
+// retired on the way: no (a,b) survives the merge, F2), the others the queued rows -- k_apply2 queues
+// a, b and Z too, those entries are skipped.  Everything a workgroup needs before its row is read
+// in one round trip (the pair, the queue length, its queue entry).
 __global__ void __launch_bounds__(1024)
-k_finish_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, DevState *st,
-              uint32_t Z, const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n, int par,
-              IterRec *rec, int iter, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
-              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint32_t nscan) {
+k_rowmax_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
+              uint32_t Z, const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
     __shared__ unsigned long long s_red[32];
-    if (blockIdx.x < nscan) {
-        if (st->status || st->defer) return;
-        const uint32_t a = (uint32_t)st->a, b = (uint32_t)st->b;
-        const uint32_t nd = *dirty_n;
-        for (uint32_t i = blockIdx.x; i < 3 + nd; i += nscan) {
-            const uint32_t x = i == 0 ? a : (i == 1 ? b : (i == 2 ? Z : dirty_list[i - 3]));
-            uint32_t m = 0, arg = 0;
-            // (a,b) is retired on the way: no (a,b) survives the merge (F2)
-            row_scan_wide(mat + (size_t)x * stride, Z + 1, x == a ? (int)b : -1, s_red, m, arg);
-            if (threadIdx.x == 0) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+    const uint32_t status = st->status, defer = st->defer;
+    const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
+    const uint32_t nd = *dirty_n;
+    uint32_t q = blockIdx.x >= 3 ? dirty_list[blockIdx.x - 3] : 0u;  // (the list has room for every row: always readable)
+    if (status || defer) return;
+    for (uint32_t i = blockIdx.x; i < 3 + nd; i += gridDim.x) {
+        uint32_t x;
+        if (i < 3) {
+            x = i == 0 ? a : (i == 1 ? b : Z);
+            if (i == 1 && b == a) continue;
+        } else {
+            x = (i == blockIdx.x) ? q : dirty_list[i - 3];
+            if (x == a || x == b || x == Z) continue;
         }
-        return;
-    }
-    if (blockIdx.x == nscan && threadIdx.x < 64) {
-        // ids removed by the merge pass: 256 counters, one per 256-byte line (see DELTA_SKEW)
-        uint32_t v = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
-            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
-            v += x;
-        }
-        v = wave_sum_u32(v);
-        if (threadIdx.x == 0) {
-            const uint32_t status = st->status, defer = st->defer;
-            const unsigned long long n = st->n[par];
-            unsigned long long nn = n;
-            if (status == 0 && !defer) {
-                nn = n - v;
-                st->n[par ^ 1] = nn;
-            }
-            st->removed = 0;
-            rec[iter].a = st->a;
-            rec[iter].b = st->b;
-            rec[iter].count = st->count;
-            rec[iter].status = status ? status : (defer ? ST_DEFER : ST_OK);
-            rec[iter].new_len = nn;
-            __threadfence_system();
-            rec[iter].seq = (unsigned long long)iter + 1;
-        }
-    }
-    if (st->status || st->defer) return;
-    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
-    const uint32_t step = (gridDim.x - nscan) * blockDim.x;
-    for (uint32_t w = (blockIdx.x - nscan) * blockDim.x + threadIdx.x; w < nwords; w += step) {
-        uint32_t m = smask[w];
-        if (!m) continue;
-        smask[w] = 0;
-        while (m) {
-            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
-            m &= m - 1u;
-            const StageRec r = stage[t];
-            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
-            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
-            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
-        }
+        uint32_t m = 0, arg = 0;
+        row_scan_wide(mat + (size_t)x * stride, Z + 1, x == a ? (int)b : -1, s_red, m, arg);
+        if (threadIdx.x == 0) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
     }
 }
 

@@ -384,7 +384,6 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
-            if (C.dirty_n) *C.dirty_n = 0;
             __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;

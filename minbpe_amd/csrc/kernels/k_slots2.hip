@@ -66,11 +66,6 @@ struct AbArgs {
     uint32_t *removed;        // [256] ids removed by this pass, spread over counters (t & 255): one
                               // counter would serialise every changed slot of a dense pass (~11 ns each)
     uint32_t *dirty_n;        // reset here for the table update that follows
-    // lean passes (k_lean.hip): the pair table is updated at the sites themselves
-    uint32_t *mat;            // count[V][V]
-    uint32_t mstride;         // ... its row stride
-    const uint32_t *rowmax;   // {max, arg} per row as it stood before this pass
-    uint32_t *dirty_list;     // rows whose maximum may have dropped (appended at *dirty_n)
 };
 
 __global__ void __launch_bounds__(256)
@@ -148,13 +143,7 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int srclane) {
 // VGPRs; the early dense passes, which run before the index exists, use the variant without).
 // LDSD: every id is below LDSD_CAP and the delta goes into the workgroup's LDS tables `sd`
 // (SL[LDSD_CAP] | SR[LDSD_CAP] | adj | removed), flushed by the kernel when its slots are done.
-// DIRECT (lean passes, k_lean.hip): no delta vectors at all -- a pass has so few sites that each
-// one updates the pair table itself: (L,a) -= w, (L,Z) += w, (b,R) -= w, (Z,R) += w, and the
-// (b,a) -> (Z,Z) pairs between adjacent sites once per wave.  The returning atomicSub tells the
-// one site that sees the ORIGINAL count of (L,a) whether that was row L's maximum: only then can the
-// maximum have dropped, and the row is queued for a re-scan (rows a, b and Z always are).  No other
-// row's maximum moves: (L,Z) <= what (L,a) lost < the row maximum.
-template <bool SPARSE, bool INDEXED, bool LDSD, bool DIRECT = false>
+template <bool SPARSE, bool INDEXED, bool LDSD>
 __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t,
                                               const AbArgs &A, const uint32_t a, const uint32_t b) {
     const int lane = lane_id();
@@ -330,11 +319,11 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
     }
     // ---- (7) pair-table delta of my sites (format B); their new pairs enter the index -----------
     if (!sites) return;  // carry only: the site belongs to the previous slot
-    if (!DIRECT && !A.delta) return;  // (experiment "exp_no_delta": time the pass without its table bookkeeping; results are wrong)
+    if (!A.delta) return;  // (experiment "exp_no_delta": time the pass without its table bookkeeping; results are wrong)
     const uint32_t nrep = 1u << (A.vcap >> 24);
     const uint32_t vc = A.vcap & 0xFFFFFFu;
-    uint32_t *dl = DIRECT ? nullptr : A.delta + delta_rep_off(t & (nrep - 1), vc);  // SL
-    uint32_t *dr = DIRECT ? nullptr : dl + vc;                                      // SR
+    uint32_t *dl = A.delta + delta_rep_off(t & (nrep - 1), vc);  // SL
+    uint32_t *dr = dl + vc;                                      // SR
     uint32_t adj = 0;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
@@ -378,12 +367,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
             if (!(wa & FLAG) && Lw != INVALID_WORD) {
                 const bool ltail = ((LL & IDMASK) == a) & ((Lw & NWMASK) == b);
                 if (!ltail) {
-                    if (DIRECT) {
-                        const uint32_t L = Lw & IDMASK;
-                        const uint32_t old = atomicSub(&A.mat[(size_t)L * A.mstride + a], wt);
-                        atomicAdd(&A.mat[(size_t)L * A.mstride + A.newid], wt);
-                        if (L != a && L != b && old == A.rowmax[2 * L]) A.dirty_list[atomicAdd(A.dirty_n, 1u)] = L;
-                    } else if (LDSD) atomicAdd(&sd[Lw & IDMASK], wt);
+                    if (LDSD) atomicAdd(&sd[Lw & IDMASK], wt);
                     else atomicAdd(&dl[Lw & IDMASK], wt);
                     // the new pair (L, Z) enters the filter of the slot that holds L, and mine too if
                     // that is another slot (a boundary pair is known to both slots it touches: the
@@ -398,10 +382,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
                 const bool rsite = ((R & IDMASK) == a) & ((RR & NWMASK) == b);
                 if (rsite) adj += wt;
-                else if (DIRECT) {
-                    atomicSub(&A.mat[(size_t)b * A.mstride + (R & IDMASK)], wt);
-                    atomicAdd(&A.mat[(size_t)A.newid * A.mstride + (R & IDMASK)], wt);
-                } else if (LDSD) atomicAdd(&sd[LDSD_CAP + (R & IDMASK)], wt);
+                else if (LDSD) atomicAdd(&sd[LDSD_CAP + (R & IDMASK)], wt);
                 else atomicAdd(&dr[R & IDMASK], wt);
                 if (INDEXED) {
                     const uint32_t y = rsite ? A.newid : (R & IDMASK);
@@ -414,10 +395,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
     if (__any(adj != 0)) {
         adj = wave_sum_u32(adj);
         if (lane == 0) {
-            if (DIRECT) {
-                atomicSub(&A.mat[(size_t)b * A.mstride + a], adj);
-                atomicAdd(&A.mat[(size_t)A.newid * A.mstride + A.newid], adj);
-            } else if (LDSD) atomicAdd(&sd[2 * LDSD_CAP], adj);
+            if (LDSD) atomicAdd(&sd[2 * LDSD_CAP], adj);
             else atomicAdd(&A.st->adj, adj);
         }
     }

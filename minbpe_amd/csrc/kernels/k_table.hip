@@ -28,6 +28,8 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
         const unsigned long long n = st->n[par];
         unsigned long long nn = n;
         if (st->status == 0) {
+            // (a deferred lean iteration, k_lean.hip, removed nothing: the length is carried forward,
+            // so that the host's ping-pong parity and a re-packing enqueued behind it stay right)
             nn = n - st->removed;
             st->n[par ^ 1] = nn;
         }
@@ -36,13 +38,13 @@ __device__ __forceinline__ void apply_body(uint32_t *__restrict__ mat, uint32_t 
             rec[iter].a = st->status == 0 ? st->fin_a : st->a;
             rec[iter].b = st->status == 0 ? st->fin_b : st->b;
             rec[iter].count = st->count;
-            rec[iter].status = st->status;
+            rec[iter].status = (st->status == 0 && st->defer) ? ST_DEFER : st->status;
             rec[iter].new_len = nn;
             __threadfence_system();
             rec[iter].seq = (unsigned long long)iter + 1;
         }
     }
-    if (st->status) return;
+    if (st->status || st->defer) return;
     // 8 lanes per token: each folds a quarter of the replicas (all its loads in flight at
     // once), then a 3-step shuffle sum.  The kernel is latency-bound, so width, not work, counts.
     const uint32_t g = threadIdx.x & 7u;
@@ -260,7 +262,7 @@ k_apply2(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ del
                                  FOLDED ? delta + 4 * (size_t)(vcap & 0xFFFFFFu) : nullptr);
         return;
     }
-    if (st->status) return;
+    if (st->status || st->defer) return;
     // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
     const uint32_t step = (gridDim.x - na) * blockDim.x;
     for (uint32_t w = (blockIdx.x - na) * blockDim.x + threadIdx.x; w < nwords; w += step) {

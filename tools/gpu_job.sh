@@ -11,7 +11,7 @@ WL=${WL:-regex1g}
 for step in $STEPS; do
 case $step in
 tests)
-    timeout -k 5 ${TEST_TIMEOUT:-400} python -X faulthandler -m pytest tests -m gpu -x -q ${PYTEST_ARGS} > gpurun_out/${TAG}_pytest.log 2>&1
+    timeout -k 5 ${TEST_TIMEOUT:-400} python -X faulthandler -m pytest ${PYTEST_FILES:-tests} -m gpu -q ${PYTEST_ARGS:--x} > gpurun_out/${TAG}_pytest.log 2>&1
     echo "pytest rc=$?"; tail -12 gpurun_out/${TAG}_pytest.log ;;
 smoke)
     timeout -k 5 200 python __graft_entry__.py --smoke > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/${TAG}_smoke.log ;;
