@@ -83,8 +83,9 @@ struct bpe_ctx {
     uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 24576;               // option "lean_count"
-    int lean_grid = 512;                      // option "lean_grid": most workgroups of a lean merge pass
+    int lean_grid = 1024;                     // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 16;                       // option "lean_scan": workgroups of k_rowmax_lean
+    int lean_select = 1;                      // option "lean_select": 1 = k_select_lean while the index is live
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
@@ -456,6 +457,25 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
                            c->vcap, c->vcur, c->d_st, stream_ref(c), c->par, c->dp_active ? 1 : 0,
                            ++c->sel_epoch, C);
     LAUNCHCHK(c, "k_select");
+    TRY(prof_end(c));
+    return BPE_OK;
+}
+
+// K2 of a lean iteration while the index is live: one workgroup decides (or defers to the general path)
+int launch_select_lean(bpe_ctx *c) {
+    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    CandArgs C;
+    C.idx = c->d_idx;
+    C.dirty = c->d_idx_dirty;
+    C.cand = nullptr;
+    C.stride = (uint32_t)c->idx_cap_words;
+    C.T = (uint32_t)c->slot_T;
+    C.enable = 0;
+    C.tie_index = 1;
+    C.tie_window = 0;
+    hipLaunchKernelGGL(k_select_lean, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap, c->vcur,
+                       c->d_st, stream_ref_h(c), C);
+    LAUNCHCHK(c, "k_select_lean");
     TRY(prof_end(c));
     return BPE_OK;
 }
@@ -862,7 +882,9 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
     const uint32_t nwords = (T + 31) / 32;
-    const unsigned g = std::max(1u, std::min((nwords + 31) / 32, (unsigned)c->lean_grid));
+    // one 32-slot word of the candidate mask (index) or one slot (no index) per wave and step
+    const uint32_t units = use_index ? nwords : T;
+    const unsigned g = std::max(1u, std::min((units + MT / 64 - 1) / (MT / 64), (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->idx_live)
         hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(MT), 0, c->stream, A, c->d_idx_dirty,

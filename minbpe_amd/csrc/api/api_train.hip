@@ -136,7 +136,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                               (lean_on || c->lean == 2 || (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count));
             if (lean) {
                 lean_on = true;
-                TRY(launch_select(c, full_rowmax, false));
+                if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax)
+                    TRY(launch_select_lean(c));
+                else
+                    TRY(launch_select(c, full_rowmax, false));
                 TRY(launch_lean(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = 0;
                 lean_kind[(size_t)i] = sparse ? 1 : 2;

@@ -42,41 +42,30 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
         if (blockIdx.x == 0 && threadIdx.x == 0) st->defer = 1;
         return;
     }
-    const int lane = lane_id();
     const uint32_t Tl = min(A.T, st->tlive);
+    const uint32_t gw = blockIdx.x * (MT / 64) + wave_id(), nw = gridDim.x * (MT / 64);
     // short slots about: adjacency in slot numbers means nothing, visit everything (k_index.hip)
-    const bool all = !use_index || st->gap != 0;
+    if (!use_index || st->gap != 0) {
+        for (uint32_t t = gw; t < Tl; t += nw) merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+        return;
+    }
+    // One 32-slot word of the candidate mask per wave and step: the three filter words of the pair
+    // AND-ed, plus the slots an a == b pass rewrote since the index was built.  The addresses are
+    // wave-uniform (scalar loads); with a few hundred candidates among ~200 k slots almost every
+    // wave finds nothing, and the ones that do are spread over the whole grid.
     const uint32_t nwords = (Tl + 31) / 32;
-    const uint32_t nchunks = (nwords + 31) / 32;
     uint32_t h1, h2, h3;
     pair_hash(a, b, h1, h2, h3);
-    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        // the candidate mask of 1024 slots: one 32-slot word per lane (lanes 0..31), every wave
-        // of the workgroup computes the same one and takes every fourth candidate
-        const uint32_t w = c * 32 + (uint32_t)lane;
-        uint32_t mk = 0;
-        if (lane < 32 && w < nwords) {
-            if (all) {
-                mk = 0xFFFFFFFFu;
-            } else {
-                mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
-                      A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
-            }
-            const uint32_t left = Tl - w * 32;
-            if (left < 32) mk &= (1u << left) - 1u;
-        }
-        unsigned long long bal = __ballot(mk != 0);
-        uint32_t k = 0;
-        while (bal) {
-            const int lw = __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mk, lw);
-            while (mm) {
-                const uint32_t t = (c * 32 + (uint32_t)lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
-                mm &= mm - 1u;
-                if ((k++ & (MT / 64 - 1)) == (uint32_t)wave_id())
-                    merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
-            }
+    for (uint32_t w = gw; w < nwords; w += nw) {
+        uint32_t mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
+                       A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
+        const uint32_t left = Tl - w * 32;
+        if (left < 32) mk &= (1u << left) - 1u;
+        mk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk);
+        while (mk) {
+            const uint32_t t = w * 32 + (uint32_t)__ffs((int)mk) - 1u;
+            mk &= mk - 1u;
+            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
         }
     }
 }

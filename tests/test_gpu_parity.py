@@ -184,8 +184,12 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
             n_same = sum(a == b for a, b in exp[0])
             if lean == 0:
                 assert stats["lean"] == 0 and stats["deferred"] == 0
-            elif lean == 2:  # every a != b merge is a lean iteration, every a == b one was handed back
-                assert stats["lean"] == nm - n_same and stats["deferred"] == n_same
+            elif lean == 2:
+                # every merge is a lean iteration or was handed back to the general path: all a == b ones
+                # are, and (index live) those whose tie k_select_lean could not settle by itself
+                assert stats["lean"] + stats["deferred"] == nm and stats["deferred"] >= n_same
+                if sparse != 2:
+                    assert stats["deferred"] == n_same
             else:
                 assert stats["lean"] > 0
         assert res["pairs"] == exp[0]
