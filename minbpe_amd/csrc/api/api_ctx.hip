@@ -84,8 +84,12 @@ struct bpe_ctx {
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 24576;               // option "lean_count"
     int lean_grid = 1024;                     // option "lean_grid": most workgroups of a lean merge pass
-    int lean_scan = 16;                       // option "lean_scan": workgroups of k_rowmax_lean
-    int lean_select = 1;                      // option "lean_select": 1 = k_select_lean while the index is live
+    int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
+    int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
+    uint32_t *d_dbits = nullptr;              // [DBITS_WORDS] rows a lean table update flagged for re-scanning
+    unsigned long long *d_lean_res = nullptr; // row maxima on their way to the deciding workgroup of k_rowsel_lean: 2 words per item
+    uint32_t lean_tag = 0;                    // ... tagged with this launch counter
+    bool rows_pending = false;                // a lean table update ran and its rows have not been re-scanned yet
     uint64_t cap_slots = 0;
     // data-parallel stepping (bpe_dp_*)
     int dp_rank = 0, dp_nranks = 1, dp_merges = 0, dp_enq = 0, dp_done = 0;
@@ -249,6 +253,12 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
     TRY(dev_realloc(c, c->d_delta, (size_t)nv * 4 * DELTA_REPL + 256 * DELTA_SKEW));  // (+ the skew of up to 256 replicas)
     TRY(dev_realloc(c, c->d_dirty_list, (size_t)nv));
     if (!c->d_dirty_n) HIPCHK(c, hipMalloc((void **)&c->d_dirty_n, sizeof(uint32_t)));
+    if (!c->d_dbits) {
+        HIPCHK(c, hipMalloc((void **)&c->d_dbits, DBITS_WORDS * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_dbits, 0, DBITS_WORDS * sizeof(uint32_t), c->stream));
+    }
+    TRY(dev_realloc(c, c->d_lean_res, 2 * ((size_t)nv + 8)));
+    HIPCHK(c, hipMemsetAsync(c->d_lean_res, 0, 2 * ((size_t)nv + 8) * sizeof(unsigned long long), c->stream));
     if (!c->d_removed) {
         HIPCHK(c, hipMalloc((void **)&c->d_removed, 256 * REMOVED_STRIDE * sizeof(uint32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_removed, 0, 256 * REMOVED_STRIDE * sizeof(uint32_t), c->stream));
@@ -461,8 +471,9 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     return BPE_OK;
 }
 
-// K2 of a lean iteration while the index is live: one workgroup decides (or defers to the general path)
-int launch_select_lean(bpe_ctx *c) {
+// K2 of a lean iteration while the index is live, fused with the row maxima the previous lean table
+// update left to do: workgroup 0 decides (or defers to the general path), the others re-scan rows
+int launch_rowsel_lean(bpe_ctx *c) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     CandArgs C;
     C.idx = c->d_idx;
@@ -473,10 +484,23 @@ int launch_select_lean(bpe_ctx *c) {
     C.enable = 0;
     C.tie_index = 1;
     C.tie_window = 0;
-    hipLaunchKernelGGL(k_select_lean, dim3(1), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat, c->vcap, c->vcur,
-                       c->d_st, stream_ref_h(c), C);
-    LAUNCHCHK(c, "k_select_lean");
+    hipLaunchKernelGGL(k_rowsel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                       c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag);
+    LAUNCHCHK(c, "k_rowsel_lean");
     TRY(prof_end(c));
+    c->rows_pending = false;
+    return BPE_OK;
+}
+
+// the row maxima a lean table update left to do, on their own (ncols = ids in use now)
+int flush_lean_rows(bpe_ctx *c, uint32_t ncols) {
+    if (!c->rows_pending) return BPE_OK;
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    hipLaunchKernelGGL(k_rowmax_lean, dim3((unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_mat, c->vcap,
+                       c->d_rowmax, c->d_st, ncols, c->d_dbits);
+    LAUNCHCHK(c, "k_rowmax_lean");
+    TRY(prof_end(c));
+    c->rows_pending = false;
     return BPE_OK;
 }
 
@@ -823,8 +847,7 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
 
 // table update of the second slotted form (+ commit of staged headers, stream length, record);
 // folded: the delta comes from the all-reduced payload of sharded training
-int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse, uint32_t dl, bool folded,
-                  bool lean = false) {
+int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool sparse, uint32_t dl, bool folded) {
     const uint32_t T = (uint32_t)c->slot_T;
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (newid + 1 + 31) / 32;
@@ -837,12 +860,8 @@ int launch_table2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
                            c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n, c->par, rec, iter, na,
                            c->d_hdr2[c->mq], c->d_stage, c->d_removed, c->d_smask, (T + 31) / 32);
     LAUNCHCHK(c, "k_apply2");
-    if (lean)
-        hipLaunchKernelGGL(k_rowmax_lean, dim3((unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_mat, c->vcap,
-                           c->d_rowmax, c->d_st, newid, c->d_dirty_list, c->d_dirty_n);
-    else
-        hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
-                           c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
+    hipLaunchKernelGGL(k_rowmax_list, dim3(ROW_BLOCKS), dim3(1024), 0, c->stream, c->d_mat, c->vcap, newid + 1,
+                       c->d_rowmax, c->d_st, c->d_dirty_list, c->d_dirty_n);
     LAUNCHCHK(c, "k_rowmax_list");
     TRY(prof_end(c));
     c->par ^= 1;
@@ -858,9 +877,10 @@ int launch_merge2(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool spars
     return launch_table2(c, newid, iter, rec, sparse, dl, false);
 }
 
-// A lean iteration (k_lean.hip) after k_select: the merge pass (waves find their own candidates),
-// then the table update with the wide row scans.  use_index: candidates come from the inverted
-// index (it is live); otherwise every live slot is visited.
+// A lean iteration (k_lean.hip) after its selection: the merge pass (waves find their own candidates),
+// then the table update -- which leaves the row maxima to the next launch that needs them
+// (k_rowsel_lean, or flush_lean_rows).  use_index: candidates come from the inverted index (it is
+// live); otherwise every live slot is visited.
 int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_index) {
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, newid);
@@ -888,12 +908,23 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->idx_live)
         hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(MT), 0, c->stream, A, c->d_idx_dirty,
-                           use_index ? 1u : 0u);
+                           use_index ? 1u : 0u, c->d_dbits);
     else
-        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u);
+        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u,
+                           c->d_dbits);
     LAUNCHCHK(c, "k_merge_ab_lean");
     TRY(prof_end(c));
-    TRY(launch_table2(c, newid, iter, rec, /*sparse (staged headers)=*/true, dl, false, /*lean=*/true));
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    const uint32_t na = (newid + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_apply_lean, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
+                       c->d_rowmax, c->d_st, newid, c->d_dbits, c->par, rec, iter, na, c->d_hdr2[c->mq], c->d_stage,
+                       c->d_removed, c->d_smask, nwords);
+    LAUNCHCHK(c, "k_apply_lean");
+    TRY(prof_end(c));
+    c->par ^= 1;  // (a sparse-style pass: staged headers, the header arrays do not flip)
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    c->rows_pending = true;
     c->n_lean++;
     if (use_index) c->n_sparse++; else c->n_dense++;
     return BPE_OK;

@@ -42,6 +42,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     c->last_count = ~0ull;
     c->n_sparse = c->n_dense = c->n_index_builds = 0;
     c->n_lean = c->n_deferred = 0;
+    c->rows_pending = false;
     // lean iterations (k_lean.hip): which ones were enqueued that way (1: candidates from the index, 2: every
     // slot), the iteration that reported ST_DEFER, and the one iteration that must take the general path
     std::vector<uint8_t> lean_kind(form2 ? (size_t)num_merges : 0, 0);
@@ -136,14 +137,17 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                               (lean_on || c->lean == 2 || (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count));
             if (lean) {
                 lean_on = true;
-                if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax)
-                    TRY(launch_select_lean(c));
-                else
+                if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax) {
+                    TRY(launch_rowsel_lean(c));
+                } else {
+                    TRY(flush_lean_rows(c, c->vcur));
                     TRY(launch_select(c, full_rowmax, false));
+                }
                 TRY(launch_lean(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = 0;
                 lean_kind[(size_t)i] = sparse ? 1 : 2;
             } else {
+            TRY(flush_lean_rows(c, c->vcur));
             TRY(launch_select(c, full_rowmax, sparse));
             if (c->slotted && c->slot2) {
                 const int mq0 = c->mq;
@@ -172,6 +176,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                     if (lean_kind[(size_t)j] == 1) c->n_sparse--; else c->n_dense--;
                     c->h_rec[j].seq = 0;
                 }
+                // (the deferred iteration's own selection launch re-scanned the rows of the merge before it;
+                // the no-op table updates behind it left nothing to re-scan)
+                c->rows_pending = false;
                 hipLaunchKernelGGL(k_clear_defer, dim3(1), dim3(1), 0, c->stream, c->d_st);
                 LAUNCHCHK(c, "k_clear_defer");
                 c->n_deferred++;
@@ -182,6 +189,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         if (consumed >= num_merges) break;
     }
+    if (!stop) TRY(flush_lean_rows(c, 256u + (uint32_t)done));
+    c->rows_pending = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->slotted) {
         // leave the ids contiguous for whoever reads them next

@@ -123,7 +123,10 @@ struct DevState {
                                   // sizes T from a length that is `depth` merges old, and nobody should walk that tail
     uint32_t defer;               // lean iterations (k_lean.hip): the decided pair needs the general path (a == b): this
                                   // iteration and everything enqueued behind it do nothing until the host has re-run it there
-    uint32_t pad_[1];
+    // lean iterations: the pair k_apply_lean folded last and its new token -- rows scan_a, scan_b, scan_z are
+    // re-scanned (and (scan_a, scan_b) retired) by the NEXT launch that needs the row maxima; 0xFFFFFFFF = none.
+    // Re-scanning them again is harmless: a merged pair never re-forms.
+    uint32_t scan_a, scan_b, scan_z;
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -1,18 +1,26 @@
 // k_lean.hip -- the training iteration once a merged pair has few sites ("lean" iterations: the
 // last ~29,000 of the 31,744 merges of a 1 GB / vocab-32000 run, where a pass rewrites a few
 // hundred slots and nothing is bound by bytes any more, only by the number of launches and of
-// dependent memory round trips inside them).  Four launches instead of five, shorter ones:
-//   k_select            (k_select.hip)  the pair -- and no candidate list
-//   k_merge_ab_lean     every wave finds its own candidate slots in the inverted index (the three
-//                       filter rows of the pair, 1024 slots per step: no list, no single block
-//                       building one) and rewrites them (merge_ab_wave, k_slots2.hip; delta format B)
-//   k_apply2            (k_table.hip)   folds the delta into the pair table, staged headers, length, record
-//   k_rowmax_lean       rows a, b, Z and the queued rows, one workgroup per row, the whole row in
-//                       flight at once (k_rowmax_list walks a row 16 KB at a time)
-// A pair with a == b is not merged here: the pass is DEFERRED -- the iteration reports ST_DEFER,
-// everything enqueued behind it is a no-op that only carries the stream length forward, and the
-// host re-runs the iteration through the general path (k_merge_aa).  75 of 31,744 merges; the
-// general path pays a k_merge_aa launch in every iteration for them.
+// dependent memory round trips inside them -- a launch costs ~2 us plus ~1.7 us per round trip).
+// Three launches instead of five, each a short chain:
+//   k_rowsel_lean    row maxima of the PREVIOUS merge + the pair of this one.  Workgroups 1.. re-scan
+//                    rows a, b, Z and the rows the last table update flagged, one row per workgroup
+//                    with the whole row in flight, and hand each result to workgroup 0 as two
+//                    tagged 8-byte words (no fence, no flag: the data is the flag).  Workgroup 0 reads
+//                    the row-maxima array meanwhile, leaves those rows out, takes them from the
+//                    hand-off, and decides -- ties through the index (tie_by_index, k_select.hip);
+//                    nothing of the decision goes through memory until it is final.
+//   k_merge_ab_lean  every wave finds its own candidate slots in the inverted index (the three
+//                    filter words of the pair per 32 slots: no candidate list, no single block
+//                    building one) and rewrites them (merge_ab_wave, k_slots2.hip; delta format B)
+//   k_apply_lean     folds the delta into the pair table, one token per thread, every load in
+//                    flight at once, no returning atomic: a row is flagged for re-scanning when the
+//                    column that attains its maximum is (or may be) the one that lost pairs
+// What workgroup 0 cannot settle alone (more than TIE_CAP tied pairs, short slots about, a tied pair
+// the index does not lead to) and every pair with a == b is DEFERRED: the iteration reports
+// ST_DEFER, everything enqueued behind it is a no-op that only carries the stream length forward,
+// and the host re-runs the iteration through the general path.  75 of 31,744 merges have a == b;
+// the general path pays a k_merge_aa launch in every iteration for them.
 // Part of bpe_kernels.hip, which includes the parts in order.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,18 +28,26 @@
 
 #include "../bpe_device.h"
 #include "k_index.hip"
+#include "k_select.hip"
 #include "k_slots2.hip"
 #include "k_table.hip"
 
 namespace bpe {
 
-// use_index == 0: no index (small streams) -- every live slot is visited
+constexpr uint32_t NOROW = 0xFFFFFFFFu;
+constexpr int DBITS_WORDS = 2048;     // one bit per row (vocab <= 65536)
+constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one k_rowsel_lean launch hands to its deciding workgroup
+
+// ---------------------------------------------------------------------------
+// merge pass.  use_index == 0: no index (small streams) -- every live slot is visited
 template <bool INDEXED>
 __global__ void __launch_bounds__(MT, 4)
-k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index) {
+k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
     DevState *st = A.st;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *A.dirty_n = 0;  // (for the table update that follows)
+    // (the rows flagged by the last table update were re-scanned by the launch before this one)
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += MT) dbits[i] = 0;
     if (st->status || st->defer) return;
     if (!st->found) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
@@ -43,35 +59,155 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
         return;
     }
     const uint32_t Tl = min(A.T, st->tlive);
-    const uint32_t gw = blockIdx.x * (MT / 64) + wave_id(), nw = gridDim.x * (MT / 64);
     // short slots about: adjacency in slot numbers means nothing, visit everything (k_index.hip)
     if (!use_index || st->gap != 0) {
-        for (uint32_t t = gw; t < Tl; t += nw) merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+        const uint32_t nw = gridDim.x * (MT / 64);
+        for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < Tl; t += nw)
+            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
         return;
     }
-    // One 32-slot word of the candidate mask per wave and step: the three filter words of the pair
-    // AND-ed, plus the slots an a == b pass rewrote since the index was built.  The addresses are
-    // wave-uniform (scalar loads); with a few hundred candidates among ~200 k slots almost every
-    // wave finds nothing, and the ones that do are spread over the whole grid.
+    // A workgroup takes four 32-slot words of the candidate mask per step -- the three filter words
+    // of the pair AND-ed, plus the slots an a == b pass rewrote since the index was built (wave-
+    // uniform addresses) -- and deals the candidates to its four waves in turn: two neighbouring
+    // slots that share a site (both are candidates) go to different waves.  With a few hundred
+    // candidates among ~200 k slots almost every workgroup finds nothing.
     const uint32_t nwords = (Tl + 31) / 32;
     uint32_t h1, h2, h3;
     pair_hash(a, b, h1, h2, h3);
-    for (uint32_t w = gw; w < nwords; w += nw) {
-        uint32_t mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
-                       A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
-        const uint32_t left = Tl - w * 32;
-        if (left < 32) mk &= (1u << left) - 1u;
-        mk = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk);
-        while (mk) {
-            const uint32_t t = w * 32 + (uint32_t)__ffs((int)mk) - 1u;
-            mk &= mk - 1u;
-            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+    constexpr uint32_t WPB = MT / 64;
+    for (uint32_t w0 = blockIdx.x * WPB; w0 < nwords; w0 += gridDim.x * WPB) {
+        uint32_t mk[WPB];
+#pragma unroll
+        for (uint32_t j = 0; j < WPB; j++) {
+            const uint32_t w = w0 + j;
+            uint32_t m = 0;
+            if (w < nwords) {
+                m = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
+                     A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
+                const uint32_t left = Tl - w * 32;
+                if (left < 32) m &= (1u << left) - 1u;
+            }
+            mk[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+        }
+        uint32_t k = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < WPB; j++) {
+            uint32_t mm = mk[j];
+            while (mm) {
+                const uint32_t t = (w0 + j) * 32 + (uint32_t)__ffs((int)mm) - 1u;
+                mm &= mm - 1u;
+                if ((k++ & (WPB - 1)) == (uint32_t)wave_id())
+                    merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+            }
         }
     }
 }
 
+// ---------------------------------------------------------------------------
+// table update, a != b (delta format B: vector 0 = SL, vector 1 = SR, st->adj; see k_slots2.hip).
+// Workgroups [0, na): one token per thread.  Workgroups [na, grid): commit the staged headers; the
+// first of them also makes the new stream length and the iteration's record.
+__global__ void __launch_bounds__(256)
+k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
+             const uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z, uint32_t *__restrict__ dbits, int par,
+             IterRec *rec, int iter, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
+             uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords) {
+    const uint32_t status = st->status, defer = st->defer;
+    if (blockIdx.x < na) {
+        if (status || defer) return;
+        const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+        if (t > Z) return;
+        const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b, adj = st->adj;
+        const uint32_t nrep = 1u << (vcap >> 24);
+        const uint32_t vc = vcap & 0xFFFFFFu;
+        const uint2 rmx = reinterpret_cast<const uint2 *>(rowmax)[t];
+        uint32_t sl = 0, sr = 0;
+        for (uint32_t r0 = 0; r0 < nrep; r0 += 16) {
+            uint32_t x[16][2];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t r = r0 + k;
+                x[k][0] = r < nrep ? delta[delta_rep_off(r, vc) + t] : 0u;
+                x[k][1] = r < nrep ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (x[k][0]) delta[delta_rep_off(r0 + k, vc) + t] = 0;
+                if (x[k][1]) delta[delta_rep_off(r0 + k, vc) + vc + t] = 0;
+                sl += x[k][0];
+                sr += x[k][1];
+            }
+        }
+        // format B -> the four table updates of token t: column a and the new column Z of row t,
+        // entries t of row b and of the new row Z
+        const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
+        if (sl) {
+            atomicSub(&mat[(size_t)t * stride + a], sl);
+            atomicAdd(&mat[(size_t)t * stride + Z], sl);
+            // Row t lost pairs in column a only and gained (t,Z) = sl <= what (t,a) lost: its maximum
+            // moves only if column a attains it.  rowarg says which column does -- or that several do.
+            // (rows a, b and Z are always re-scanned)
+            if (t != a && t != b && t != Z && (rmx.y == a || rmx.y == ROWARG_MULTI))
+                atomicOr(&dbits[t >> 5], 1u << (t & 31));
+        }
+        if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
+        if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+        return;
+    }
+    if (blockIdx.x == na && threadIdx.x < 64) {
+        // ids removed by the merge pass: 256 counters, one per 256-byte line (see DELTA_SKEW)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
+            v += x;
+        }
+        v = wave_sum_u32(v);
+        if (threadIdx.x == 0) {
+            const unsigned long long n = st->n[par];
+            unsigned long long nn = n;
+            if (status == 0) {
+                nn = n - v;  // (a deferred iteration removed nothing: the length is carried forward)
+                st->n[par ^ 1] = nn;
+                if (!defer) {
+                    st->scan_a = (uint32_t)st->fin_a;
+                    st->scan_b = (uint32_t)st->fin_b;
+                    st->scan_z = Z;
+                }
+            }
+            st->removed = 0;
+            rec[iter].a = status == 0 ? st->fin_a : st->a;
+            rec[iter].b = status == 0 ? st->fin_b : st->b;
+            rec[iter].count = st->count;
+            rec[iter].status = (status == 0 && defer) ? ST_DEFER : status;
+            rec[iter].new_len = nn;
+            __threadfence_system();
+            rec[iter].seq = (unsigned long long)iter + 1;
+        }
+    }
+    if (status || defer) return;
+    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
+    const uint32_t step = (gridDim.x - na) * blockDim.x;
+    for (uint32_t w = (blockIdx.x - na) * blockDim.x + threadIdx.x; w < nwords; w += step) {
+        uint32_t m = smask[w];
+        if (!m) continue;
+        smask[w] = 0;
+        while (m) {
+            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const StageRec r = stage[t];
+            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
+            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
+            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // One row of the table by a 1024-thread workgroup, every load of the row in flight at once
-// (vocab 32000: 8 x 16 bytes per thread); otherwise row_scan (k_table.hip).
+// (vocab 32000: 8 x 16 bytes per thread).  zero_col >= 0: that entry is retired on the way.
+// Returns the result to thread 0.
 __device__ __forceinline__ void row_scan_wide(uint32_t *__restrict__ row, uint32_t ncols, int zero_col,
                                               unsigned long long *s_red, uint32_t &m_out, uint32_t &arg_out) {
     unsigned long long kf = 0, kl = 0;  // count << 32 | ~column  and  count << 32 | column
@@ -89,7 +225,8 @@ __device__ __forceinline__ void row_scan_wide(uint32_t *__restrict__ row, uint32
             const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
             uint32_t v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
             if (zero_col >= 0 && (uint32_t)zero_col - y < 4u && y < n4) {
-                v[(uint32_t)zero_col - y] = 0;
+                const uint32_t k = (uint32_t)zero_col - y;
+                if (k == 0) v[0] = 0; else if (k == 1) v[1] = 0; else if (k == 2) v[2] = 0; else v[3] = 0;
                 row[zero_col] = 0;
             }
 #pragma unroll
@@ -126,31 +263,197 @@ __device__ __forceinline__ void row_scan_wide(uint32_t *__restrict__ row, uint32
     }
 }
 
-// Row maxima after k_apply2: workgroups 0, 1, 2 take rows a, b, Z (always re-scanned; (a,b) is
-// retired on the way: no (a,b) survives the merge, F2), the others the queued rows -- k_apply2 queues
-// a, b and Z too, those entries are skipped.  Everything a workgroup needs before its row is read
-// in one round trip (the pair, the queue length, its queue entry).
+// The rows to re-scan after a lean table update, as an indexable set: items 0, 1, 2 = rows scan_a,
+// scan_b, scan_z (NOROW before the first lean update), item 3 + j = the j-th flagged row in ascending
+// order.  Every workgroup builds the same view: the flag words and their exclusive popcount prefix
+// in LDS (1024 threads).  Returns the number of flagged rows.
+struct DirtyView {
+    uint32_t *words;  // [DBITS_WORDS]
+    uint32_t *pref;   // [DBITS_WORDS + 1]
+};
+__device__ __forceinline__ uint32_t dirty_view_build(const uint32_t *__restrict__ dbits, const DirtyView &D) {
+    __shared__ uint32_t s_wtot[16];
+    const uint32_t w0 = dbits[2 * threadIdx.x], w1 = dbits[2 * threadIdx.x + 1];
+    D.words[2 * threadIdx.x] = w0;
+    D.words[2 * threadIdx.x + 1] = w1;
+    const uint32_t c0 = (uint32_t)__popc(w0), c = c0 + (uint32_t)__popc(w1);
+    const uint32_t inc = wave_iscan_add(c);
+    if (lane_id() == 63) s_wtot[wave_id()] = inc;
+    __syncthreads();
+    uint32_t off = inc - c, tot = 0;
+    for (int v = 0; v < 16; v++) {
+        const uint32_t x = s_wtot[v];
+        if (v < wave_id()) off += x;
+        tot += x;
+    }
+    D.pref[2 * threadIdx.x] = off;
+    D.pref[2 * threadIdx.x + 1] = off + c0;
+    if (threadIdx.x == 0) D.pref[DBITS_WORDS] = tot;
+    __syncthreads();
+    return tot;
+}
+__device__ __forceinline__ uint32_t dirty_view_row(const DirtyView &D, uint32_t j) {  // j < number of flagged rows
+    uint32_t lo = 0, hi = DBITS_WORDS;  // the word w with pref[w] <= j < pref[w + 1]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (D.pref[mid] <= j) lo = mid; else hi = mid;
+    }
+    uint32_t m = D.words[lo];
+    for (uint32_t k = j - D.pref[lo]; k > 0; k--) m &= m - 1u;
+    return lo * 32 + (uint32_t)__ffs((int)m) - 1u;
+}
+
+// a row maximum on its way to the deciding workgroup: two 8-byte words {tag, value}, written and
+// polled with agent-scope relaxed accesses (the tag never repeats: a launch counter)
+typedef unsigned long long __attribute__((address_space(1))) gu64;
+__device__ __forceinline__ void granule_put(unsigned long long *p, uint32_t tag, uint32_t v) {
+    __hip_atomic_store((gu64 *)p, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool granule_get(unsigned long long *p, uint32_t tag, uint32_t &v) {
+    for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
+        const unsigned long long g = __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(g >> 32) == tag) {
+            v = (uint32_t)g;
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// Re-scan the rows in the set (items i = first, first + step, ...); publish == true hands every
+// result to the deciding workgroup as well.
+__device__ __forceinline__ void lean_scan_rows(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax,
+                                               uint32_t ncols, const uint32_t sa, const uint32_t sb, const uint32_t sz,
+                                               const DirtyView &D, uint32_t n_items, uint32_t first, uint32_t step,
+                                               unsigned long long *res, uint32_t tag, bool publish,
+                                               unsigned long long *s_red) {
+    for (uint32_t i = first; i < n_items; i += step) {
+        const uint32_t x = i == 0 ? sa : (i == 1 ? sb : (i == 2 ? sz : dirty_view_row(D, i - 3)));
+        uint32_t m = 0, arg = 0;
+        if (x != NOROW) row_scan_wide(mat + (size_t)x * stride, ncols, x == sa ? (int)sb : -1, s_red, m, arg);
+        if (threadIdx.x == 0) {
+            if (x != NOROW) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+            if (publish) {
+                granule_put(res + 2 * (size_t)i, tag, m);
+                granule_put(res + 2 * (size_t)i + 1, tag, arg);
+            }
+        }
+    }
+}
+
+// Row maxima alone (no selection): before a general k_select that follows a lean table update, and
+// when training ends.
 __global__ void __launch_bounds__(1024)
 k_rowmax_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
-              uint32_t Z, const uint32_t *__restrict__ dirty_list, const uint32_t *__restrict__ dirty_n) {
+              uint32_t ncols, const uint32_t *__restrict__ dbits) {
     __shared__ unsigned long long s_red[32];
+    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     const uint32_t status = st->status, defer = st->defer;
-    const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b;
-    const uint32_t nd = *dirty_n;
-    uint32_t q = blockIdx.x >= 3 ? dirty_list[blockIdx.x - 3] : 0u;  // (the list has room for every row: always readable)
+    const uint32_t sa = st->scan_a, sb = st->scan_b, sz = st->scan_z;
+    const DirtyView D{s_words, s_pref};
+    const uint32_t nd = dirty_view_build(dbits, D);
     if (status || defer) return;
-    for (uint32_t i = blockIdx.x; i < 3 + nd; i += gridDim.x) {
-        uint32_t x;
-        if (i < 3) {
-            x = i == 0 ? a : (i == 1 ? b : Z);
-            if (i == 1 && b == a) continue;
-        } else {
-            x = (i == blockIdx.x) ? q : dirty_list[i - 3];
-            if (x == a || x == b || x == Z) continue;
+    lean_scan_rows(mat, stride, rowmax, ncols, sa, sb, sz, D, 3 + nd, blockIdx.x, gridDim.x, nullptr, 0u, false, s_red);
+}
+
+// K2 of a lean iteration with the index live, fused with the row maxima the previous table update
+// left to do.  ncols = vcur = the ids in use (the previous merge's new token included).
+__global__ void __launch_bounds__(1024)
+k_rowsel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, DevState *st,
+              SlotRefH ref, CandArgs C, const uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res,
+              uint32_t tag) {
+    __shared__ unsigned long long s_red[32];
+    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ uint32_t s_bits[2048];
+    __shared__ uint32_t s_exrow[LEAN_EX_CAP], s_exm[LEAN_EX_CAP], s_exarg[LEAN_EX_CAP];
+    __shared__ uint32_t s_fail;
+    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
+    const uint32_t sa = st->scan_a, sb = st->scan_b, sz = st->scan_z;
+    const DirtyView D{s_words, s_pref};
+    if (blockIdx.x != 0) {
+        const uint32_t nd = dirty_view_build(dbits, D);
+        if (status || defer) return;
+        lean_scan_rows(mat, stride, rowmax, vcur, sa, sb, sz, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag, true,
+                       s_red);
+        return;
+    }
+    // ---- the deciding workgroup ---------------------------------------------------------------
+    uint32_t rm[SEL_RPT];
+    select_load(rowmax, vcur, rm);  // (in flight while the set of rows to leave out is put together)
+    for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;
+    if (threadIdx.x == 0) s_fail = 0;
+    const uint32_t nd = dirty_view_build(dbits, D);
+    if (status || defer) return;
+    const uint32_t n_items = 3 + nd;
+    if (n_items > LEAN_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
+        if (threadIdx.x == 0) {
+            st->found = 0;
+            st->defer = 2;
         }
+        return;
+    }
+    if (threadIdx.x < n_items) {
+        const uint32_t i = threadIdx.x;
+        const uint32_t x = i == 0 ? sa : (i == 1 ? sb : (i == 2 ? sz : dirty_view_row(D, i - 3)));
         uint32_t m = 0, arg = 0;
-        row_scan_wide(mat + (size_t)x * stride, Z + 1, x == a ? (int)b : -1, s_red, m, arg);
-        if (threadIdx.x == 0) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+        const bool ok = granule_get(res + 2 * (size_t)i, tag, m) && granule_get(res + 2 * (size_t)i + 1, tag, arg);
+        if (!ok) s_fail = 1;
+        s_exrow[i] = x == NOROW ? 0u : x;
+        s_exm[i] = x == NOROW ? 0u : m;
+        s_exarg[i] = arg;
+    }
+    __syncthreads();
+    // s_words becomes the bitmap of rows whose entry in the row-maxima array is stale (only now: the
+    // searches above count the bits of the flagged rows inside a word)
+    if (threadIdx.x < 3) {
+        const uint32_t x = threadIdx.x == 0 ? sa : (threadIdx.x == 1 ? sb : sz);
+        if (x != NOROW) atomicOr(&s_words[x >> 5], 1u << (x & 31));
+    }
+    __syncthreads();
+    if (s_fail) {  // a row never arrived: never decide on a stale maximum
+        if (threadIdx.x == 0) atomicExch(&st->status, ST_LOOKBACK);
+        return;
+    }
+    uint32_t M, nt;
+    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{s_words, n_items, s_exrow, s_exm, s_exarg});
+    if (M == 0) {
+        if (threadIdx.x == 0) {
+            st->status = ST_EMPTY;
+            st->count = 0;
+            st->found = 0;
+            st->sel_tie = 0;
+        }
+        return;
+    }
+    uint32_t pi = 0;
+    unsigned long long pos = NOPOS;
+    bool decided = (nt == 1);
+    if (!decided && nt <= TIE_CAP && gap == 0) {
+        const unsigned long long key = tie_by_index(ref, C, s_tied, nt);
+        if (key != NOPOS) {
+            pi = (uint32_t)(key & 127u);
+            pos = key >> 7;
+            decided = true;
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
+        st->count = M;
+        st->ntied = nt;
+        st->firstpos = pos;
+        st->sel_tie = 0;
+        if (decided) {
+            st->a = s_tied[2 * pi];
+            st->b = s_tied[2 * pi + 1];
+            st->fin_a = s_tied[2 * pi];
+            st->fin_b = s_tied[2 * pi + 1];
+            st->found = 1;
+        } else {
+            st->found = 0;
+            st->defer = 2;
+        }
     }
 }
 

@@ -93,27 +93,46 @@ __device__ __forceinline__ uint64_t view_tile(const SlotRefH &) { return TILE2; 
 // several columns (ROWARG_MULTI) is scanned.
 // select_core leaves the result in LDS / registers (every thread gets M and the number of tied
 // pairs, TIE_CAP + 1 = too many to list; the pairs are in s_tied); select_body also writes it to st.
+constexpr int SEL_RPT = 32;  // 32 x 1024 row maxima in registers; rows beyond (vocab > 32768) are read twice
+// A lean iteration re-scans a few rows in the same launch that selects (k_rowsel_lean, k_lean.hip):
+// those rows are EXCLUDED from the row-maxima array (a bitmap in LDS) and come in as extra
+// (row, maximum, column) items instead.
+struct SelExtra {
+    const uint32_t *excl;  // LDS bitmap of excluded rows, or nullptr
+    uint32_t n;            // extra items ...
+    const uint32_t *row, *m, *arg;  // ... in LDS
+};
+// issue the loads of this thread's share of the row maxima (rowmax[2x] = maximum of row x,
+// rowmax[2x + 1] = the column that attains it, same cache line)
+__device__ __forceinline__ void select_load(const uint32_t *__restrict__ rowmax, uint32_t vcur, uint32_t (&rm)[SEL_RPT]) {
+    const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
+#pragma unroll
+    for (int i = 0; i < SEL_RPT; i++) {
+        const uint32_t x = threadIdx.x + 1024u * i;
+        rm[i] = (x < vcur) ? rowma[x].x : 0u;
+    }
+}
 __device__ __forceinline__ void select_core(const uint32_t *__restrict__ rowmax,
                                             const uint32_t *__restrict__ mat, uint32_t stride,
                                             uint32_t vcur, int32_t *s_tied, uint32_t *s_bits, uint32_t &M_out,
-                                            uint32_t &nt_out) {
+                                            uint32_t &nt_out, uint32_t (&rm)[SEL_RPT], const SelExtra &E) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
-    // rowmax[2x] = maximum of row x, rowmax[2x + 1] = the column that attains it (same cache line);
     // every thread keeps its share in registers: the second look (which rows attain the
     // maximum) needs no second trip to memory
     const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
-    constexpr int RPT = 32;  // 32 x 1024 rows in registers; rows beyond (vocab > 32768) are read twice
-    uint32_t rm[RPT];
+    constexpr int RPT = SEL_RPT;
+    auto excluded = [&](uint32_t x) -> bool { return E.excl && ((E.excl[x >> 5] >> (x & 31)) & 1u); };
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
-        const uint32_t x = threadIdx.x + 1024u * i;
-        rm[i] = (x < vcur) ? rowma[x].x : 0u;
+        if (excluded(threadIdx.x + 1024u * i)) rm[i] = 0u;
         m = max(m, rm[i]);
     }
-    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) m = max(m, rowma[x].x);
+    for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024)
+        if (!excluded(x)) m = max(m, rowma[x].x);
+    for (uint32_t i = threadIdx.x; i < E.n; i += 1024) m = max(m, E.m[i]);
     m = wave_max_u32(m);
     if (lane_id() == 0) s_red[wave_id()] = m;
     if (threadIdx.x == 0) {
@@ -149,9 +168,12 @@ __device__ __forceinline__ void select_core(const uint32_t *__restrict__ rowmax,
         if (rm[i] == M)  // (M > 0, rows beyond vcur hold 0; the column sits in the cache line just read)
             row_at_max(threadIdx.x + 1024u * i, rowma[threadIdx.x + 1024u * i].y);
     for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024) {
+        if (excluded(x)) continue;
         const uint2 v = rowma[x];
         if (v.x == M) row_at_max(x, v.y);
     }
+    for (uint32_t i = threadIdx.x; i < E.n; i += 1024)
+        if (E.m[i] == M) row_at_max(E.row[i], E.arg[i]);
     __syncthreads();
     const uint32_t nrows = s_nrows;
     if (nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
@@ -178,7 +200,9 @@ __device__ __forceinline__ void select_body(const uint32_t *__restrict__ rowmax,
                                             const uint32_t *__restrict__ mat, uint32_t stride,
                                             uint32_t vcur, DevState *st, int32_t *s_tied, uint32_t *s_bits) {
     uint32_t M, nt;
-    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt);
+    uint32_t rm[SEL_RPT];
+    select_load(rowmax, vcur, rm);
+    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{nullptr, 0u, nullptr, nullptr, nullptr});
     if (M == 0) {
         if (threadIdx.x == 0) {
             st->status = ST_EMPTY;
@@ -567,7 +591,10 @@ k_select_lean(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ 
     }
     for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;
     uint32_t M, nt;
-    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt);  // (its barriers publish s_state too)
+    uint32_t rm[SEL_RPT];
+    select_load(rowmax, vcur, rm);
+    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm,
+                SelExtra{nullptr, 0u, nullptr, nullptr, nullptr});  // (its barriers publish s_state too)
     if (s_state[0] || s_state[1]) return;
     if (M == 0) {
         if (threadIdx.x == 0) {

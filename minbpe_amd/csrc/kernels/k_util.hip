@@ -85,6 +85,7 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->ncand = 0;
     st->gap = 0;
     st->defer = 0;
+    st->scan_a = st->scan_b = st->scan_z = 0xFFFFFFFFu;
 }
 
 }  // namespace bpe
