@@ -15,7 +15,7 @@
 //                    building one) and rewrites them (merge_ab_wave, k_slots2.hip; delta format B)
 //   k_apply_lean     folds the delta into the pair table, one token per thread, every load in
 //                    flight at once, no returning atomic: a row is flagged for re-scanning when the
-//                    column that attains its maximum is (or may be) the one that lost pairs
+//                    entry that lost pairs attained its maximum
 // What workgroup 0 cannot settle alone (more than TIE_CAP tied pairs, short slots about, a tied pair
 // the index does not lead to) and every pair with a == b is DEFERRED: the iteration reports
 // ST_DEFER, everything enqueued behind it is a no-op that only carries the stream length forward,
@@ -120,7 +120,11 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
         const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b, adj = st->adj;
         const uint32_t nrep = 1u << (vcap >> 24);
         const uint32_t vc = vcap & 0xFFFFFFu;
-        const uint2 rmx = reinterpret_cast<const uint2 *>(rowmax)[t];
+        // (t,a) as it stands: only this thread touches it in this launch ((b,a) also takes thread a's
+        // update, and row b is always re-scanned).  Loaded for every token, with everything else --
+        // a column walk, one 64-byte sector per token, instead of a dependent round trip later
+        const uint32_t rm_t = rowmax[2 * t];
+        const uint32_t old_ta = mat[(size_t)t * stride + a];
         uint32_t sl = 0, sr = 0;
         for (uint32_t r0 = 0; r0 < nrep; r0 += 16) {
             uint32_t x[16][2];
@@ -145,10 +149,8 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
             atomicSub(&mat[(size_t)t * stride + a], sl);
             atomicAdd(&mat[(size_t)t * stride + Z], sl);
             // Row t lost pairs in column a only and gained (t,Z) = sl <= what (t,a) lost: its maximum
-            // moves only if column a attains it.  rowarg says which column does -- or that several do.
-            // (rows a, b and Z are always re-scanned)
-            if (t != a && t != b && t != Z && (rmx.y == a || rmx.y == ROWARG_MULTI))
-                atomicOr(&dbits[t >> 5], 1u << (t & 31));
+            // moves only if (t,a) attained it (rows a, b and Z are always re-scanned)
+            if (t != a && t != b && t != Z && old_ta == rm_t) atomicOr(&dbits[t >> 5], 1u << (t & 31));
         }
         if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
         if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);

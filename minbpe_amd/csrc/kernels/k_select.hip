@@ -241,24 +241,39 @@ __device__ __forceinline__ unsigned long long slot_find_pair(const SlotRefH &ref
     const int lane = lane_id();
     // this slot's header and the next one's, issued together (the caller made sure no slot is
     // short or empty: st->gap == 0, so the word after the slot is the next slot's first)
+    // ... and the slot's words with them, speculatively from buffer 0 (where a slot lives unless an
+    // a == b pass moved it) and whatever its length: one round trip instead of two.  Every slot has
+    // TILE2 words of room, and the word after them is the next slot's room or the buffer's padding.
+    constexpr int SB = TILE2 / 256;  // the whole slot in one batch: 4 stripes of 256 words
+    const uint32_t *src = ref.b0 + (size_t)t * TILE2;
+    uint4 v[SB];
+    uint32_t nx[SB];
+#pragma unroll
+    for (int j = 0; j < SB; j++) {
+        const uint32_t q = j * 256 + lane * 4;
+        v[j] = *reinterpret_cast<const uint4 *>(src + q);
+        nx[j] = src[q + 4];
+    }
     const uint32_t m = ref.hdr[t].meta;
     const uint32_t after = (t + 1 < ref.T) ? ref.hdr[t + 1].w0 : INVALID_WORD;
     const uint32_t len = m & 0x7FFFFFFFu;
     if (len == 0) return NOPOS;
-    const uint32_t *src = ((m >> 31) ? ref.b1 : ref.b0) + (size_t)t * TILE2;
-    constexpr int SB = TILE2 / 256;  // the whole slot in one batch: 4 stripes of 256 words
-    for (uint32_t base = 0; base < len; base += SB * 256) {
-        uint4 v[SB];
-        uint32_t nx[SB];
+    if (m >> 31) {  // (uniform, rare) the slot lives in the other buffer: load again
+        src = ref.b1 + (size_t)t * TILE2;
 #pragma unroll
         for (int j = 0; j < SB; j++) {
-            const uint32_t q = base + j * 256 + lane * 4;
-            v[j] = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD);
-            nx[j] = INVALID_WORD;
-            if (q < len) {
-                v[j] = *reinterpret_cast<const uint4 *>(src + q);
-                if (q + 4 < len) nx[j] = src[q + 4];
-            }
+            const uint32_t q = j * 256 + lane * 4;
+            v[j] = *reinterpret_cast<const uint4 *>(src + q);
+            nx[j] = src[q + 4];
+        }
+    }
+    {
+        const uint32_t base = 0;
+#pragma unroll
+        for (int j = 0; j < SB; j++) {
+            const uint32_t q = j * 256 + lane * 4;
+            if (q >= len) v[j] = make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, INVALID_WORD);
+            if (q + 4 >= len) nx[j] = INVALID_WORD;
         }
 #pragma unroll
         for (int j = 0; j < SB; j++) {
