@@ -83,7 +83,7 @@ struct bpe_ctx {
     uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 24576;               // option "lean_count"
-    int lean_grid = 16384;                    // option "lean_grid": most workgroups of a lean merge pass
+    int lean_grid = 1024;                     // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     uint32_t *d_dbits = nullptr;              // [DBITS_WORDS] rows a lean table update flagged for re-scanning
@@ -916,7 +916,9 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (newid + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_apply_lean, dim3(na + 8), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
+    // (+ workgroups that commit the staged headers: a mask word or two per thread)
+    const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
+    hipLaunchKernelGGL(k_apply_lean, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
                        c->d_rowmax, c->d_st, newid, c->d_dbits, c->par, rec, iter, na, c->d_hdr2[c->mq], c->d_stage,
                        c->d_removed, c->d_smask, nwords);
     LAUNCHCHK(c, "k_apply_lean");

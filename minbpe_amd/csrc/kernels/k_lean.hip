@@ -66,38 +66,34 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
             merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
         return;
     }
-    // A workgroup takes four 32-slot words of the candidate mask per step -- the three filter words
-    // of the pair AND-ed, plus the slots an a == b pass rewrote since the index was built (wave-
-    // uniform addresses) -- and deals the candidates to its four waves in turn: two neighbouring
-    // slots that share a site (both are candidates) go to different waves.  With a few hundred
-    // candidates among ~200 k slots almost every workgroup finds nothing.
+    // Wave g of the (resident) grid owns the 32-slot words g, g + waves, g + 2 waves, ... of the
+    // candidate mask: lane k loads the k-th of them -- the three filter words of the pair AND-ed,
+    // plus the slots an a == b pass rewrote since the index was built -- so every mask word of the
+    // pass is in flight in ONE round trip, whatever the stream length (64 words per wave: 8 M
+    // slots at 1024 workgroups).  With a few hundred candidates among ~200 k slots almost every
+    // wave finds nothing; the ones that do are spread over the whole grid.
     const uint32_t nwords = (Tl + 31) / 32;
+    const uint32_t gw = blockIdx.x * (MT / 64) + wave_id(), nw = gridDim.x * (MT / 64);
     uint32_t h1, h2, h3;
     pair_hash(a, b, h1, h2, h3);
-    constexpr uint32_t WPB = MT / 64;
-    for (uint32_t w0 = blockIdx.x * WPB; w0 < nwords; w0 += gridDim.x * WPB) {
-        uint32_t mk[WPB];
-#pragma unroll
-        for (uint32_t j = 0; j < WPB; j++) {
-            const uint32_t w = w0 + j;
-            uint32_t m = 0;
-            if (w < nwords) {
-                m = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
-                     A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
-                const uint32_t left = Tl - w * 32;
-                if (left < 32) m &= (1u << left) - 1u;
-            }
-            mk[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    for (uint32_t wbase = gw; wbase < nwords; wbase += 64 * nw) {
+        const uint32_t w = wbase + (uint32_t)lane_id() * nw;
+        uint32_t mk = 0;
+        if (w < nwords) {
+            mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
+                  A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
+            const uint32_t left = Tl - w * 32;
+            if (left < 32) mk &= (1u << left) - 1u;
         }
-        uint32_t k = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < WPB; j++) {
-            uint32_t mm = mk[j];
+        unsigned long long bal = __ballot(mk != 0);
+        while (bal) {
+            const int lw = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mk, lw);
             while (mm) {
-                const uint32_t t = (w0 + j) * 32 + (uint32_t)__ffs((int)mm) - 1u;
+                const uint32_t t = (wbase + (uint32_t)lw * nw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
                 mm &= mm - 1u;
-                if ((k++ & (WPB - 1)) == (uint32_t)wave_id())
-                    merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+                merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
             }
         }
     }
