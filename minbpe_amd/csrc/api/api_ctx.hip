@@ -83,7 +83,7 @@ struct bpe_ctx {
     uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 24576;               // option "lean_count"
-    int lean_grid = 1024;                     // option "lean_grid": most workgroups of a lean merge pass
+    int lean_grid = 256;                      // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     uint32_t *d_dbits = nullptr;              // [DBITS_WORDS] rows a lean table update flagged for re-scanning
@@ -902,15 +902,16 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
     const uint32_t nwords = (T + 31) / 32;
-    // one 32-slot word of the candidate mask (index) or one slot (no index) per wave and step
+    // a resident grid: one 1024-thread workgroup per CU at most; a workgroup takes at least 16 mask
+    // words (index) or 16 slots (no index)
     const uint32_t units = use_index ? nwords : T;
-    const unsigned g = std::max(1u, std::min((units + MT / 64 - 1) / (MT / 64), (unsigned)c->lean_grid));
+    const unsigned g = std::max(1u, std::min((units + 15) / 16, (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->idx_live)
-        hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(MT), 0, c->stream, A, c->d_idx_dirty,
+        hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
                            use_index ? 1u : 0u, c->d_dbits);
     else
-        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u,
+        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(LEAN_MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u,
                            c->d_dbits);
     LAUNCHCHK(c, "k_merge_ab_lean");
     TRY(prof_end(c));

@@ -39,15 +39,25 @@ constexpr int DBITS_WORDS = 2048;     // one bit per row (vocab <= 65536)
 constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one k_rowsel_lean launch hands to its deciding workgroup
 
 // ---------------------------------------------------------------------------
-// merge pass.  use_index == 0: no index (small streams) -- every live slot is visited
+// merge pass.  use_index == 0: no index (small streams) -- every live slot is visited.
+// One 1024-thread workgroup per CU (sixteen waves = sixteen slots in flight).  A workgroup owns a
+// contiguous range of the candidate mask -- the three filter words of the pair AND-ed per 32 slots,
+// plus the slots an a == b pass rewrote since the index was built; thread k loads word k, all in one
+// round trip -- compacts its candidates into a list in LDS and deals them to its waves one by one.
+// (Measured: letting every wave work through the candidates of its own mask words costs 2x in the
+// pass's duration -- one wave in a few hundred draws five or six slots and everybody waits for it.)
+constexpr int LEAN_MT = 1024;
+constexpr uint32_t LEAN_SUB = 128;  // mask words per round of a workgroup: at most 4096 candidates listed
 template <bool INDEXED>
-__global__ void __launch_bounds__(MT, 4)
+__global__ void __launch_bounds__(LEAN_MT)
 k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[LEAN_MT / 64][TILE2];
+    __shared__ uint32_t s_list[LEAN_SUB * 32];
+    __shared__ uint32_t s_tot[2];
     DevState *st = A.st;
     // (the rows flagged by the last table update were re-scanned by the launch before this one)
     if (blockIdx.x == 0)
-        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += MT) dbits[i] = 0;
+        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
     if (st->status || st->defer) return;
     if (!st->found) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
@@ -59,43 +69,45 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
         return;
     }
     const uint32_t Tl = min(A.T, st->tlive);
+    constexpr uint32_t NWV = LEAN_MT / 64;
     // short slots about: adjacency in slot numbers means nothing, visit everything (k_index.hip)
     if (!use_index || st->gap != 0) {
-        const uint32_t nw = gridDim.x * (MT / 64);
-        for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < Tl; t += nw)
+        const uint32_t nw = gridDim.x * NWV;
+        for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw)
             merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
         return;
     }
-    // Wave g of the (resident) grid owns the 32-slot words g, g + waves, g + 2 waves, ... of the
-    // candidate mask: lane k loads the k-th of them -- the three filter words of the pair AND-ed,
-    // plus the slots an a == b pass rewrote since the index was built -- so every mask word of the
-    // pass is in flight in ONE round trip, whatever the stream length (64 words per wave: 8 M
-    // slots at 1024 workgroups).  With a few hundred candidates among ~200 k slots almost every
-    // wave finds nothing; the ones that do are spread over the whole grid.
     const uint32_t nwords = (Tl + 31) / 32;
-    const uint32_t gw = blockIdx.x * (MT / 64) + wave_id(), nw = gridDim.x * (MT / 64);
+    const uint32_t per = (nwords + gridDim.x - 1) / gridDim.x;  // mask words of one workgroup
+    const uint32_t wlo = blockIdx.x * per, whi = min(nwords, wlo + per);
     uint32_t h1, h2, h3;
     pair_hash(a, b, h1, h2, h3);
-    for (uint32_t wbase = gw; wbase < nwords; wbase += 64 * nw) {
-        const uint32_t w = wbase + (uint32_t)lane_id() * nw;
+    for (uint32_t sub = wlo; sub < whi; sub += LEAN_SUB) {
         uint32_t mk = 0;
-        if (w < nwords) {
+        const uint32_t w = sub + threadIdx.x;
+        if (threadIdx.x < LEAN_SUB && w < whi) {
             mk = (A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
                   A.idx[(size_t)h3 * A.istride + w]) | idx_dirty[w];
             const uint32_t left = Tl - w * 32;
             if (left < 32) mk &= (1u << left) - 1u;
         }
-        unsigned long long bal = __ballot(mk != 0);
-        while (bal) {
-            const int lw = __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)mk, lw);
-            while (mm) {
-                const uint32_t t = (wbase + (uint32_t)lw * nw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
-                mm &= mm - 1u;
-                merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+        // (the words live in waves 0 and 1: two wave scans, no more)
+        const uint32_t c = (uint32_t)__popc(mk);
+        const uint32_t inc = wave_iscan_add(c);
+        if (threadIdx.x < 128 && lane_id() == 63) s_tot[wave_id()] = inc;
+        __syncthreads();
+        const uint32_t n = s_tot[0] + s_tot[1];
+        if (threadIdx.x < LEAN_SUB) {
+            uint32_t o = inc - c + (wave_id() == 1 ? s_tot[0] : 0u);
+            while (mk) {
+                s_list[o++] = w * 32 + (uint32_t)__ffs((int)mk) - 1u;
+                mk &= mk - 1u;
             }
         }
+        __syncthreads();
+        for (uint32_t i = wave_id(); i < n; i += NWV)
+            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, s_list[i], A, a, b);
+        __syncthreads();  // (the list is rewritten by the next round)
     }
 }
 
