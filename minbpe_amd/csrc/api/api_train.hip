@@ -133,8 +133,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             }
             bool sparse = false;
             if (c->slotted && c->slot2) TRY(plan_pass2(c, &sparse));
+            // lean iterations (k_lean.hip): every sparse pass whose pair is rare enough, and every pass of a
+            // stream too small for the index (a few thousand slots: visiting them all costs nothing)
             const bool lean = c->slotted && c->slot2 && c->lean && i != force_general &&
-                              (lean_on || c->lean == 2 || (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count));
+                              (lean_on || c->lean == 2 ||
+                               (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count &&
+                                (sparse || c->slot_T <= 16 * SPARSE_GRID)));
             if (lean) {
                 lean_on = true;
                 if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax) {

@@ -81,6 +81,35 @@ def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golde
     _check_digests(engine.train(g["merges"]), g)
 
 
+# (sparse, lean): the default engine; every a != b pass through the index (k_rowsel_lean breaks the ties, or
+# defers them); the general path alone, without and with the index
+FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0)]
+
+
+@pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
+@pytest.mark.parametrize("name", ["full16r", "full12b"])
+def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_golden, name, sparse, lean):
+    """The headline's whole vocabulary range (vocab 32000 = 31,744 merges) on inputs the oracle finishes in
+    half an hour: 16 MB with the GPT-4 split (regex.py:49-63) and 12 MB as one stream (basic.py:31-42).
+    Counts fall to 2-3 here: hundreds of pairs tied at the maximum (more than TIE_CAP), rows with several
+    maximal columns, the vocabulary beyond 8448 -- every select / table path the 1 GB run takes late."""
+    g = big_golden[name]
+    data = native.synth_text(g["bytes"], g["seed"])
+    assert hashlib.sha256(data).hexdigest() == g["data_sha256"]
+    offs = None
+    if g["chunked"]:
+        offs = native.split_offsets(data, 4)
+        assert hashlib.sha256(np.ascontiguousarray(offs, dtype=np.uint64).tobytes()).hexdigest() == g["offsets_sha256"]
+    engine.set_option("sparse", sparse)
+    engine.set_option("lean", lean)
+    try:
+        engine.load_bytes(data, offs)
+        _check_digests(engine.train(g["merges"]), g)
+    finally:
+        engine.set_option("sparse", 1)
+        engine.set_option("lean", 1)
+
+
 def test_cross_mode_large_chunked(native, engine):
     """The literal reference loop (mode 0: clear, get_stats, arg-max, merge every iteration) and the
     default engine (pair table kept current by the merge pass) must agree merge for merge on a stream
