@@ -320,8 +320,8 @@ class Engine:
                             C.byref(done))
         d = done.value
         self.last_train = dict(
-            pairs=[(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(d)],
-            counts=[int(x) for x in counts[:d]], lens=[int(x) for x in lens[:d]],
+            pairs=list(map(tuple, pairs[:2 * d].reshape(d, 2).tolist())),
+            counts=counts[:d].tolist(), lens=lens[:d].tolist(),
             iter_ms=None if ms is None else ms[:d].copy(), n_done=d)
         self._check(rc)
         return self.last_train
@@ -394,8 +394,8 @@ class Engine:
         rc = _lib.bpe_dp_train(self._h, num_merges, _ptr(pairs), _ptr(counts), _ptr(lens), C.byref(done))
         d = done.value
         self.last_train = dict(
-            pairs=[(int(pairs[2 * i]), int(pairs[2 * i + 1])) for i in range(d)],
-            counts=[int(x) for x in counts[:d]], lens=[int(x) for x in lens[:d]], iter_ms=None, n_done=d)
+            pairs=list(map(tuple, pairs[:2 * d].reshape(d, 2).tolist())),
+            counts=counts[:d].tolist(), lens=lens[:d].tolist(), iter_ms=None, n_done=d)
         self._check(rc)
         return self.last_train
 

@@ -8,6 +8,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
     if (!c->have_bytes) return fail(c, BPE_E_STATE, "bpe_load_bytes first");
     if (c->dp_active) return fail(c, BPE_E_STATE, "bpe_dp_end first");
+    // BPE_TIMING=1: host wall time of the phases of this call on stderr (where does wall - device go?)
+    static const bool timing = getenv("BPE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_begin = now();
     if (n_done) *n_done = 0;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_table(c, 256u + (uint32_t)num_merges));
@@ -105,6 +109,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         return BPE_OK;
     };
 
+    auto t_loop = now();
     int i = 0;
     while (!stop) {
         // enqueue iteration i (if any is left), then look at the record `depth` back
@@ -195,7 +200,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     }
     if (!stop) TRY(flush_lean_rows(c, 256u + (uint32_t)done));
     c->rows_pending = false;
+    auto t_drain = now();
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto t_tail = now();
     if (c->slotted) {
         // leave the ids contiguous for whoever reads them next
         if (stop) {  // parity of the no-op iterations enqueued after the failing one
@@ -227,6 +234,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
     }
     TRY(prof_drain(c));
+    if (timing) {
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[bpe_train] %d merges: setup+enqueue of the first pass %.2f ms, loop %.2f ms, drain %.2f ms, "
+                        "re-pack + timers %.2f ms\n", done, ms(t_begin, t_loop), ms(t_loop, t_drain), ms(t_drain, t_tail),
+                ms(t_tail, now()));
+    }
     if (n_done) *n_done = done;
     return rc;
 }
