@@ -130,6 +130,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "lean_grid")) {
         if (value < 1 || value > 65535) return fail(c, BPE_E_ARG, "lean_grid must be 1..65535");
         c->lean_grid = (int)value;
+    } else if (!strcmp(name, "prof_stride")) {
+        if (value < 1 || value > 1024) return fail(c, BPE_E_ARG, "prof_stride must be 1..1024");
+        c->prof_stride = (int)value;
     } else if (!strcmp(name, "lean_select")) {
         c->lean_select = value != 0;
     } else if (!strcmp(name, "lean_scan")) {

@@ -12,6 +12,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     static const bool timing = getenv("BPE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_begin = now();
+    struct ProfIterReset {  // (whatever the exit path: the sampling of profiling events is this loop's business)
+        bpe_ctx *c;
+        ~ProfIterReset() { c->prof_iter = -1; }
+    } prof_iter_reset{c};
     if (n_done) *n_done = 0;
     HIPCHK(c, hipSetDevice(c->device));
     TRY(ensure_table(c, 256u + (uint32_t)num_merges));
@@ -115,6 +119,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         // enqueue iteration i (if any is left), then look at the record `depth` back
         if (i < num_merges) {
             c->vcur = 256u + (uint32_t)i;
+            c->prof_iter = i;
             bool full_rowmax = (i == 0);
             if (!delta && i > 0) {
                 TRY(clear_table(c));
@@ -198,6 +203,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         if (consumed >= num_merges) break;
     }
+    c->prof_iter = -1;
     if (!stop) TRY(flush_lean_rows(c, 256u + (uint32_t)done));
     c->rows_pending = false;
     auto t_drain = now();

@@ -33,6 +33,7 @@ struct ProfEv {
     int kind;
     hipEvent_t e0, e1;
     uint64_t bytes;
+    uint32_t weight;  // sampled iterations stand for this many
 };
 }  // namespace
 

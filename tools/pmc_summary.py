@@ -7,8 +7,11 @@ writes 4n): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2; WRI
 
 usage: tools/pmc_summary.py fetch.db write.db workload_name out.json [n_bytes_of_the_input]
 
-A "launch" of the merge pass is one training iteration = the a != b kernel (dense or sparse)
-plus the a == b kernel (a no-op unless the pair has a == b); bench.py times exactly that group.
+A "launch" of the merge pass is one training iteration = the a != b kernel (dense, sparse or lean)
+plus, in the general path, the a == b kernel (a no-op unless the pair has a == b); bench.py times
+exactly that group.  The number of iterations = launches of the table-update kernel (k_apply2 in the
+general path, k_apply_lean in lean iterations; one per iteration).  "all_kernels" = every kernel of
+the run, for the whole-iteration fraction.
 """
 import json
 import os
@@ -42,13 +45,18 @@ def main():
         calls = max(f.get(k, [0])[0], w.get(k, [0])[0])
         kernels[k] = {"calls": calls, "fetch_bytes_x2": 2.0 * f.get(k, [0, 0.0])[1], "write_bytes": w.get(k, [0, 0.0])[1]}
     merge = {k: v for k, v in kernels.items() if k.startswith("k_merge_")}
-    iters = max((v["calls"] for k, v in merge.items() if k.startswith("k_merge_aa")), default=0)
+    iters = sum(v["calls"] for k, v in kernels.items() if k.startswith(("k_apply2", "k_apply_lean", "k_apply_delta")))
+    if not iters:
+        iters = max((v["calls"] for k, v in merge.items() if k.startswith("k_merge_aa")), default=0)
     total = sum(v["fetch_bytes_x2"] + v["write_bytes"] for v in merge.values())
+    total_all = sum(v["fetch_bytes_x2"] + v["write_bytes"] for v in kernels.values())
     import bench
     out = {
         "workload": workload, "source_hash": bench.source_hash(),
         "launches": iters, "hbm_bytes_total": total,
         "hbm_bytes_per_launch": total / iters if iters else None,
+        "all_kernels_hbm_bytes_total": total_all,
+        "all_kernels_hbm_bytes_per_iteration": total_all / iters if iters else None,
         "merge_kernels": merge,
         "correction": "FETCH_SIZE x2 (gfx950, wide coalesced reads), WRITE_SIZE x1; counters are KiB",
         "calibration_k_widen": {**kernels.get("k_widen", {}), "expected": "reads n input bytes, writes 4n",
