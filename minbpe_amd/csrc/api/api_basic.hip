@@ -110,8 +110,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "rep_min")) {
         if (value < 0 || value > 8) return fail(c, BPE_E_ARG, "rep_min: 0..8");
         c->rep_min = value;
-    } else if (!strcmp(name, "dense_prefetch")) {
-        c->dense_prefetch = value != 0;
     } else if (!strcmp(name, "lds_delta")) {
         c->lds_delta = value != 0;
     } else if (!strcmp(name, "exp_no_delta")) {

@@ -73,7 +73,6 @@ struct bpe_ctx {
     int rep_max = 8;                          // log2 of the most delta-vector replicas a pass may use (experiments)
     int rep_min = 4;                          // option "rep_min": log2 of the fewest delta replicas a pass uses (a hot token's
                                               // atomics queue ~11 ns apiece per replica: 16 replicas beat 1 by ~2 us per late pass)
-    int dense_prefetch = 0;                   // option "dense_prefetch": early dense passes load a wave's next slot ahead (experiment)
     int lds_delta = 1;                        // option "lds_delta": a != b passes aggregate their delta in LDS while ids < LDSD_CAP
     int exp_no_delta = 0;                     // experiment: a != b passes skip the pair-table bookkeeping (wrong results)
     int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
@@ -822,12 +821,8 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
         c->n_sparse++;
     } else {
         const unsigned g = std::max((T + MT / 64 - 1) / (MT / 64), 1u);  // one wave per slot
-        const unsigned ge = std::min(g, (c->dense_prefetch ? 4u : 5u) * (unsigned)c->num_cus);  // ... or a resident grid
-        if (ldsd && A.idx && c->dense_prefetch)
-            hipLaunchKernelGGL((k_merge_ab_dense_early<true, true>), dim3(ge), dim3(MT), 0, c->stream, A);
-        else if (ldsd && c->dense_prefetch)
-            hipLaunchKernelGGL((k_merge_ab_dense_early<false, true>), dim3(ge), dim3(MT), 0, c->stream, A);
-        else if (ldsd && A.idx)
+        const unsigned ge = std::min(g, 5u * (unsigned)c->num_cus);       // ... or a resident grid
+        if (ldsd && A.idx)
             hipLaunchKernelGGL(k_merge_ab_dense_early<true>, dim3(ge), dim3(MT), 0, c->stream, A);
         else if (ldsd)
             hipLaunchKernelGGL(k_merge_ab_dense_early<false>, dim3(ge), dim3(MT), 0, c->stream, A);

@@ -143,23 +143,9 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int srclane) {
 // VGPRs; the early dense passes, which run before the index exists, use the variant without).
 // LDSD: every id is below LDSD_CAP and the delta goes into the workgroup's LDS tables `sd`
 // (SL[LDSD_CAP] | SR[LDSD_CAP] | adj | removed), flushed by the kernel when its slots are done.
-// The loads of step (1) below, as a function: a striding wave issues them for its NEXT slot before it
-// works on the current one (PRE).  pre[0..MJ) = the slot's words, pre[MJ] = this lane's header piece.
-__device__ __forceinline__ void merge_ab_load(const AbArgs &A, const uint32_t t, uint4 *pre) {
-    const int lane = lane_id();
-    const uint32_t *src = A.b0 + (size_t)t * TILE2;
-#pragma unroll
-    for (int j = 0; j < MJ; j++) pre[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
-    uint4 hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
-                          : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
-    const long long hi = 2ll * (long long)t - 2 + lane;
-    if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
-    pre[MJ] = hv;
-}
-template <bool SPARSE, bool INDEXED, bool LDSD, bool PRE = false>
+template <bool SPARSE, bool INDEXED, bool LDSD>
 __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t,
-                                              const AbArgs &A, const uint32_t a, const uint32_t b,
-                                              const uint4 *pre = nullptr) {
+                                              const AbArgs &A, const uint32_t a, const uint32_t b) {
     const int lane = lane_id();
     const uint32_t Tl = min(A.T, A.st->tlive);  // no slot from here on holds anything
     // ---- (1) every load that does not depend on another one -------------------------------
@@ -168,16 +154,11 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
     // the headers of slots t-1, t, t+1: six 16-byte pieces, lanes 0..5
     const uint32_t *src = A.b0 + (size_t)t * TILE2;
     uint4 rv[MJ];
-    uint4 hv;
-    if (PRE) {
 #pragma unroll
-        for (int j = 0; j < MJ; j++) rv[j] = pre[j];
-        hv = pre[MJ];
-    } else {
-#pragma unroll
-        for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
-        hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
-                        : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
+    uint4 hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
+                          : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    {
         const long long hi = 2ll * (long long)t - 2 + lane;
         if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
     }
@@ -464,10 +445,8 @@ k_merge_ab_dense(AbArgs A) {
 }
 // ... while every id is below LDSD_CAP: a resident grid (five workgroups per CU), wave w of the
 // grid takes slots w, w + waves, ...; the delta goes through LDS
-// PF: the wave issues the loads of its next slot before it works on the current one (20 more VGPRs:
-// four waves per SIMD instead of five, but loads stay in flight through the compaction).
-template <bool INDEXED, bool PF = false>
-__global__ void __launch_bounds__(MT, PF ? 4 : 5)
+template <bool INDEXED>
+__global__ void __launch_bounds__(MT, 5)
 k_merge_ab_dense_early(AbArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
     __shared__ uint32_t s_delta[2 * LDSD_CAP + 2];
@@ -482,23 +461,8 @@ k_merge_ab_dense_early(AbArgs A) {
     if (a == b) return;
     ldsd_clear(s_delta);
     const uint32_t nw = gridDim.x * (MT / 64);
-    if (PF) {
-        uint32_t t = blockIdx.x * (MT / 64) + wave_id();
-        uint4 cur[MJ + 1], nxt[MJ + 1];
-        if (t < A.T) merge_ab_load(A, t, cur);
-        for (; t < A.T; t += nw) {
-            const bool more = t + nw < A.T;  // (uniform)
-            if (more) merge_ab_load(A, t + nw, nxt);
-            merge_ab_wave<false, INDEXED, true, true>(s_out[wave_id()], s_delta, t, A, a, b, cur);
-            if (more) {
-#pragma unroll
-                for (int j = 0; j <= MJ; j++) cur[j] = nxt[j];
-            }
-        }
-    } else {
-        for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
-            merge_ab_wave<false, INDEXED, true>(s_out[wave_id()], s_delta, t, A, a, b);
-    }
+    for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
+        merge_ab_wave<false, INDEXED, true>(s_out[wave_id()], s_delta, t, A, a, b);
     ldsd_flush(s_delta, A);
 }
 
