@@ -120,6 +120,8 @@ int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
  *       bpe_dp_select(i)                     arg-max on the replica; local tie-break candidate
  *       [all-reduce MIN   tiekey  (int64 x 3)]   lowest (rank, position) wins the tie (F3/F5);
  *                                               word 2 = -(device status): any rank's failure stops all
+ *                                               (a status raised inside merge i travels with exchange i + 1:
+ *                                               the peers stop one merge after the failing rank)
  *       bpe_dp_merge(i)                      merge locally, produce the 4 delta vectors
  *       [all-reduce SUM   delta   (int32 x delta_count)]
  *       bpe_dp_apply(i)                      fold them into the replica
@@ -200,6 +202,9 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
 /* How the last bpe_train ran its merge passes: out[0] = dense passes (every slot of the stream
  * is visited), out[1] = sparse passes (only the slots the inverted slot index cannot rule out),
  * out[2] = builds of that index, out[3] = slots of the stream at the end. */
+/* Whether bpe_encode_batch runs its 16-bit path for this merge table (host logic, no GPU): every
+ * rank below 65535 and every token id -- merge_ids[r], or 256 + r when merge_ids is NULL -- below 65536. */
+int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M);
 int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
 /* The same, extended: out[4] = lean iterations among the passes above (three launches per merge, the
  * pair table updated at the merge sites themselves; option "lean"), out[5] = iterations a lean pass

@@ -92,6 +92,7 @@ _SIGS = {
     "bpe_decode_read": (C.c_int, [_p, _p, _u64, _p, _u64, _p]),
     "bpe_prof_reset": (C.c_int, [_p]),
     "bpe_prof_read": (C.c_int, [_p, _p, _p, _p]),
+    "bpe_encode_uses_16bit": (C.c_int, [_p, C.c_int32]),
     "bpe_train_stats": (C.c_int, [_p, _p]),
     "bpe_train_stats_ex": (C.c_int, [_p, _p, C.c_int]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),

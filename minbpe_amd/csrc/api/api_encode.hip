@@ -19,6 +19,14 @@ int upload_offsets(bpe_ctx *c, const uint64_t *chunk_offsets, uint64_t n_chunks)
 }
 }  // namespace
 
+// 16-bit token / rank columns in k_encode_short: every rank (0xFFFF = "none") and every token id must fit.
+// Without merge_ids token r is 256 + r: the last one, 255 + M, must still be below 65536.
+extern "C" int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M) {
+    bool narrow = merge_ids ? M < 65535 : M <= 65536 - 256;
+    for (int32_t r = 0; narrow && merge_ids && r < M; r++) narrow = merge_ids[r] >= 0 && merge_ids[r] < 65536;
+    return narrow ? 1 : 0;
+}
+
 extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
                                 const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
                                 uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
@@ -102,8 +110,7 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     // 4. one chunk per lane
     TRY(prof_begin(c, BPE_PROF_ENCODE, n));
     // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
-    bool narrow = M < 65535;
-    for (int32_t r = 0; narrow && merge_ids && r < M; r++) narrow = merge_ids[r] >= 0 && merge_ids[r] < 65536;
+    const bool narrow = bpe_encode_uses_16bit(merge_ids, M) != 0;
     if (narrow)
         hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,

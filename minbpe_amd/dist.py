@@ -5,8 +5,10 @@ One process per GPU.  Each rank owns a contiguous range of the regex chunks
 keeps a replica of the GLOBAL pair table.  Per merge the ranks exchange
   - three int64 words (MIN all-reduce): two decide the reference's first-occurrence
     tie-break across ranks -- lowest (rank, local position) wins (F3/F5) -- and the
-    third carries -(status), so that a failure on any rank stops every rank at the
-    same merge,
+    third carries -(status), so that a failure on any rank stops every rank: an empty
+    pair table (decided before the exchange) at the same merge on all of them, a device
+    failure raised INSIDE rank r's merge pass with the next merge's exchange -- the peers
+    have applied that merge and stop one later; every rank raises either way,
   - four dense vectors of length vocab (SUM all-reduce): how the table changes.
 The id streams and the table itself never cross xGMI.
 

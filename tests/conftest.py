@@ -15,8 +15,17 @@ def pytest_configure(config):
     # package at collection time: build first (hipcc cross-compiles without a GPU, ~30 s)
     if not (os.path.exists(os.path.join(ROOT, "minbpe_amd", "lib", "libbpe_hip.so"))
             and os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so"))):
-        import __graft_entry__
-        __graft_entry__.build()
+        try:
+            import __graft_entry__
+            __graft_entry__.build()
+        except Exception as e:  # no ROCm toolchain on this host: the oracle-only tests can still run
+            print(f"conftest: build() failed ({type(e).__name__}: {e}); tests that need libbpe_hip will error",
+                  file=sys.stderr)
+            try:
+                import oracle
+                oracle.build()
+            except Exception:
+                pass
     # GPU session: bring torch's HIP runtime up BEFORE libbpe_hip.so loads its own copy, the order
     # bench.py uses (torch ships a private libamdhip64 / libhsa-runtime64; initialising it second,
     # late in a long-lived process, was seen to fail with "No HIP GPUs are available").

@@ -49,3 +49,18 @@ def test_no_silent_cpu_fallback(native):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         native.Engine(0)
+
+
+def test_encode_16bit_path_boundary(native):
+    """bpe_encode_batch's 16-bit columns must hold every token id: without merge_ids token r is 256 + r
+    (api_encode.hip); the largest table that still fits has 65280 merges, not 65534."""
+    import ctypes as C
+    import numpy as np
+    lib = native._lib
+    assert lib.bpe_encode_uses_16bit(None, 65280) == 1
+    assert lib.bpe_encode_uses_16bit(None, 65281) == 0
+    assert lib.bpe_encode_uses_16bit(None, 65534) == 0
+    ids = np.arange(256, 256 + 1000, dtype=np.int32)
+    assert lib.bpe_encode_uses_16bit(ids.ctypes.data_as(C.c_void_p), 1000) == 1
+    ids[500] = 70000
+    assert lib.bpe_encode_uses_16bit(ids.ctypes.data_as(C.c_void_p), 1000) == 0
