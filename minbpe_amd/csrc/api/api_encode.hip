@@ -101,23 +101,52 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         TRY(dev_realloc(c, c->d_enc_len, (size_t)n_chunks));
         TRY(dev_realloc(c, c->d_enc_off, (size_t)n_chunks + 1));
         TRY(dev_realloc(c, c->d_enc_bsum, (size_t)nb + 1));
+        TRY(dev_realloc(c, c->d_enc_rep, (size_t)n_chunks));
         c->cap_enc_chunks = n_chunks;
+    }
+    // the chunk cache (k_encode.hip): room for twice the chunks, at most 2^24 slots (what does not fit
+    // is encoded on its own); chunk indices are 32-bit there
+    const bool cache = c->enc_cache && n_chunks < 0xFFFFFFFFull;
+    uint64_t tslots = 1024;
+    while (tslots < 2 * n_chunks && tslots < (1ull << 24)) tslots <<= 1;
+    if (cache) {
+        if (tslots > c->cap_enc_tab) {
+            TRY(dev_realloc(c, c->d_enc_tab_hash, (size_t)tslots));
+            TRY(dev_realloc(c, c->d_enc_tab_rep, (size_t)tslots));
+            c->cap_enc_tab = tslots;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_enc_tab_hash, 0, tslots * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_enc_tab_rep, 0xFF, tslots * sizeof(uint32_t), c->stream));
     }
     unsigned long long *d_nlong = c->d_scratch, *d_total = c->d_scratch + 1;
     uint32_t *d_min = (uint32_t *)(c->d_scratch + 2);
     HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, 2 * sizeof(unsigned long long), c->stream));
     const uint32_t mask = (uint32_t)(hs - 1);
-    // 4. one chunk per lane
+    // 4. one chunk per lane -- with the cache, one DISTINCT chunk per lane
     TRY(prof_begin(c, BPE_PROF_ENCODE, n));
     // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
     const bool narrow = bpe_encode_uses_16bit(merge_ids, M) != 0;
-    if (narrow)
-        hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
+    const unsigned gch = (unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS);
+    if (cache) {
+        hipLaunchKernelGGL(k_enc_hash, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_bytes,
+                           c->d_offsets, n_chunks, n, c->d_enc_tab_hash, c->d_enc_tab_rep, (uint32_t)(tslots - 1),
+                           c->d_enc_rep, c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull);
+        LAUNCHCHK(c, "k_enc_hash");
+        if (narrow)
+            hipLaunchKernelGGL(k_enc_owner<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes,
+                               c->d_offsets, n_chunks, n, c->d_enc_tab_rep, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals,
+                               mask, d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
+        else
+            hipLaunchKernelGGL(k_enc_owner<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes,
+                               c->d_offsets, n_chunks, n, c->d_enc_tab_rep, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals,
+                               mask, d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
+    } else if (narrow)
+        hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3(gch),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
                            c->d_enc_long, d_nlong);
     else
-        hipLaunchKernelGGL(k_encode_short<uint32_t>, dim3((unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)),
+        hipLaunchKernelGGL(k_encode_short<uint32_t>, dim3(gch),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
                            c->d_enc_long, d_nlong);
@@ -199,7 +228,13 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         }
         if (rc_long != BPE_OK) return rc_long;
     }
-    // 6. output offsets = exclusive scan of the per-chunk lengths
+    // 6. output offsets = exclusive scan of the per-chunk lengths (cached chunks take their owner's first)
+    TRY(prof_begin(c, BPE_PROF_ENCODE, 0));
+    if (cache) {
+        hipLaunchKernelGGL(k_enc_count, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_enc_rep,
+                           n_chunks, c->d_enc_len);
+        LAUNCHCHK(c, "k_enc_count");
+    }
     hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len,
                        n_chunks, c->d_enc_bsum);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
@@ -207,9 +242,14 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
                        c->d_enc_bsum, c->d_enc_off);
     LAUNCHCHK(c, "k_scan_*");
     // 7. placement and copy-out
-    hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
-                       c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+    if (cache)
+        hipLaunchKernelGGL(k_enc_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_enc_tmp, c->d_offsets, c->d_enc_rep, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+    else
+        hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
+                           c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
     LAUNCHCHK(c, "k_encode_place");
+    TRY(prof_end(c));
     unsigned long long total = 0;
     HIPCHK(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -297,13 +297,58 @@ def _train_pairs(native, n, nm, seed, kind):
     return oracle.train(data, nm, offs)[0]
 
 
+# cache: (enc_cache, enc_hash_bits) -- the chunk cache on (default) / off; on with the chunk hash cut to 3 bits,
+# so that thousands of different chunks share a slot and only the byte comparison keeps them apart
+ENC_VARIANTS = [(1, 0), (0, 0), (1, 3)]
+
+
+def _enc_variant(engine, cache, bits):
+    engine.set_option("enc_cache", cache)
+    engine.set_option("enc_hash_bits", bits)
+
+
+@pytest.mark.parametrize("cache,bits", ENC_VARIANTS)
 @pytest.mark.parametrize("kind", ["basic", "regex"])
-def test_encode_batch_vs_oracle(engine, native, kind):
+def test_encode_batch_vs_oracle(engine, native, kind, cache, bits):
     pairs = _train_pairs(native, 300_000, 600, 21, kind)
     text = native.synth_text(150_000, 22)
     data, offs = (text, None) if kind == "basic" else split_chunks(text.decode())
     exp_ids, exp_off = oracle.encode(pairs, data, offs)
-    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    _enc_variant(engine, cache, bits)
+    try:
+        ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    finally:
+        _enc_variant(engine, 1, 0)
+    assert np.array_equal(ids, exp_ids)
+    assert np.array_equal(out_off, exp_off)
+
+
+@pytest.mark.parametrize("cache,bits", ENC_VARIANTS)
+def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits):
+    """The cache's own cases: the same chunk at every byte alignment, chunks that differ in one byte (first,
+    last, beyond the 8th / 16th / 24th), prefixes of one another, lengths 1..32, many repeats."""
+    pairs = _train_pairs(native, 200_000, 500, 23, "regex")
+    base = native.synth_text(4000, 26)
+    rng = np.random.default_rng(5)
+    words = []
+    for rep in range(40):
+        for L in (1, 2, 3, 7, 8, 9, 15, 16, 17, 24, 25, 31, 32):
+            w = bytearray(base[100:100 + L])
+            words.append(bytes(w))
+            if rep % 3 == 1:
+                w[int(rng.integers(0, L))] ^= 1  # one byte off, somewhere
+                words.append(bytes(w))
+            if rep % 5 == 2:
+                words.append(bytes(w[:max(1, L - 1)]))  # a prefix
+        words.append(b"x" * (1 + rep % 7))  # shifts the alignment of everything that follows
+    data = b"".join(words)
+    offs = np.cumsum([0] + [len(w) for w in words[:-1]]).astype(np.uint64)
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    _enc_variant(engine, cache, bits)
+    try:
+        ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    finally:
+        _enc_variant(engine, 1, 0)
     assert np.array_equal(ids, exp_ids)
     assert np.array_equal(out_off, exp_off)
 
