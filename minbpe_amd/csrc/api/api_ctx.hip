@@ -118,8 +118,8 @@ struct bpe_ctx {
     int32_t *d_merge_ids = nullptr;
     uint64_t cap_enc_n = 0, cap_enc_chunks = 0, cap_ht = 0, cap_merge_ids = 0;
     // the chunk cache of bpe_encode_batch (k_encode.hip): hash table + per chunk its slot, then its owner
-    unsigned long long *d_enc_tab_hash = nullptr;
-    uint32_t *d_enc_tab_rep = nullptr, *d_enc_rep = nullptr;
+    EncEntry *d_enc_tab = nullptr;
+    uint32_t *d_enc_rep = nullptr;  // per chunk: its slot
     uint64_t cap_enc_tab = 0;
     int enc_cache = 1;  // option "enc_cache": 0 = encode every chunk on its own
     int enc_hash_bits = 0;  // option "enc_hash_bits" (tests): keep only this many bits of the chunk hash (0 = all 64)

@@ -104,19 +104,21 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         TRY(dev_realloc(c, c->d_enc_rep, (size_t)n_chunks));
         c->cap_enc_chunks = n_chunks;
     }
-    // the chunk cache (k_encode.hip): room for twice the chunks, at most 2^24 slots (what does not fit
-    // is encoded on its own); chunk indices are 32-bit there
+    // the chunk cache (k_encode.hip): a slot per four chunks, 2^12 .. 2^22 slots of 32 bytes (the distinct
+    // chunks of a text are few; what does not fit is encoded on its own); chunk indices are 32-bit there
     const bool cache = c->enc_cache && n_chunks < 0xFFFFFFFFull;
-    uint64_t tslots = 1024;
-    while (tslots < 2 * n_chunks && tslots < (1ull << 24)) tslots <<= 1;
+    uint64_t tslots = 1ull << 12;
+    while (tslots < n_chunks / 4 && tslots < (1ull << 22)) tslots <<= 1;
     if (cache) {
         if (tslots > c->cap_enc_tab) {
-            TRY(dev_realloc(c, c->d_enc_tab_hash, (size_t)tslots));
-            TRY(dev_realloc(c, c->d_enc_tab_rep, (size_t)tslots));
+            TRY(dev_realloc(c, c->d_enc_tab, (size_t)tslots));
             c->cap_enc_tab = tslots;
         }
-        HIPCHK(c, hipMemsetAsync(c->d_enc_tab_hash, 0, tslots * sizeof(unsigned long long), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_enc_tab_rep, 0xFF, tslots * sizeof(uint32_t), c->stream));
+        // (key 0 = empty; rep all ones: the atomicMin of the hashed chunks starts from there)
+        HIPCHK(c, hipMemsetAsync(c->d_enc_tab, 0, tslots * sizeof(EncEntry), c->stream));
+        hipLaunchKernelGGL(k_enc_tab_init, dim3((unsigned)((tslots + 255) / 256)), dim3(256), 0, c->stream, c->d_enc_tab,
+                           tslots);
+        LAUNCHCHK(c, "k_enc_tab_init");
     }
     unsigned long long *d_nlong = c->d_scratch, *d_total = c->d_scratch + 1;
     uint32_t *d_min = (uint32_t *)(c->d_scratch + 2);
@@ -128,18 +130,23 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     const bool narrow = bpe_encode_uses_16bit(merge_ids, M) != 0;
     const unsigned gch = (unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS);
     if (cache) {
-        hipLaunchKernelGGL(k_enc_hash, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_bytes,
-                           c->d_offsets, n_chunks, n, c->d_enc_tab_hash, c->d_enc_tab_rep, (uint32_t)(tslots - 1),
-                           c->d_enc_rep, c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull);
-        LAUNCHCHK(c, "k_enc_hash");
-        if (narrow)
-            hipLaunchKernelGGL(k_enc_owner<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes,
-                               c->d_offsets, n_chunks, n, c->d_enc_tab_rep, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals,
-                               mask, d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
-        else
-            hipLaunchKernelGGL(k_enc_owner<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes,
-                               c->d_offsets, n_chunks, n, c->d_enc_tab_rep, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals,
-                               mask, d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
+        const unsigned long long keep = c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull;
+        const uint32_t tmask = (uint32_t)(tslots - 1);
+        if (narrow) {
+            hipLaunchKernelGGL(k_enc_pass1<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
+                               n_chunks, n, c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask,
+                               d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
+            hipLaunchKernelGGL(k_enc_pass2<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
+                               n_chunks, n, c->d_enc_tab, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
+                               c->d_enc_tmp, c->d_enc_len);
+        } else {
+            hipLaunchKernelGGL(k_enc_pass1<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
+                               n_chunks, n, c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask,
+                               d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
+            hipLaunchKernelGGL(k_enc_pass2<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
+                               n_chunks, n, c->d_enc_tab, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
+                               c->d_enc_tmp, c->d_enc_len);
+        }
     } else if (narrow)
         hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3(gch),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
@@ -231,8 +238,8 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     // 6. output offsets = exclusive scan of the per-chunk lengths (cached chunks take their owner's first)
     TRY(prof_begin(c, BPE_PROF_ENCODE, 0));
     if (cache) {
-        hipLaunchKernelGGL(k_enc_count, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_enc_rep,
-                           n_chunks, c->d_enc_len);
+        hipLaunchKernelGGL(k_enc_count, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_enc_tab,
+                           c->d_enc_rep, n_chunks, c->d_enc_len);
         LAUNCHCHK(c, "k_enc_count");
     }
     hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len,
@@ -244,7 +251,8 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     // 7. placement and copy-out
     if (cache)
         hipLaunchKernelGGL(k_enc_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_enc_tmp, c->d_offsets, c->d_enc_rep, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+                           c->d_enc_tmp, c->d_offsets, c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_off, n_chunks,
+                           c->d_enc_out);
     else
         hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);

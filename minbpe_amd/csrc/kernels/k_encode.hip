@@ -109,22 +109,31 @@ k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ o
 // ---------------------------------------------------------------------------
 // Encode with a chunk cache.  _encode_chunk is a pure function of the chunk's bytes, and under a
 // GPT-style split a text is a few hundred thousand distinct chunks repeated a hundred million
-// times: each DISTINCT short chunk is encoded once, by its first occurrence (its "owner"), and
-// every other occurrence copies the owner's tokens.  Exact whatever the input: equality of chunks is
-// decided by comparing their bytes, never by the hash alone, and a chunk the table has no room for
-// is simply its own owner.
-//   k_enc_hash   chunk -> slot of an open-addressing table keyed by a 64-bit hash of the bytes; the
-//                slot's representative = the lowest chunk index that hashed there (atomicMin)
-//   k_enc_owner  chunk == its slot's representative, or its bytes differ from the representative's
-//                (a hash collision), or it has no slot: owner, encoded here (one chunk per lane);
-//                else rep[c] = the representative
-//   k_enc_count  every other chunk takes its owner's token count; then the usual scan, and
-//   k_enc_place  copies the owner's tokens
+// times: each DISTINCT short chunk is encoded once, by one of its occurrences (its "owner"), and
+// every other occurrence copies the owner's tokens.  Exact whatever the input: two chunks are the
+// same only if their BYTES are -- a chunk of up to 7 bytes is its own 64-bit table key, a longer one
+// is keyed by a hash and compared byte for byte with the slot's owner -- and a chunk the table has
+// no room for is simply encoded on its own.
+//   k_enc_pass1  every chunk finds (or claims, compare-and-swap) its slot of an open-addressing
+//                table.  Up to 7 bytes: the thread whose claim succeeds is the owner and encodes on
+//                the spot (one chunk per lane, as k_encode_short).  8..32 bytes: the slot's owner is
+//                the lowest chunk index that hashed there (atomicMin), settled when the launch ends
+//   k_enc_pass2  8..32 bytes: the owner encodes; every other occurrence compares its bytes with
+//                the owner's (a different chunk behind the same hash: encoded on its own)
+//   k_enc_count  per chunk, the token count of its slot; then the usual scan, and
+//   k_enc_place  copies the tokens: the first four sit in the slot itself
 // Hot words: a slot is read before it is written (relaxed agent-scope loads: L2-served, past the
 // per-CU L1 that another CU's insert never refreshes), so a word that occurs five million times
 // costs a handful of atomics, not five million on one address.
 constexpr uint32_t ENC_NOSLOT = 0xFFFFFFFFu;
 constexpr uint32_t ENC_PROBES = 64;  // slots tried before a chunk goes uncached
+constexpr uint32_t ENC_KEYBYTES = 7;  // chunks up to this length are their own key
+struct __attribute__((aligned(32))) EncEntry {
+    unsigned long long key;  // 0 = empty | (0x80 | len) << 56 | the chunk's bytes | 0x40 << 56 | 56 bits of hash
+    uint32_t rep;            // the owner's chunk index
+    uint32_t ntok;           // its token count ...
+    uint32_t tok[4];         // ... and first four tokens (the rest: staging area, at the owner's byte offset)
+};
 
 // the chunk's bytes as four little-endian 64-bit words (zero beyond len), from aligned loads
 __device__ __forceinline__ void chunk_words(const uint8_t *__restrict__ bytes, uint64_t s0, uint32_t len,
@@ -153,52 +162,35 @@ __device__ __forceinline__ unsigned long long chunk_hash(const unsigned long lon
     }
     h *= 0xC4CEB9FE1A85EC53ull;
     h ^= h >> 29;
-    return h ? h : 1ull;  // 0 = empty slot
+    return h;
+}
+__device__ __forceinline__ uint32_t key_home(unsigned long long key, uint32_t tmask) {
+    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 36) & tmask;
 }
 
 typedef unsigned long long __attribute__((address_space(1))) enc_gu64;
 typedef uint32_t __attribute__((address_space(1))) enc_gu32;
 
-__global__ void __launch_bounds__(256)
-k_enc_hash(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
-           unsigned long long *__restrict__ tab_hash, uint32_t *__restrict__ tab_rep, uint32_t tmask,
-           uint32_t *__restrict__ slot_of, unsigned long long hash_keep) {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t s0 = off[c];
-    const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
-    const uint64_t len = e0 - s0;
-    if (len == 0 || len > ENC_LMAX) {  // (empty: nothing to encode; long: the stream-wide path)
-        slot_of[c] = ENC_NOSLOT;
-        return;
+// the owner's result goes into its slot (and, beyond four tokens, into the staging area)
+template <typename TT>
+__device__ __forceinline__ void enc_store(const TT *tok, uint32_t L, EncEntry *e, uint32_t *__restrict__ tmp, uint64_t s0,
+                                          uint32_t *__restrict__ outlen, uint64_t c) {
+    if (e) {
+        uint32_t t4[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) t4[i] = i < L ? (uint32_t)tok[i * ENC_THREADS] : 0u;
+        e->ntok = L;
+        *reinterpret_cast<uint4 *>(e->tok) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
     }
-    unsigned long long w[4];
-    chunk_words(bytes, s0, (uint32_t)len, w);
-    // (hash_keep: all ones -- or, in tests, a few bits only, so that different chunks collide and the
-    // byte comparison in k_enc_owner has to tell them apart)
-    const unsigned long long hsh = (chunk_hash(w, (uint32_t)len) & hash_keep) | 1ull;
-    uint32_t h = (uint32_t)(hsh >> 20) & tmask;
-    uint32_t slot = ENC_NOSLOT;
-    for (uint32_t probe = 0; probe < ENC_PROBES; probe++) {
-        unsigned long long cur = __hip_atomic_load((enc_gu64 *)&tab_hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0) cur = atomicCAS(&tab_hash[h], 0ull, hsh);
-        if (cur == 0 || cur == hsh) {
-            slot = h;
-            break;
-        }
-        h = (h + 1) & tmask;
-    }
-    slot_of[c] = slot;
-    if (slot != ENC_NOSLOT) {
-        const uint32_t cur = __hip_atomic_load((enc_gu32 *)&tab_rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)c < cur) atomicMin(&tab_rep[slot], (uint32_t)c);
-    }
+    if (!e || L > 4)
+        for (uint32_t i = 0; i < L; i++) tmp[s0 + i] = tok[i * ENC_THREADS];
+    outlen[c] = L;
 }
 
 template <typename TT>
 __global__ void __launch_bounds__(ENC_THREADS)
-k_enc_owner(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
-            const uint32_t *__restrict__ tab_rep, uint32_t *__restrict__ slot_rep,
+k_enc_pass1(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
+            EncEntry *__restrict__ tab, uint32_t tmask, uint32_t *__restrict__ slot_of, unsigned long long hash_keep,
             const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t mask,
             const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
             unsigned long long *__restrict__ long_list, unsigned long long *__restrict__ n_long) {
@@ -209,23 +201,73 @@ k_enc_owner(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off,
     const uint64_t s0 = off[c];
     const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
     uint32_t L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
-    const uint32_t slot = slot_rep[c];  // (k_enc_hash left the slot here; the owner's index replaces it)
-    slot_rep[c] = (uint32_t)c;
-    if (L == 0) {
+    if (L == 0 || L > ENC_LMAX) {  // (empty: nothing to encode; long: the stream-wide path)
+        slot_of[c] = ENC_NOSLOT;
         outlen[c] = 0;
-        return;
-    }
-    if (L > ENC_LMAX) {
-        outlen[c] = 0;
-        long_list[atomicAdd(n_long, 1ull)] = c;
+        if (L) long_list[atomicAdd(n_long, 1ull)] = c;
         return;
     }
     unsigned long long w[4];
     chunk_words(bytes, s0, L, w);
+    const bool exact = L <= ENC_KEYBYTES && hash_keep == ~0ull;
+    // (hash_keep: all ones -- or, in tests, a few bits only: every chunk goes the hashed way and
+    // thousands of different ones collide, so that the byte comparison of pass 2 has to tell them apart)
+    const unsigned long long key = exact ? (w[0] | ((unsigned long long)(0x80u | L) << 56))
+                                         : ((chunk_hash(w, L) & hash_keep & 0x00FFFFFFFFFFFFFFull) | (0x40ull << 56));
+    uint32_t h = key_home(key, tmask);
+    uint32_t slot = ENC_NOSLOT;
+    bool claimed = false;
+    for (uint32_t probe = 0; probe < ENC_PROBES; probe++) {
+        unsigned long long cur = __hip_atomic_load((enc_gu64 *)&tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            cur = atomicCAS(&tab[h].key, 0ull, key);
+            claimed = cur == 0;
+        }
+        if (claimed || cur == key) {
+            slot = h;
+            break;
+        }
+        h = (h + 1) & tmask;
+    }
+    slot_of[c] = slot;
+    if (!exact) {
+        if (slot != ENC_NOSLOT) {  // the owner is settled when this launch ends: pass 2 goes on
+            const uint32_t cur = __hip_atomic_load((enc_gu32 *)&tab[slot].rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)c < cur) atomicMin(&tab[slot].rep, (uint32_t)c);
+        }
+        return;
+    }
+    if (slot != ENC_NOSLOT && !claimed) return;  // another occurrence owns the slot
+    TT *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
+    TT *rk = s_rk + threadIdx.x;
+    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = (TT)((w[0] >> (8 * i)) & 0xFFu);
+    L = encode_lane<TT>(tok, rk, L, keys, vals, mask, merge_ids);
+    if (slot != ENC_NOSLOT) tab[slot].rep = (uint32_t)c;
+    enc_store<TT>(tok, L, slot != ENC_NOSLOT ? &tab[slot] : nullptr, tmp, s0, outlen, c);
+}
+
+template <typename TT>
+__global__ void __launch_bounds__(ENC_THREADS)
+k_enc_pass2(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
+            EncEntry *__restrict__ tab, uint32_t *__restrict__ slot_of, unsigned long long hash_keep,
+            const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t mask,
+            const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen) {
+    __shared__ TT s_tok[ENC_LMAX * ENC_THREADS];
+    __shared__ TT s_rk[ENC_LMAX * ENC_THREADS];
+    const uint64_t c = (uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint64_t s0 = off[c];
+    const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
+    uint32_t L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
+    if (L == 0 || L > ENC_LMAX) return;
+    if (L <= ENC_KEYBYTES && hash_keep == ~0ull) return;  // settled in pass 1
+    unsigned long long w[4];
+    chunk_words(bytes, s0, L, w);
+    uint32_t slot = slot_of[c];
     if (slot != ENC_NOSLOT) {
-        const uint32_t r = tab_rep[slot];
+        const uint32_t r = tab[slot].rep;
         if (r != (uint32_t)c) {
-            // same slot, same 64-bit hash: the same bytes, unless the hash collided -- look
+            // same slot, same hash: the same bytes, unless the hash collided -- look
             const uint64_t rs = off[r];
             const uint64_t re = ((uint64_t)r + 1 < n_chunks) ? off[r + 1] : n;
             bool same = (re - rs) == (uint64_t)L;
@@ -234,41 +276,58 @@ k_enc_owner(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off,
                 chunk_words(bytes, rs, L, v);
                 same = (v[0] == w[0]) & (v[1] == w[1]) & (v[2] == w[2]) & (v[3] == w[3]);
             }
-            if (same) {
-                slot_rep[c] = r;  // the count follows in k_enc_count
-                return;
-            }
+            if (same) return;  // the owner's tokens are mine
+            slot = ENC_NOSLOT;   // a different chunk behind the same hash: on its own
+            slot_of[c] = ENC_NOSLOT;
         }
     }
-    TT *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
+    TT *tok = s_tok + threadIdx.x;
     TT *rk = s_rk + threadIdx.x;
     for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = (TT)((w[i >> 3] >> (8 * (i & 7))) & 0xFFu);
     L = encode_lane<TT>(tok, rk, L, keys, vals, mask, merge_ids);
-    for (uint32_t i = 0; i < L; i++) tmp[s0 + i] = tok[i * ENC_THREADS];
-    outlen[c] = L;
+    enc_store<TT>(tok, L, slot != ENC_NOSLOT ? &tab[slot] : nullptr, tmp, s0, outlen, c);
 }
 
-// every chunk that is not its own owner takes the owner's count (owners are final: written by the
-// launch before, or by the long-chunk path)
+__global__ void __launch_bounds__(256) k_enc_tab_init(EncEntry *__restrict__ tab, uint64_t nslots) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nslots) tab[i].rep = 0xFFFFFFFFu;  // (the rest of the table was zeroed)
+}
+
+// every cached chunk takes its slot's count (uncached, long and empty chunks have theirs already)
 __global__ void __launch_bounds__(256)
-k_enc_count(const uint32_t *__restrict__ rep, uint64_t n_chunks, uint32_t *__restrict__ outlen) {
+k_enc_count(const EncEntry *__restrict__ tab, const uint32_t *__restrict__ slot_of, uint64_t n_chunks,
+            uint32_t *__restrict__ outlen) {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n_chunks) return;
-    const uint32_t r = rep[c];
-    if (r != (uint32_t)c) outlen[c] = outlen[r];
+    const uint32_t slot = slot_of[c];
+    if (slot != ENC_NOSLOT) outlen[c] = tab[slot].ntok;
 }
 
-// final placement with the cache: chunk c's tokens are its owner's
+// final placement with the cache
 __global__ void __launch_bounds__(256)
-k_enc_place(const uint32_t *__restrict__ tmp, const uint64_t *__restrict__ off, const uint32_t *__restrict__ rep,
-            const uint32_t *__restrict__ outlen, const unsigned long long *__restrict__ out_off, uint64_t n_chunks,
-            int32_t *__restrict__ out) {
+k_enc_place(const uint32_t *__restrict__ tmp, const uint64_t *__restrict__ off, const EncEntry *__restrict__ tab,
+            const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ outlen,
+            const unsigned long long *__restrict__ out_off, uint64_t n_chunks, int32_t *__restrict__ out) {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n_chunks) return;
     const uint32_t L = outlen[c];
-    const uint64_t s0 = off[rep[c]];
+    if (L == 0) return;
     const unsigned long long d0 = out_off[c];
-    for (uint32_t i = 0; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
+    const uint32_t slot = slot_of[c];
+    if (slot == ENC_NOSLOT) {
+        const uint64_t s0 = off[c];
+        for (uint32_t i = 0; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
+        return;
+    }
+    const uint4 t4 = *reinterpret_cast<const uint4 *>(tab[slot].tok);
+    const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++)
+        if (i < L) out[d0 + i] = (int32_t)t[i];
+    if (L > 4) {
+        const uint64_t s0 = off[tab[slot].rep];
+        for (uint32_t i = 4; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
+    }
 }
 
 // long chunks: lowest rank present anywhere in the (flagged) stream
