@@ -86,6 +86,9 @@ struct bpe_ctx {
     int lean_grid = 256;                      // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
+    int lean_sum = 1;                         // option "lean_sum": 1 = k_sel_lean (selection from the table update's per-wave records) whenever they are current
+    uint4 *d_lean_sum = nullptr;              // [4][LEAN_SUM_CAP] those records (k_lean.hip)
+    bool sum_valid = false;                   // ... describe the table as it stands (the last iteration enqueued was a lean one)
     uint32_t *d_dbits = nullptr;              // [DBITS_WORDS] rows a lean table update flagged for re-scanning
     unsigned long long *d_lean_res = nullptr; // row maxima on their way to the deciding workgroup of k_rowsel_lean: 2 words per item
     uint32_t lean_tag = 0;                    // ... tagged with this launch counter
@@ -269,6 +272,7 @@ int ensure_table(bpe_ctx *c, uint32_t v) {
         HIPCHK(c, hipMemsetAsync(c->d_dbits, 0, DBITS_WORDS * sizeof(uint32_t), c->stream));
     }
     TRY(dev_realloc(c, c->d_lean_res, 2 * ((size_t)nv + 8)));
+    if (!c->d_lean_sum) HIPCHK(c, hipMalloc((void **)&c->d_lean_sum, 4 * (size_t)LEAN_SUM_CAP * sizeof(uint4)));
     HIPCHK(c, hipMemsetAsync(c->d_lean_res, 0, 2 * ((size_t)nv + 8) * sizeof(unsigned long long), c->stream));
     if (!c->d_removed) {
         HIPCHK(c, hipMalloc((void **)&c->d_removed, 256 * REMOVED_STRIDE * sizeof(uint32_t)));
@@ -508,6 +512,29 @@ int launch_rowsel_lean(bpe_ctx *c) {
     hipLaunchKernelGGL(k_rowsel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag);
     LAUNCHCHK(c, "k_rowsel_lean");
+    TRY(prof_end(c));
+    c->rows_pending = false;
+    return BPE_OK;
+}
+
+// K2 of a lean iteration right after a lean table update: from that update's per-wave records
+int launch_sel_lean(bpe_ctx *c) {
+    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    CandArgs C;
+    C.idx = c->d_idx;
+    C.dirty = c->d_idx_dirty;
+    C.cand = nullptr;
+    C.stride = (uint32_t)c->idx_cap_words;
+    C.T = (uint32_t)c->slot_T;
+    C.enable = 0;
+    C.tie_index = 1;
+    C.tie_window = 0;
+    // the update before this selection made token vcur - 1: one record per wave of its token workgroups
+    const uint32_t nwv = ((c->vcur + 255u) / 256u) * 4u;
+    hipLaunchKernelGGL(k_sel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                       c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag,
+                       c->d_lean_sum, nwv);
+    LAUNCHCHK(c, "k_sel_lean");
     TRY(prof_end(c));
     c->rows_pending = false;
     return BPE_OK;
@@ -942,7 +969,7 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
     hipLaunchKernelGGL(k_apply_lean, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
                        c->d_rowmax, c->d_st, newid, c->d_dbits, c->par, rec, iter, na, c->d_hdr2[c->mq], c->d_stage,
-                       c->d_removed, c->d_smask, nwords);
+                       c->d_removed, c->d_smask, nwords, c->d_lean_sum);
     LAUNCHCHK(c, "k_apply_lean");
     TRY(prof_end(c));
     c->par ^= 1;  // (a sparse-style pass: staged headers, the header arrays do not flip)

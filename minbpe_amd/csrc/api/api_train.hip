@@ -51,6 +51,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     c->n_sparse = c->n_dense = c->n_index_builds = 0;
     c->n_lean = c->n_deferred = 0;
     c->rows_pending = false;
+    c->sum_valid = false;
     // lean iterations (k_lean.hip): which ones were enqueued that way (1: candidates from the index, 2: every
     // slot), the iteration that reported ST_DEFER, and the one iteration that must take the general path
     std::vector<uint8_t> lean_kind(form2 ? (size_t)num_merges : 0, 0);
@@ -151,7 +152,11 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                                 (sparse || c->slot_T <= 16 * SPARSE_GRID)));
             if (lean) {
                 lean_on = true;
-                if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax) {
+                // (the selection works from the previous table update's records when that was a lean one
+                // too: nothing else has touched the table or the row maxima since)
+                if (c->lean_select && c->lean_sum && c->sum_valid && c->idx_live && c->tie_index && !full_rowmax) {
+                    TRY(launch_sel_lean(c));
+                } else if (c->lean_select && c->idx_live && c->tie_index && !full_rowmax) {
                     TRY(launch_rowsel_lean(c));
                 } else {
                     TRY(flush_lean_rows(c, c->vcur));
@@ -160,7 +165,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 TRY(launch_lean(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = 0;
                 lean_kind[(size_t)i] = sparse ? 1 : 2;
+                c->sum_valid = true;
             } else {
+            c->sum_valid = false;
             TRY(flush_lean_rows(c, c->vcur));
             TRY(launch_select(c, full_rowmax, sparse));
             if (c->slotted && c->slot2) {

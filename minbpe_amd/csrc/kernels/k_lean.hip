@@ -3,19 +3,26 @@
 // hundred slots and nothing is bound by bytes any more, only by the number of launches and of
 // dependent memory round trips inside them -- a launch costs ~2 us plus ~1.7 us per round trip).
 // Three launches instead of five, each a short chain:
-//   k_rowsel_lean    row maxima of the PREVIOUS merge + the pair of this one.  Workgroups 1.. re-scan
-//                    rows a, b, Z and the rows the last table update flagged, one row per workgroup
-//                    with the whole row in flight, and hand each result to workgroup 0 as two
-//                    tagged 8-byte words (no fence, no flag: the data is the flag).  Workgroup 0 reads
-//                    the row-maxima array meanwhile, leaves those rows out, takes them from the
-//                    hand-off, and decides -- ties through the index (tie_by_index, k_select.hip);
-//                    nothing of the decision goes through memory until it is final.
+//   k_sel_lean       the pair of this merge from a TWO-LEVEL view of the row maxima: the table update
+//                    of the previous merge left one record per 64 rows (their maximum, who attains
+//                    it) and the new maxima of rows a, b, Z as per-wave partial results, so the
+//                    deciding workgroup reads ~30 KB instead of the 256 KB row-maxima array and waits
+//                    for nobody -- unless that update flagged rows for re-scanning (one iteration in
+//                    five): workgroups 1.. re-scan those and hand each result over as two tagged
+//                    8-byte words (no fence, no flag: the data is the flag).  Ties through the index
+//                    (tie_by_index, k_select.hip); nothing of the decision goes through memory until
+//                    it is final.
+//   k_rowsel_lean    the same without the records (the first lean iteration after one of the general
+//                    path): workgroups 1.. re-scan rows a, b, Z and the flagged rows, workgroup 0
+//                    reads the whole row-maxima array meanwhile and leaves those rows out.
 //   k_merge_ab_lean  every wave finds its own candidate slots in the inverted index (the three
 //                    filter words of the pair per 32 slots: no candidate list, no single block
 //                    building one) and rewrites them (merge_ab_wave, k_slots2.hip; delta format B)
 //   k_apply_lean     folds the delta into the pair table, one token per thread, every load in
 //                    flight at once, no returning atomic: a row is flagged for re-scanning when the
-//                    entry that lost pairs attained its maximum
+//                    entry that lost pairs attained its maximum.  Thread t also holds entry t of rows
+//                    a, b and Z as they will stand, so every wave leaves the partial maxima of those
+//                    rows and the record of its 64 rows for k_sel_lean
 // What workgroup 0 cannot settle alone (more than TIE_CAP tied pairs, short slots about, a tied pair
 // the index does not lead to) and every pair with a == b is DEFERRED: the iteration reports
 // ST_DEFER, everything enqueued behind it is a no-op that only carries the stream length forward,
@@ -37,6 +44,14 @@ namespace bpe {
 constexpr uint32_t NOROW = 0xFFFFFFFFu;
 constexpr int DBITS_WORDS = 2048;     // one bit per row (vocab <= 65536)
 constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one k_rowsel_lean launch hands to its deciding workgroup
+// Per-wave records of k_apply_lean (wave w of the token workgroups = tokens [64w, 64w + 64)), read by
+// k_sel_lean: four arrays of LEAN_SUM_CAP uint4,
+//   [0][w] = {maximum of the row maxima of rows 64w.. (rows a, b, Z and the rows flagged by this update
+//             left out), the first row that attains it, that row's rowarg, how many rows attain it}
+//   [1 + r][w], r = 0, 1, 2 for rows a, b, Z as they stand after the update: {maximum over columns
+//             64w.., first column that attains it, last column that attains it, 0}
+constexpr uint32_t LEAN_SUM_CAP = 1024;  // waves of the token workgroups at vocab 65536
+constexpr uint32_t LEAN_BLK_CAP = 128;   // 64-row groups with several rows at the maximum that one selection looks into
 
 // ---------------------------------------------------------------------------
 // merge pass.  use_index == 0: no index (small streams) -- every live slot is visited.
@@ -112,6 +127,20 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
 }
 
 // ---------------------------------------------------------------------------
+// unsigned maximum over the wave, every lane gets it (DPP scan + readlane: VALU speed)
+__device__ __forceinline__ uint32_t wave_umax_dpp(uint32_t x) {
+    int v = (int)x;
+    auto umax = [](int p, int q) { return (int)max((uint32_t)p, (uint32_t)q); };
+    v = umax(v, dpp_mov<0x111>(0, v));
+    v = umax(v, dpp_mov<0x112>(0, v));
+    v = umax(v, dpp_mov<0x114>(0, v));
+    v = umax(v, dpp_mov<0x118>(0, v));
+    v = umax(v, dpp_mov<0x142, 0xA>(0, v));
+    v = umax(v, dpp_mov<0x143, 0xC>(0, v));
+    return lane_last((uint32_t)v);
+}
+
+// ---------------------------------------------------------------------------
 // table update, a != b (delta format B: vector 0 = SL, vector 1 = SR, st->adj; see k_slots2.hip).
 // Workgroups [0, na): one token per thread.  Workgroups [na, grid): commit the staged headers; the
 // first of them also makes the new stream length and the iteration's record.
@@ -119,28 +148,35 @@ __global__ void __launch_bounds__(256)
 k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
              const uint32_t *__restrict__ rowmax, DevState *st, uint32_t Z, uint32_t *__restrict__ dbits, int par,
              IterRec *rec, int iter, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
-             uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords) {
+             uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums) {
     const uint32_t status = st->status, defer = st->defer;
     if (blockIdx.x < na) {
         if (status || defer) return;
         const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-        if (t > Z) return;
+        const bool live = t <= Z;  // (dead lanes stay for the wave reductions below)
         const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b, adj = st->adj;
         const uint32_t nrep = 1u << (vcap >> 24);
         const uint32_t vc = vcap & 0xFFFFFFu;
         // (t,a) as it stands: only this thread touches it in this launch ((b,a) also takes thread a's
-        // update, and row b is always re-scanned).  Loaded for every token, with everything else --
-        // a column walk, one 64-byte sector per token, instead of a dependent round trip later
-        const uint32_t rm_t = rowmax[2 * t];
-        const uint32_t old_ta = mat[(size_t)t * stride + a];
+        // update, and row b is re-scanned when that happens).  Loaded for every token, with everything
+        // else -- a column walk, one 64-byte sector per token, instead of a dependent round trip
+        // later -- and so are entry t of row a and of row b (two coalesced row reads)
+        uint2 rm = make_uint2(0u, 0u);
+        uint32_t old_ta = 0, old_at = 0, old_bt = 0;
+        if (live) {
+            rm = reinterpret_cast<const uint2 *>(rowmax)[t];
+            old_ta = mat[(size_t)t * stride + a];
+            old_at = mat[(size_t)a * stride + t];
+            old_bt = mat[(size_t)b * stride + t];
+        }
         uint32_t sl = 0, sr = 0;
         for (uint32_t r0 = 0; r0 < nrep; r0 += 16) {
             uint32_t x[16][2];
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t r = r0 + k;
-                x[k][0] = r < nrep ? delta[delta_rep_off(r, vc) + t] : 0u;
-                x[k][1] = r < nrep ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
+                x[k][0] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + t] : 0u;
+                x[k][1] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -153,15 +189,44 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
         // format B -> the four table updates of token t: column a and the new column Z of row t,
         // entries t of row b and of the new row Z
         const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
+        const bool abz = (t == a) | (t == b) | (t == Z);
+        bool flagged = false;
         if (sl) {
             atomicSub(&mat[(size_t)t * stride + a], sl);
             atomicAdd(&mat[(size_t)t * stride + Z], sl);
             // Row t lost pairs in column a only and gained (t,Z) = sl <= what (t,a) lost: its maximum
-            // moves only if (t,a) attained it (rows a, b and Z are always re-scanned)
-            if (t != a && t != b && t != Z && old_ta == rm_t) atomicOr(&dbits[t >> 5], 1u << (t & 31));
+            // moves only if (t,a) attained it.  Rows a and b: sl != 0 means (a,Z) resp. (b,a) and (b,Z)
+            // change by an amount only this thread knows, while threads Z and a account for those
+            // entries below -- re-scan the row instead (rare: a site preceded by a resp. by a lone b)
+            flagged = abz ? true : (old_ta == rm.x);
+            if (flagged) atomicOr(&dbits[t >> 5], 1u << (t & 31));
         }
         if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
         if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+        if (live && t == b) mat[(size_t)a * stride + b] = 0;  // no (a,b) survives the merge (F2)
+        // ---- what the next selection needs, per wave -------------------------------------------
+        // entry t of rows a, b, Z after this update (exact unless the row was flagged just above)
+        const uint32_t va = (!live || t == b || t == Z) ? 0u : (t == a ? old_at - sl : old_at);
+        const uint32_t vb = live ? old_bt - dr : 0u;
+        const uint32_t vz = live ? ir : 0u;
+        const uint32_t vs = (!live || abz || flagged) ? 0u : rm.x;
+        const uint32_t gw = blockIdx.x * 4u + wave_id(), base = gw * 64u;
+        const int lane = lane_id();
+        {
+            const uint32_t m = wave_umax_dpp(vs);
+            const unsigned long long bal = __ballot(m != 0 && vs == m);
+            const int fl = bal ? __ffsll((long long)bal) - 1 : 0;
+            const uint32_t arg = (uint32_t)__shfl((int)rm.y, fl);
+            if (lane == 0) sums[gw] = make_uint4(m, base + (uint32_t)fl, arg, (uint32_t)__popcll(bal));
+        }
+        const uint32_t v3[3] = {va, vb, vz};
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t m = wave_umax_dpp(v3[r]);
+            const unsigned long long bal = __ballot(m != 0 && v3[r] == m);
+            const int fl = bal ? __ffsll((long long)bal) - 1 : 0, ll = bal ? 63 - __clzll((long long)bal) : 0;
+            if (lane == 0) sums[(size_t)(1 + r) * LEAN_SUM_CAP + gw] = make_uint4(m, base + (uint32_t)fl, base + (uint32_t)ll, 0u);
+        }
         return;
     }
     if (blockIdx.x == na && threadIdx.x < 64) {
@@ -331,22 +396,22 @@ __device__ __forceinline__ bool granule_get(unsigned long long *p, uint32_t tag,
     return false;
 }
 
-// Re-scan the rows in the set (items i = first, first + step, ...); publish == true hands every
-// result to the deciding workgroup as well.
+// Re-scan the rows in the set (items i = lo + first, lo + first + step, ...; lo = 3 leaves rows a, b, Z
+// out); publish == true hands every result to the deciding workgroup as well, as item i - lo.
 __device__ __forceinline__ void lean_scan_rows(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax,
                                                uint32_t ncols, const uint32_t sa, const uint32_t sb, const uint32_t sz,
                                                const DirtyView &D, uint32_t n_items, uint32_t first, uint32_t step,
                                                unsigned long long *res, uint32_t tag, bool publish,
-                                               unsigned long long *s_red) {
-    for (uint32_t i = first; i < n_items; i += step) {
+                                               unsigned long long *s_red, uint32_t lo = 0) {
+    for (uint32_t i = lo + first; i < n_items; i += step) {
         const uint32_t x = i == 0 ? sa : (i == 1 ? sb : (i == 2 ? sz : dirty_view_row(D, i - 3)));
         uint32_t m = 0, arg = 0;
         if (x != NOROW) row_scan_wide(mat + (size_t)x * stride, ncols, x == sa ? (int)sb : -1, s_red, m, arg);
         if (threadIdx.x == 0) {
             if (x != NOROW) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
             if (publish) {
-                granule_put(res + 2 * (size_t)i, tag, m);
-                granule_put(res + 2 * (size_t)i + 1, tag, arg);
+                granule_put(res + 2 * (size_t)(i - lo), tag, m);
+                granule_put(res + 2 * (size_t)(i - lo) + 1, tag, arg);
             }
         }
     }
@@ -449,6 +514,217 @@ k_rowsel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         }
     }
     if (threadIdx.x == 0) {
+        st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
+        st->count = M;
+        st->ntied = nt;
+        st->firstpos = pos;
+        st->sel_tie = 0;
+        if (decided) {
+            st->a = s_tied[2 * pi];
+            st->b = s_tied[2 * pi + 1];
+            st->fin_a = s_tied[2 * pi];
+            st->fin_b = s_tied[2 * pi + 1];
+            st->found = 1;
+        } else {
+            st->found = 0;
+            st->defer = 2;
+        }
+    }
+}
+
+// K2 of a lean iteration that follows a lean table update (index live): the deciding workgroup works
+// from k_apply_lean's per-wave records (LEAN_SUM_CAP above) -- nwv of them, one per thread -- instead
+// of the row-maxima array.  Rows a, b, Z of the previous merge come from their partial maxima and
+// their entries in the row-maxima array are written here; the rows that update flagged are re-scanned
+// by workgroups 1.. (items 0.. of the hand-off) and override a partial result for the same row.
+__global__ void __launch_bounds__(1024)
+k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, DevState *st,
+           SlotRefH ref, CandArgs C, const uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+           const uint4 *__restrict__ sums, uint32_t nwv) {
+    __shared__ unsigned long long s_red[32];
+    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ uint32_t s_exrow[LEAN_EX_CAP + 3], s_exm[LEAN_EX_CAP + 3], s_exarg[LEAN_EX_CAP + 3];
+    __shared__ uint32_t s_pr[16][3][3];
+    __shared__ uint32_t s_blk[LEAN_BLK_CAP], s_rows[ARGMAX_ROWS];
+    __shared__ uint32_t s_wm[16];
+    __shared__ uint32_t s_fail, s_M, s_nt, s_nrows, s_nblk;
+    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
+    const uint32_t sa = st->scan_a, sb = st->scan_b, sz = st->scan_z;
+    const DirtyView D{s_words, s_pref};
+    if (blockIdx.x != 0) {
+        const uint32_t nd = dirty_view_build(dbits, D);
+        if (status || defer || nd == 0) return;
+        lean_scan_rows(mat, stride, rowmax, vcur, sa, sb, sz, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag, true,
+                       s_red, 3);
+        return;
+    }
+    // ---- the deciding workgroup ---------------------------------------------------------------
+    const uint32_t tid = threadIdx.x;
+    const int lane = lane_id(), wv = wave_id();
+    uint4 su = make_uint4(0u, 0u, 0u, 0u), pr[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) pr[r] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < nwv) {  // (all in flight with the flag words below)
+        su = sums[tid];
+#pragma unroll
+        for (int r = 0; r < 3; r++) pr[r] = sums[(size_t)(1 + r) * LEAN_SUM_CAP + tid];
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_nt = 0;
+        s_nrows = 0;
+        s_nblk = 0;
+    }
+    const uint32_t nd = dirty_view_build(dbits, D);
+    if (status || defer) return;
+    auto flagged = [&](uint32_t x) -> bool { return (s_words[x >> 5] >> (x & 31)) & 1u; };
+    // rows a, b, Z: maximum, first and last column that attains it, over the waves' partial results
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t m = wave_umax_dpp(pr[r].x);
+        const bool at = pr[r].x == m && m != 0;
+        const uint32_t f = wave_umax_dpp(at ? 0xFFFFFFFFu - pr[r].y : 0u), l = wave_umax_dpp(at ? pr[r].z : 0u);
+        if (lane == 0) {
+            s_pr[wv][r][0] = m;
+            s_pr[wv][r][1] = f;
+            s_pr[wv][r][2] = l;
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint32_t pm = lane < 16 ? s_pr[lane][r][0] : 0u;
+            const uint32_t m = wave_umax_dpp(pm);
+            const bool at = lane < 16 && pm == m && m != 0;
+            const uint32_t f = wave_umax_dpp(at ? s_pr[lane][r][1] : 0u), l = wave_umax_dpp(at ? s_pr[lane][r][2] : 0u);
+            if (lane == 0) {
+                const uint32_t x = r == 0 ? sa : (r == 1 ? sb : sz);
+                const uint32_t cf = 0xFFFFFFFFu - f;
+                const uint32_t arg = (m == 0) ? 0u : (cf == l ? cf : ROWARG_MULTI);
+                // (a flagged row is re-scanned by another workgroup, which also writes its entry)
+                const bool use = x != NOROW && !flagged(x);
+                if (use) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+                s_exrow[r] = use ? x : 0u;
+                s_exm[r] = use ? m : 0u;
+                s_exarg[r] = arg;
+            }
+        }
+    }
+    const uint32_t n_items = 3 + nd;
+    if (n_items > LEAN_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
+        if (tid == 0) {
+            st->found = 0;
+            st->defer = 2;
+        }
+        return;
+    }
+    if (tid < nd) {
+        const uint32_t x = dirty_view_row(D, tid);
+        uint32_t m = 0, arg = 0;
+        const bool ok = granule_get(res + 2 * (size_t)tid, tag, m) && granule_get(res + 2 * (size_t)tid + 1, tag, arg);
+        if (!ok) s_fail = 1;
+        s_exrow[3 + tid] = x;
+        s_exm[3 + tid] = m;
+        s_exarg[3 + tid] = arg;
+    }
+    __syncthreads();
+    if (s_fail) {  // a row never arrived: never decide on a stale maximum
+        if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
+        return;
+    }
+    // ---- the maximum ------------------------------------------------------------------------------
+    {
+        uint32_t m = su.x;  // (0 beyond nwv)
+        if (tid < n_items) m = max(m, s_exm[tid]);
+        m = wave_umax_dpp(m);
+        if (lane == 0) s_wm[wv] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t M = 0;
+        for (int i = 0; i < 16; i++) M = max(M, s_wm[i]);
+        s_M = M;
+    }
+    __syncthreads();
+    const uint32_t M = s_M;
+    if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
+        if (tid == 0) {
+            st->status = ST_EMPTY;
+            st->count = 0;
+            st->found = 0;
+            st->sel_tie = 0;
+        }
+        return;
+    }
+    // ---- every pair that attains it ---------------------------------------------------------------
+    auto row_at_max = [&](uint32_t x, uint32_t y) {
+        if (y != ROWARG_MULTI) {
+            const uint32_t s = atomicAdd(&s_nt, 1u);
+            if (s < TIE_CAP) {
+                s_tied[2 * s] = (int32_t)x;
+                s_tied[2 * s + 1] = (int32_t)y;
+            }
+        } else {
+            const uint32_t s = atomicAdd(&s_nrows, 1u);
+            if (s < ARGMAX_ROWS) s_rows[s] = x;
+        }
+    };
+    if (su.x == M) {
+        if (su.w == 1) {
+            row_at_max(su.y, su.z);
+        } else {  // several rows of this group of 64 attain it: look into the group
+            const uint32_t s = atomicAdd(&s_nblk, 1u);
+            if (s < LEAN_BLK_CAP) s_blk[s] = tid;
+        }
+    }
+    if (tid < n_items && s_exm[tid] == M) row_at_max(s_exrow[tid], s_exarg[tid]);
+    __syncthreads();
+    const uint32_t nblk = s_nblk;
+    if (nblk <= LEAN_BLK_CAP) {
+        const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
+        for (uint32_t i = wv; i < nblk; i += 16) {
+            const uint32_t x = s_blk[i] * 64u + (uint32_t)lane;
+            // (rows a, b, Z and the flagged rows were left out of the record: they came in above)
+            if (x < vcur && x != sa && x != sb && x != sz && !flagged(x)) {
+                const uint2 v = rowma[x];
+                if (v.x == M) row_at_max(x, v.y);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nrows = s_nrows;
+    if (nblk <= LEAN_BLK_CAP && nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
+        for (uint32_t r = 0; r < nrows; r++) {
+            const uint32_t x = s_rows[r];
+            const uint32_t *row = mat + (size_t)x * stride;
+            for (uint32_t y = tid; y < vcur; y += 1024) {
+                if (row[y] == M) {
+                    const uint32_t s = atomicAdd(&s_nt, 1u);
+                    if (s < TIE_CAP) {
+                        s_tied[2 * s] = (int32_t)x;
+                        s_tied[2 * s + 1] = (int32_t)y;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // more than TIE_CAP pairs (or groups / rows left unexamined): the general path decides
+    const uint32_t nt = (nblk > LEAN_BLK_CAP || nrows > ARGMAX_ROWS) ? (TIE_CAP + 1) : min(s_nt, (uint32_t)TIE_CAP + 1);
+    uint32_t pi = 0;
+    unsigned long long pos = NOPOS;
+    bool decided = (nt == 1);
+    if (!decided && nt <= TIE_CAP && gap == 0) {
+        const unsigned long long key = tie_by_index(ref, C, s_tied, nt);
+        if (key != NOPOS) {
+            pi = (uint32_t)(key & 127u);
+            pos = key >> 7;
+            decided = true;
+        }
+    }
+    if (tid == 0) {
         st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
         st->count = M;
         st->ntied = nt;

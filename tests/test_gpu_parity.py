@@ -117,9 +117,12 @@ def test_train_golden_cases(golden, engine, native):
 # engine variants: (mode, merge impl, slots, sparse, lean) -- slots 2 = the second slotted form (default);
 # sparse 2 = every a != b pass goes through the inverted index and the sparse kernel; lean 1 (default) =
 # lean iterations (k_lean.hip: three launches, table updated at the merge sites, a == b deferred to the
-# general path) once the host has seen a count <= lean_count, 2 = from the first merge on, 0 = never
+# general path) once the host has seen a count <= lean_count, 2 = from the first merge on, 0 = never,
+# 3 = as 2 but every selection reads the whole row-maxima array (k_rowsel_lean; option lean_sum = 0)
+# instead of the previous table update's per-wave records (k_sel_lean, the default)
 VARIANTS = [(0, 0, 0, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 1), (1, 1, 0, 1, 1), (0, 1, 0, 1, 1), (1, 0, 2, 1, 1),
-            (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2)]
+            (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2),
+            (1, 0, 2, 2, 3)]
 
 
 def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
@@ -127,7 +130,8 @@ def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
     engine.set_option("merge", mimpl)
     engine.set_option("slots", slots)
     engine.set_option("sparse", sparse)
-    engine.set_option("lean", lean)
+    engine.set_option("lean", 2 if lean == 3 else lean)
+    engine.set_option("lean_sum", 0 if lean == 3 else 1)
 
 
 def reset_variant(engine):
@@ -184,7 +188,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
             n_same = sum(a == b for a, b in exp[0])
             if lean == 0:
                 assert stats["lean"] == 0 and stats["deferred"] == 0
-            elif lean == 2:
+            elif lean >= 2:
                 # every merge is a lean iteration or was handed back to the general path: all a == b ones
                 # are, and (index live) those whose tie k_select_lean could not settle by itself
                 assert stats["lean"] + stats["deferred"] == nm and stats["deferred"] >= n_same
