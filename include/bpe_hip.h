@@ -208,7 +208,9 @@ int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M);
 int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
 /* The same, extended: out[4] = lean iterations among the passes above (three launches per merge, the
  * pair table updated at the merge sites themselves; option "lean"), out[5] = iterations a lean pass
- * handed back to the general path (pairs with a == b).  Writes min(n, 6) values. */
+ * handed back to the general path (pairs with a == b), out[6] = lean iterations that took their pair off
+ * the list an earlier selection made (the tied pairs in order of first occurrence: the reference merges them
+ * in that order while their counts stand) instead of selecting.  Writes min(n, 7) values. */
 int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */

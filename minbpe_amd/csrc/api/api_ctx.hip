@@ -86,6 +86,7 @@ struct bpe_ctx {
     int lean_grid = 256;                      // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
+    int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
     int lean_sum = 1;                         // option "lean_sum": 1 = k_sel_lean (selection from the table update's per-wave records) whenever they are current
     uint4 *d_lean_sum = nullptr;              // [4][LEAN_SUM_CAP] those records (k_lean.hip)
     bool sum_valid = false;                   // ... describe the table as it stands (the last iteration enqueued was a lean one)
@@ -533,7 +534,7 @@ int launch_sel_lean(bpe_ctx *c) {
     const uint32_t nwv = ((c->vcur + 255u) / 256u) * 4u;
     hipLaunchKernelGGL(k_sel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag,
-                       c->d_lean_sum, nwv);
+                       c->d_lean_sum, nwv, (uint32_t)c->lean_chain);
     LAUNCHCHK(c, "k_sel_lean");
     TRY(prof_end(c));
     c->rows_pending = false;

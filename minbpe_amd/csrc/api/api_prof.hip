@@ -36,8 +36,14 @@ int bpe_train_stats(bpe_ctx *c, uint64_t *out4) {
 
 int bpe_train_stats_ex(bpe_ctx *c, uint64_t *out, int n) {
     if (!c || !out || n < 0) return BPE_E_ARG;
-    const uint64_t v[6] = {c->n_dense, c->n_sparse, c->n_index_builds, c->slot_T, c->n_lean, c->n_deferred};
-    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    uint64_t chained = 0;
+    if (n > 6 && c->d_st) {  // (device-side count: iterations whose pair came off a chain, k_lean.hip)
+        DevState stt;
+        TRY(read_state(c, &stt));
+        chained = stt.chain_taken;
+    }
+    const uint64_t v[7] = {c->n_dense, c->n_sparse, c->n_index_builds, c->slot_T, c->n_lean, c->n_deferred, chained};
+    for (int i = 0; i < n && i < 7; i++) out[i] = v[i];
     return BPE_OK;
 }
 

@@ -127,6 +127,15 @@ struct DevState {
     // re-scanned (and (scan_a, scan_b) retired) by the NEXT launch that needs the row maxima; 0xFFFFFFFF = none.
     // Re-scanning them again is harmless: a merged pair never re-forms.
     uint32_t scan_a, scan_b, scan_z;
+    // lean iterations, chained merges (k_lean.hip): the pairs tied at the maximum when k_sel_lean last
+    // decided, in the order of their first occurrences, up to the first one that shares a token with an
+    // earlier one or has a == b.  chain[0] was that iteration's merge; the following iterations take
+    // chain[chain_pos], chain_pos + 1, ... without selecting, as long as no merge of the chain created
+    // a pair that reaches the tied count (chain_cut, set by k_apply_lean).
+    uint32_t chain_n, chain_pos, chain_cut;
+    uint32_t chain_taken;         // iterations that took their pair off the chain since the stream was loaded (statistics)
+    uint32_t sel_ran;             // the last selection launch re-scanned every flagged row: the next lean merge pass clears the flags
+    int32_t chain[2 * TIE_CAP];
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -51,6 +51,7 @@ constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one k_rowsel_lean launch hands t
 //   [1 + r][w], r = 0, 1, 2 for rows a, b, Z as they stand after the update: {maximum over columns
 //             64w.., first column that attains it, last column that attains it, 0}
 constexpr uint32_t LEAN_SUM_CAP = 1024;  // waves of the token workgroups at vocab 65536
+constexpr uint32_t LEAN_CHAIN_TIES = 48;  // more tied pairs than this: no chain (every pair's first occurrence would be looked up)
 constexpr uint32_t LEAN_BLK_CAP = 128;   // 64-row groups with several rows at the maximum that one selection looks into
 
 // ---------------------------------------------------------------------------
@@ -70,9 +71,15 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
     __shared__ uint32_t s_list[LEAN_SUB * 32];
     __shared__ uint32_t s_tot[2];
     DevState *st = A.st;
-    // (the rows flagged by the last table update were re-scanned by the launch before this one)
-    if (blockIdx.x == 0)
+    // the rows flagged by the table updates so far were re-scanned by the launch before this one -- unless
+    // that was a chained iteration, whose selection launch only takes the next pair of the chain
+    // (k_sel_lean): the flags then stay and pile up until a selection does re-scan them
+    const uint32_t ran = st->sel_ran;
+    if (blockIdx.x == 0 && ran) {
         for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
+        __syncthreads();  // (every thread has read the word above)
+        if (threadIdx.x == 0) st->sel_ran = 0;
+    }
     if (st->status || st->defer) return;
     if (!st->found) {
         if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
@@ -151,33 +158,40 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums) {
     const uint32_t status = st->status, defer = st->defer;
     if (blockIdx.x < na) {
-        if (status || defer) return;
         const uint32_t t = blockIdx.x * 256u + threadIdx.x;
         const bool live = t <= Z;  // (dead lanes stay for the wave reductions below)
-        const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b, adj = st->adj;
         const uint32_t nrep = 1u << (vcap >> 24);
         const uint32_t vc = vcap & 0xFFFFFFu;
-        // (t,a) as it stands: only this thread touches it in this launch ((b,a) also takes thread a's
-        // update, and row b is re-scanned when that happens).  Loaded for every token, with everything
-        // else -- a column walk, one 64-byte sector per token, instead of a dependent round trip
-        // later -- and so are entry t of row a and of row b (two coalesced row reads)
-        uint2 rm = make_uint2(0u, 0u);
-        uint32_t old_ta = 0, old_at = 0, old_bt = 0;
-        if (live) {
-            rm = reinterpret_cast<const uint2 *>(rowmax)[t];
-            old_ta = mat[(size_t)t * stride + a];
-            old_at = mat[(size_t)a * stride + t];
-            old_bt = mat[(size_t)b * stride + t];
-        }
-        uint32_t sl = 0, sr = 0;
-        for (uint32_t r0 = 0; r0 < nrep; r0 += 16) {
-            uint32_t x[16][2];
+        // the first sixteen replicas of this token's delta: on their way before anything is known
+        // about the iteration (the state words above are scalar loads; these do not wait for them)
+        uint32_t x[16][2];
+        auto load_batch = [&](uint32_t r0) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint32_t r = r0 + k;
                 x[k][0] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + t] : 0u;
                 x[k][1] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
             }
+        };
+        load_batch(0);
+        if (status || defer) return;
+        const uint32_t a = (uint32_t)st->fin_a, b = (uint32_t)st->fin_b, adj = st->adj;
+        // (t,a) as it stands: only this thread touches it in this launch ((b,a) also takes thread a's
+        // update, and row b is re-scanned when that happens).  Loaded for every token, with everything
+        // else -- a column walk, one 64-byte sector per token, instead of a dependent round trip
+        // later -- and so are entry t of row a and of row b (two coalesced row reads)
+        uint2 rm = make_uint2(0u, 0u);
+        uint32_t old_ta = 0, old_at = 0, old_bt = 0, prevflag = 0;
+        const uint32_t tied_count = st->count;
+        if (live) {
+            prevflag = (dbits[t >> 5] >> (t & 31)) & 1u;  // (flagged by an earlier update of a chain, not re-scanned yet)
+            rm = reinterpret_cast<const uint2 *>(rowmax)[t];
+            old_ta = mat[(size_t)t * stride + a];
+            old_at = mat[(size_t)a * stride + t];
+            old_bt = mat[(size_t)b * stride + t];
+        }
+        uint32_t sl = 0, sr = 0;
+        for (uint32_t r0 = 0;;) {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if (x[k][0]) delta[delta_rep_off(r0 + k, vc) + t] = 0;
@@ -185,6 +199,9 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
                 sl += x[k][0];
                 sr += x[k][1];
             }
+            r0 += 16;
+            if (r0 >= nrep) break;
+            load_batch(r0);
         }
         // format B -> the four table updates of token t: column a and the new column Z of row t,
         // entries t of row b and of the new row Z
@@ -209,9 +226,12 @@ k_apply_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__
         const uint32_t va = (!live || t == b || t == Z) ? 0u : (t == a ? old_at - sl : old_at);
         const uint32_t vb = live ? old_bt - dr : 0u;
         const uint32_t vz = live ? ir : 0u;
-        const uint32_t vs = (!live || abz || flagged) ? 0u : rm.x;
+        const uint32_t vs = (!live || abz || flagged || prevflag) ? 0u : rm.x;
         const uint32_t gw = blockIdx.x * 4u + wave_id(), base = gw * 64u;
         const int lane = lane_id();
+        // a pair this merge created -- (t,Z) = sl, (Z,t) = ir -- that reaches the count the chain's pairs
+        // are tied at: the next pair of the chain is no longer known to be the reference's next merge
+        if (wave_umax_dpp(max(sl, ir)) >= tied_count && lane == 0) st->chain_cut = 1;
         {
             const uint32_t m = wave_umax_dpp(vs);
             const unsigned long long bal = __ballot(m != 0 && vs == m);
@@ -420,7 +440,7 @@ __device__ __forceinline__ void lean_scan_rows(uint32_t *__restrict__ mat, uint3
 // Row maxima alone (no selection): before a general k_select that follows a lean table update, and
 // when training ends.
 __global__ void __launch_bounds__(1024)
-k_rowmax_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, const DevState *__restrict__ st,
+k_rowmax_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ rowmax, DevState *__restrict__ st,
               uint32_t ncols, const uint32_t *__restrict__ dbits) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
@@ -429,6 +449,10 @@ k_rowmax_lean(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     const DirtyView D{s_words, s_pref};
     const uint32_t nd = dirty_view_build(dbits, D);
     if (status || defer) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->sel_ran = 1;  // (every flagged row is re-scanned here)
+        st->chain_n = 0;
+    }
     lean_scan_rows(mat, stride, rowmax, ncols, sa, sb, sz, D, 3 + nd, blockIdx.x, gridDim.x, nullptr, 0u, false, s_red);
 }
 
@@ -461,6 +485,10 @@ k_rowsel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     if (threadIdx.x == 0) s_fail = 0;
     const uint32_t nd = dirty_view_build(dbits, D);
     if (status || defer) return;
+    if (threadIdx.x == 0) {
+        st->sel_ran = 1;  // (this launch re-scans every flagged row)
+        st->chain_n = 0;
+    }
     const uint32_t n_items = 3 + nd;
     if (n_items > LEAN_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
         if (threadIdx.x == 0) {
@@ -539,8 +567,8 @@ k_rowsel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
 // by workgroups 1.. (items 0.. of the hand-off) and override a partial result for the same row.
 __global__ void __launch_bounds__(1024)
 k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, uint32_t vcur, DevState *st,
-           SlotRefH ref, CandArgs C, const uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-           const uint4 *__restrict__ sums, uint32_t nwv) {
+           SlotRefH ref, CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+           const uint4 *__restrict__ sums, uint32_t nwv, uint32_t chain_on) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     __shared__ int32_t s_tied[2 * TIE_CAP];
@@ -549,8 +577,34 @@ k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     __shared__ uint32_t s_blk[LEAN_BLK_CAP], s_rows[ARGMAX_ROWS];
     __shared__ uint32_t s_wm[16];
     __shared__ uint32_t s_fail, s_M, s_nt, s_nrows, s_nblk;
+    __shared__ unsigned long long s_pos[TIE_CAP];
+    __shared__ uint32_t s_order[TIE_CAP], s_cut;
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
     const uint32_t sa = st->scan_a, sb = st->scan_b, sz = st->scan_z;
+    // ---- a chained iteration: the pair was lined up by an earlier selection ---------------------------
+    // (DevState::chain; valid as long as no merge of the chain created a pair at the tied count.)  Nothing
+    // is re-scanned and nothing selected: rows a, b, Z of the merge before this one join the flagged rows
+    // (their partial maxima are about to be overwritten by the next table update).
+    const uint32_t ch_pos = st->chain_pos;
+    if (!status && !defer && chain_on && ch_pos < st->chain_n && !st->chain_cut) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (sa != NOROW) atomicOr(&dbits[sa >> 5], 1u << (sa & 31));
+            if (sb != NOROW) atomicOr(&dbits[sb >> 5], 1u << (sb & 31));
+            if (sz != NOROW) atomicOr(&dbits[sz >> 5], 1u << (sz & 31));
+            const int32_t a = st->chain[2 * ch_pos], b = st->chain[2 * ch_pos + 1];
+            st->a = a;
+            st->b = b;
+            st->fin_a = a;
+            st->fin_b = b;
+            st->found = 1;
+            st->adj = 0;
+            st->sel_tie = 0;
+            st->firstpos = NOPOS;
+            st->chain_pos = ch_pos + 1;
+            st->chain_taken++;
+        }
+        return;
+    }
     const DirtyView D{s_words, s_pref};
     if (blockIdx.x != 0) {
         const uint32_t nd = dirty_view_build(dbits, D);
@@ -578,6 +632,11 @@ k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     }
     const uint32_t nd = dirty_view_build(dbits, D);
     if (status || defer) return;
+    if (tid == 0) {
+        st->sel_ran = 1;  // (this launch re-scans every flagged row)
+        st->chain_n = 0;
+        st->chain_cut = 0;
+    }
     auto flagged = [&](uint32_t x) -> bool { return (s_words[x >> 5] >> (x & 31)) & 1u; };
     // rows a, b, Z: maximum, first and last column that attains it, over the waves' partial results
 #pragma unroll
@@ -716,12 +775,52 @@ k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     uint32_t pi = 0;
     unsigned long long pos = NOPOS;
     bool decided = (nt == 1);
+    // Up to LEAN_CHAIN_TIES tied pairs: find EVERY pair's first occurrence -- the reference merges them in
+    // that order for as long as their counts stay what they are (the pairs share no token: a merge leaves
+    // every occurrence of the others in place, and their order with it) and nothing new reaches the tied
+    // count (k_apply_lean watches that): the iterations that follow take the pairs off this list
+    const bool chain = chain_on && nt > 1 && nt <= LEAN_CHAIN_TIES && gap == 0;
     if (!decided && nt <= TIE_CAP && gap == 0) {
-        const unsigned long long key = tie_by_index(ref, C, s_tied, nt);
+        const unsigned long long key = tie_by_index(ref, C, s_tied, nt, chain ? s_pos : nullptr);
         if (key != NOPOS) {
             pi = (uint32_t)(key & 127u);
             pos = key >> 7;
             decided = true;
+        }
+    }
+    uint32_t chain_len = 0;
+    if (chain && decided) {
+        // order of first occurrences (positions are distinct); a pair the index did not lead to ends the list
+        if (tid == 0) s_cut = nt;
+        __syncthreads();
+        if (tid < nt) {
+            const unsigned long long me = s_pos[tid];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < nt; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
+            s_order[rank] = tid;
+        }
+        __syncthreads();
+        // the list ends before the first pair that shares a token with an earlier one, has a == b (the
+        // general path's merge) or was not found
+        for (uint32_t k = tid; k < nt * nt; k += 1024) {
+            const uint32_t j = k / nt, i = k % nt;
+            if (j == 0 || i > j) continue;
+            const uint32_t pj = s_order[j], pi2 = s_order[i];
+            const int32_t aj = s_tied[2 * pj], bj = s_tied[2 * pj + 1];
+            bool stop;
+            if (i == j) {
+                stop = (aj == bj) || s_pos[pj] == NOPOS;
+            } else {
+                const int32_t ai = s_tied[2 * pi2], bi = s_tied[2 * pi2 + 1];
+                stop = (ai == aj) | (ai == bj) | (bi == aj) | (bi == bj);
+            }
+            if (stop) atomicMin(&s_cut, j);
+        }
+        __syncthreads();
+        chain_len = s_cut;  // (>= 1: entry 0 is this iteration's pair)
+        if (tid < chain_len) {
+            st->chain[2 * tid] = s_tied[2 * s_order[tid]];
+            st->chain[2 * tid + 1] = s_tied[2 * s_order[tid] + 1];
         }
     }
     if (tid == 0) {
@@ -736,6 +835,8 @@ k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
             st->fin_a = s_tied[2 * pi];
             st->fin_b = s_tied[2 * pi + 1];
             st->found = 1;
+            st->chain_n = chain_len;
+            st->chain_pos = 1;
         } else {
             st->found = 0;
             st->defer = 2;
@@ -744,6 +845,9 @@ k_sel_lean(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
 }
 
 // host: a deferred iteration is about to be re-run through the general path
-__global__ void k_clear_defer(DevState *st) { st->defer = 0; }
+__global__ void k_clear_defer(DevState *st) {
+    st->defer = 0;
+    st->chain_n = 0;  // (a chain of merges lined up by k_sel_lean ends here)
+}
 
 }  // namespace bpe

@@ -298,13 +298,18 @@ __device__ __forceinline__ unsigned long long slot_find_pair(const SlotRefH &ref
     return NOPOS;
 }
 
+// s_pos != nullptr: EVERY tied pair's first occurrence is found (s_pos[p], NOPOS if the index leads to
+// none) -- nobody stops because another pair occurs earlier; the chained merges of k_sel_lean need the
+// whole order.
 __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, const CandArgs &C,
-                                                          const int32_t *s_tied, uint32_t nt) {
+                                                          const int32_t *s_tied, uint32_t nt,
+                                                          unsigned long long *s_pos = nullptr) {
     __shared__ unsigned long long s_best;
     if (threadIdx.x == 0) s_best = NOPOS;
     __syncthreads();
     const int lane = lane_id();
     const uint32_t nwords = (C.T + 31) / 32;
+    const bool all = s_pos != nullptr;
     for (uint32_t p = wave_id(); p < nt; p += 16) {
         const uint32_t x = (uint32_t)s_tied[2 * p], y = (uint32_t)s_tied[2 * p + 1];
         uint32_t h1, h2, h3;
@@ -312,7 +317,7 @@ __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, 
         unsigned long long found = NOPOS;
         bool done = false;
         for (uint32_t wb = 0; wb < nwords && !done; wb += 64) {
-            if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)wb * 32 * TILE2) break;  // cannot win
+            if (!all && (__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)wb * 32 * TILE2) break;  // cannot win
             const uint32_t w = wb + lane;
             uint32_t mk = 0;
             if (w < nwords) {
@@ -329,7 +334,7 @@ __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, 
                 while (mm) {
                     const uint32_t t = (wb + lw) * 32 + (uint32_t)__ffs((int)mm) - 1u;
                     mm &= mm - 1u;
-                    if ((__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)t * TILE2) {
+                    if (!all && (__atomic_load_n(&s_best, __ATOMIC_RELAXED) >> 7) < (unsigned long long)t * TILE2) {
                         done = true;  // another pair already occurs before this slot
                         break;
                     }
@@ -343,13 +348,14 @@ __device__ __forceinline__ unsigned long long tie_by_index(const SlotRefH &ref, 
             }
         }
         if (found != NOPOS && lane == 0) atomicMin(&s_best, (found << 7) | p);  // (p < TIE_CAP <= 128)
+        if (all && lane == 0) s_pos[p] = found;
     }
     __syncthreads();
     return s_best;  // position << 7 | index of the pair in s_tied
 }
 // (the contiguous / first-form views have no index: never called)
 __device__ __forceinline__ unsigned long long tie_by_index(const SlotRef &, const CandArgs &, const int32_t *,
-                                                          uint32_t) {
+                                                          uint32_t, unsigned long long * = nullptr) {
     return NOPOS;
 }
 
@@ -436,6 +442,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
             st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
+            st->chain_n = 0;  // (whatever chain of merges a lean selection had lined up, k_lean.hip, is void)
             __hip_atomic_store(&st->sel_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;

@@ -86,6 +86,8 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->gap = 0;
     st->defer = 0;
     st->scan_a = st->scan_b = st->scan_z = 0xFFFFFFFFu;
+    st->chain_n = st->chain_pos = st->chain_cut = st->chain_taken = 0;
+    st->sel_ran = 0;
 }
 
 }  // namespace bpe

@@ -85,7 +85,8 @@ def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golde
 # defers them); the general path alone, without and with the index
 # (lean 3: lean iterations that select from the whole row-maxima array, k_rowsel_lean, not from the table
 # update's per-wave records)
-FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3)]
+# (lean 4: every lean iteration selects, no chained merges)
+FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4)]
 
 
 @pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
@@ -103,8 +104,9 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
         offs = native.split_offsets(data, 4)
         assert hashlib.sha256(np.ascontiguousarray(offs, dtype=np.uint64).tobytes()).hexdigest() == g["offsets_sha256"]
     engine.set_option("sparse", sparse)
-    engine.set_option("lean", 1 if lean == 3 else lean)
+    engine.set_option("lean", 1 if lean >= 3 else lean)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
+    engine.set_option("lean_chain", 0 if lean == 4 else 1)
     try:
         engine.load_bytes(data, offs)
         _check_digests(engine.train(g["merges"]), g)
@@ -112,6 +114,7 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
         engine.set_option("sparse", 1)
         engine.set_option("lean", 1)
         engine.set_option("lean_sum", 1)
+        engine.set_option("lean_chain", 1)
 
 
 def test_cross_mode_large_chunked(native, engine):

@@ -28,6 +28,7 @@ prof)   # rocprofv3 kernel trace of one train of the first PROF_MERGES merges
     echo "prof rc=$?"; tail -2 gpurun_out/${TAG}_prof.log
     db=$(ls gpurun_out/${TAG}_prof/*/*.db gpurun_out/${TAG}_prof/*.db 2>/dev/null | head -1)
     [ -n "$db" ] && python tools/rocpd_stats.py $db > gpurun_out/${TAG}_kernel_stats.csv && head -20 gpurun_out/${TAG}_kernel_stats.csv
+    [ -n "$db" ] && python tools/rocpd_phases.py $db > gpurun_out/${TAG}_phases.json
     [ -n "$db" ] && python tools/rocpd_timeline.py $db ${TIMELINE_N:-400} | head -${TIMELINE_HEAD:-120} > gpurun_out/${TAG}_timeline.txt
     rm -rf gpurun_out/${TAG}_prof ;;
 pmc)    # kernel-trace stats + the two HBM-traffic counter passes, each its own run (tools/gpu_pmc.sh)
