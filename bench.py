@@ -188,11 +188,16 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     dt = reduce_max(time.perf_counter() - t0)
     prof = eng.prof_read()
     eng.set_option("profile", 0)
+    # the same step without the event records of the timed region (what they cost: an event drains the queue)
+    t0 = time.perf_counter()
+    step()
+    plain_ms = (time.perf_counter() - t0) * 1e3
     out = {
         "workload": f"{wl['desc']}, {wl['bytes']} B synthetic UTF-8 (seed {wl['seed']}), vocab {wl['vocab']} "
                     f"({num_merges} merges)" + (f", {len(offs)} chunks" if offs is not None else ""),
         "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
         "merges_per_s": round(num_merges * steps / dt, 2),
+        "ms_per_step_without_event_records": round(plain_ms, 3),
         "host_prep_s": round(prep_s, 2), "upload_s": round(upload_s, 3),
         "pcie_inclusive_merges_per_s": round(num_merges / (dt / steps + upload_s), 2),
         "final_len": res["lens"][-1] if res["lens"] else len(data),
@@ -200,7 +205,7 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
         "invariants": invariants(res, len(data)),
     }
     # dominant kernel class by device time -> roofline (timed live in the timed region: hipEvents on the
-    # library's stream around that class, every iteration up to 2048 and every 8th after, weighted)
+    # library's stream around that class, every iteration up to 1024 and every 64th after, weighted)
     hot = max(("pair_count", "merge", "widen"), key=lambda k: breakdown[k]["ms"])
     hp = prof[hot] if prof[hot]["launches"] else breakdown[hot]
     alg_GBps = hp["alg_bytes"] / (hp["ms"] * 1e-3) / 1e9 if hp["ms"] > 0 else 0.0

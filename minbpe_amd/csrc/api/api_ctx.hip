@@ -77,7 +77,7 @@ struct bpe_ctx {
     int exp_no_delta = 0;                     // experiment: a != b passes skip the pair-table bookkeeping (wrong results)
     int tie_window = 0;                       // block 0 sweeps the first slots alone on a tie (measured slower: off)
     int tie_index = 1;                        // break ties through the index when it is live (0: always sweep)
-    int sparse_ratio = 2;                     // sparse pass when (count of the pair) * ratio < slots
+    int sparse_ratio = 1;                     // sparse pass when (count of the pair) * ratio < slots (measured at 1 GB: 1 beats 2 by 30 us per merge over iterations 300-1000)
     uint64_t last_count = ~0ull;              // count of the last merge the host has seen: an upper bound of the next ones
     uint64_t n_sparse = 0, n_dense = 0, n_index_builds = 0;  // passes of the last train() (bpe_train_stats)
     uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
@@ -140,11 +140,12 @@ struct bpe_ctx {
 
     int mode = 1;     // 0 recount | 1 delta
     int profile = 0;  // 0 off | 1 hipEvents around the merge pass | 2 around every kernel class
-    // Two event records per iteration cost ~3 us of device time each once an iteration is 30 us (measured:
-    // +9 % on a whole 1 GB train).  Inside bpe_train the first PROF_FULL_ITERS iterations -- the long ones,
-    // where an event is free -- are all timed, later ones every prof_stride-th, weighted by the stride.
+    // An event record drains the queue: a timed iteration costs ~30 us more than an untimed one (measured:
+    // +9 % on a whole 1 GB train with every 8th late iteration timed).  Inside bpe_train the first
+    // PROF_FULL_ITERS iterations -- the long ones, where an event is free -- are all timed, later ones every
+    // prof_stride-th, weighted by the stride.
     int prof_iter = -1;   // iteration being enqueued by bpe_train (-1: not in its loop)
-    int prof_stride = 8;  // option "prof_stride"
+    int prof_stride = 64;  // option "prof_stride"
     bool prof_active = false;
     int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache (8-byte slots) | 2 = 1 + dense 16-bit LDS table for byte streams | 3 = 2 with the 4-byte-slot LDS cache for general unweighted streams (measured: no faster, both bound by L2 atomics on cold pairs)
     bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
@@ -303,7 +304,7 @@ int ensure_rec(bpe_ctx *c, int n) {
 }
 
 // ---- profiling --------------------------------------------------------------
-constexpr int PROF_FULL_ITERS = 2048;
+constexpr int PROF_FULL_ITERS = 1024;
 int prof_begin(bpe_ctx *c, int kind, uint64_t bytes) {
     // level 1: only the dominant kernel class (merge) -- two event records per
     // iteration; level 2: every class (adds marker packets between all kernels)
