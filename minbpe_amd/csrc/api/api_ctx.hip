@@ -124,8 +124,11 @@ struct bpe_ctx {
     // the chunk cache of bpe_encode_batch (k_encode.hip): hash table + per chunk its slot, then its owner
     EncEntry *d_enc_tab = nullptr;
     uint32_t *d_enc_rep = nullptr;  // per chunk: its slot
+    uint8_t *d_enc_mid = nullptr;             // pass 2's work list: lane numbers, packed per workgroup of pass 1 (k_encode.hip)
+    uint32_t *d_enc_midn = nullptr;           // ... and how many per workgroup
     uint64_t cap_enc_tab = 0;
     int enc_cache = 1;  // option "enc_cache": 0 = encode every chunk on its own
+    int enc_chain = 1;  // option "enc_chain": 1 = output offsets and placement in one chained pass (k_enc_place_chained)
     int enc_hash_bits = 0;  // option "enc_hash_bits" (tests): keep only this many bits of the chunk hash (0 = all 64)
 
     // decode (grow-only): vocab table, then ids / lengths / offsets / bytes of the last batch

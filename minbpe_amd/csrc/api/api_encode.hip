@@ -100,8 +100,10 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     if (n_chunks > c->cap_enc_chunks) {
         TRY(dev_realloc(c, c->d_enc_len, (size_t)n_chunks));
         TRY(dev_realloc(c, c->d_enc_off, (size_t)n_chunks + 1));
-        TRY(dev_realloc(c, c->d_enc_bsum, (size_t)nb + 1));
+        TRY(dev_realloc(c, c->d_enc_bsum, (size_t)nb * (SCAN_TILE / ENC_PLACE_TILE) + 2));  // (also the chained pass's descriptors)
         TRY(dev_realloc(c, c->d_enc_rep, (size_t)n_chunks));
+        TRY(dev_realloc(c, c->d_enc_mid, (size_t)((n_chunks + ENC_THREADS - 1) / ENC_THREADS) * ENC_THREADS));
+        TRY(dev_realloc(c, c->d_enc_midn, (size_t)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)));
         c->cap_enc_chunks = n_chunks;
     }
     // the chunk cache (k_encode.hip): a slot per four chunks, 2^12 .. 2^22 slots of 32 bytes (the distinct
@@ -132,21 +134,12 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     if (cache) {
         const unsigned long long keep = c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull;
         const uint32_t tmask = (uint32_t)(tslots - 1);
-        if (narrow) {
-            hipLaunchKernelGGL(k_enc_pass1<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
-                               n_chunks, n, c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask,
-                               d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
-            hipLaunchKernelGGL(k_enc_pass2<uint16_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
-                               n_chunks, n, c->d_enc_tab, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
-                               c->d_enc_tmp, c->d_enc_len);
-        } else {
-            hipLaunchKernelGGL(k_enc_pass1<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
-                               n_chunks, n, c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask,
-                               d_mids, c->d_enc_tmp, c->d_enc_len, c->d_enc_long, d_nlong);
-            hipLaunchKernelGGL(k_enc_pass2<uint32_t>, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets,
-                               n_chunks, n, c->d_enc_tab, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
-                               c->d_enc_tmp, c->d_enc_len);
-        }
+        hipLaunchKernelGGL(k_enc_pass1, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp,
+                           c->d_enc_len, c->d_enc_long, d_nlong, c->d_enc_mid, c->d_enc_midn);
+        hipLaunchKernelGGL(k_enc_pass2, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           c->d_enc_tab, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp,
+                           c->d_enc_len, c->d_enc_mid, c->d_enc_midn);
     } else if (narrow)
         hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3(gch),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
@@ -238,24 +231,31 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     // 6. output offsets = exclusive scan of the per-chunk lengths (cached chunks take their owner's first)
     TRY(prof_begin(c, BPE_PROF_ENCODE, 0));
     if (cache) {
-        hipLaunchKernelGGL(k_enc_count, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream, c->d_enc_tab,
-                           c->d_enc_rep, n_chunks, c->d_enc_len);
-        LAUNCHCHK(c, "k_enc_count");
-    }
-    hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len,
-                       n_chunks, c->d_enc_bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
-                       c->d_enc_bsum, c->d_enc_off);
-    LAUNCHCHK(c, "k_scan_*");
-    // 7. placement and copy-out
-    if (cache)
-        hipLaunchKernelGGL(k_enc_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_enc_tmp, c->d_offsets, c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_off, n_chunks,
-                           c->d_enc_out);
-    else
+        // (token counts, the scan over them and the placement in one chained pass; option enc_chain = 0: the
+        // three-launch form -- counts, block sums, scan inside the tile + placement)
+        if (c->enc_chain) {
+            const uint64_t nbp = (n_chunks + ENC_PLACE_TILE - 1) / ENC_PLACE_TILE;
+            HIPCHK(c, hipMemsetAsync(c->d_enc_bsum, 0, (nbp + 1) * sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(d_min, 0, 4, c->stream));  // (the tile ticket; the long-chunk rounds are over)
+            hipLaunchKernelGGL(k_enc_place_chained, dim3((unsigned)nbp), dim3(256), 0, c->stream, c->d_enc_tmp, c->d_offsets,
+                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, d_min, c->d_enc_off, n_chunks,
+                               c->d_enc_out, d_total);
+        } else {
+            hipLaunchKernelGGL(k_enc_lens, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_tab, c->d_enc_rep, n_chunks,
+                               c->d_enc_len, c->d_enc_bsum);
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
+            hipLaunchKernelGGL(k_enc_place, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_tmp, c->d_offsets,
+                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, c->d_enc_off, n_chunks, c->d_enc_out);
+        }
+    } else {
+        hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
+                           c->d_enc_bsum);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
+                           c->d_enc_bsum, c->d_enc_off);
         hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
                            c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+    }
     LAUNCHCHK(c, "k_encode_place");
     TRY(prof_end(c));
     unsigned long long total = 0;

@@ -66,10 +66,23 @@ __device__ __forceinline__ uint32_t wave_iscan_add(uint32_t x) {
     v += dpp_mov<0x143, 0xC>(0, v);
     return (uint32_t)v;
 }
+__device__ __forceinline__ uint32_t lane_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 0); }
+__device__ __forceinline__ uint32_t lane_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+// unsigned maximum over the wave, every lane gets it (DPP scan + readlane: VALU speed)
+__device__ __forceinline__ uint32_t wave_umax_dpp(uint32_t x) {
+    int v = (int)x;
+    auto umax = [](int p, int q) { return (int)max((uint32_t)p, (uint32_t)q); };
+    v = umax(v, dpp_mov<0x111>(0, v));
+    v = umax(v, dpp_mov<0x112>(0, v));
+    v = umax(v, dpp_mov<0x114>(0, v));
+    v = umax(v, dpp_mov<0x118>(0, v));
+    v = umax(v, dpp_mov<0x142, 0xA>(0, v));
+    v = umax(v, dpp_mov<0x143, 0xC>(0, v));
+    return lane_last((uint32_t)v);
+}
+__device__ __forceinline__ uint32_t wave_umin_dpp(uint32_t x) { return ~wave_umax_dpp(~x); }
 __device__ __forceinline__ uint32_t lane_next(uint32_t x, uint32_t fill) {  // value of lane+1 (lane 63: fill)
     return (uint32_t)dpp_mov<0x130>((int)fill, (int)x);
 }
-__device__ __forceinline__ uint32_t lane_first(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 0); }
-__device__ __forceinline__ uint32_t lane_last(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
 
 }  // namespace bpe

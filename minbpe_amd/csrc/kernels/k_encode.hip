@@ -164,128 +164,246 @@ __device__ __forceinline__ unsigned long long chunk_hash(const unsigned long lon
     h ^= h >> 29;
     return h;
 }
-__device__ __forceinline__ uint32_t key_home(unsigned long long key, uint32_t tmask) {
-    return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 36) & tmask;
-}
 
 typedef unsigned long long __attribute__((address_space(1))) enc_gu64;
 typedef uint32_t __attribute__((address_space(1))) enc_gu32;
 
-// the owner's result goes into its slot (and, beyond four tokens, into the staging area)
-template <typename TT>
-__device__ __forceinline__ void enc_store(const TT *tok, uint32_t L, EncEntry *e, uint32_t *__restrict__ tmp, uint64_t s0,
-                                          uint32_t *__restrict__ outlen, uint64_t c) {
-    if (e) {
-        uint32_t t4[4];
-#pragma unroll
-        for (uint32_t i = 0; i < 4; i++) t4[i] = i < L ? (uint32_t)tok[i * ENC_THREADS] : 0u;
-        e->ntok = L;
-        *reinterpret_cast<uint4 *>(e->tok) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+// ---------------------------------------------------------------------------
+// One chunk by ONE WAVE: lane i holds token i (i < L <= 64), ranks of the adjacent pairs are looked up
+// by all lanes at once, and a merge step is one wave-wide minimum, one lane shift and the two new
+// look-ups side by side -- (merges + 1) dependent table accesses instead of the (L + 2 * merges) a
+// single lane needs (encode_lane).  Owners are few (one per DISTINCT chunk), so a wave spends its
+// lanes on one of them at a time instead of waiting for one lane.  Returns the new length; tok is
+// updated (lanes >= L: undefined).
+__device__ __forceinline__ uint32_t encode_wave(uint32_t &tok, uint32_t L, const unsigned long long *__restrict__ keys,
+                                                const uint32_t *__restrict__ vals, uint32_t mask,
+                                                const int32_t *__restrict__ merge_ids) {
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const uint32_t lane = (uint32_t)lane_id();
+    uint32_t nx = lane_next(tok, 0u);
+    uint32_t rk = (lane + 1 < L) ? rank_lookup(keys, vals, mask, tok, nx) : NONE;
+    while (L >= 2) {
+        const uint32_t m = wave_umin_dpp(rk);
+        if (m == NONE) break;  // nothing else can be merged
+        const uint32_t bi = (uint32_t)__ffsll((long long)__ballot(rk == m)) - 1u;  // leftmost occurrence of the lowest rank
+        const uint32_t z = merge_ids ? (uint32_t)merge_ids[m] : 256u + m;
+        const uint32_t tn = lane_next(tok, 0u), rn = lane_next(rk, NONE);
+        if (lane == bi) tok = z;
+        if (lane > bi) {
+            tok = tn;
+            rk = rn;
+        }
+        L--;
+        nx = lane_next(tok, 0u);
+        if (lane + 1 >= L) rk = NONE;
+        else if (lane + 1 == bi || lane == bi) rk = rank_lookup(keys, vals, mask, tok, nx);
     }
-    if (!e || L > 4)
-        for (uint32_t i = 0; i < L; i++) tmp[s0 + i] = tok[i * ENC_THREADS];
-    outlen[c] = L;
+    return L;
+}
+// ... and its result: into the owner's slot (token count, first four tokens; the rest: staging area, at the
+// owner's byte offset); slot == ENC_NOSLOT: everything into the staging area
+__device__ __forceinline__ void enc_store_wave(uint32_t tok, uint32_t L, EncEntry *__restrict__ tab, uint32_t slot,
+                                               uint32_t *__restrict__ tmp, uint64_t s0, uint32_t *__restrict__ outlen,
+                                               uint64_t c) {
+    const uint32_t lane = (uint32_t)lane_id();
+    if (slot != ENC_NOSLOT) {
+        if (lane < 4) tab[slot].tok[lane] = lane < L ? tok : 0u;
+        if (lane == 0) {
+            tab[slot].rep = (uint32_t)c;
+            tab[slot].ntok = L;
+        }
+    }
+    if ((slot == ENC_NOSLOT || L > 4) && lane < L) tmp[s0 + lane] = tok;
+    if (lane == 0) outlen[c] = L;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-template <typename TT>
+// the first min(len, 8) bytes of a chunk as one little-endian word (zero beyond len), from aligned loads
+__device__ __forceinline__ unsigned long long chunk_word0(const uint8_t *__restrict__ bytes, uint64_t s0, uint32_t len) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(bytes + (s0 & ~7ull));
+    const uint32_t sh = (uint32_t)(s0 & 7u) * 8u;
+    unsigned long long v = p[0] >> sh;
+    if (sh + 8u * len > 64u) v |= p[1] << (64u - sh);  // (sh != 0 here)
+    return len >= 8 ? v : (v & ((1ull << (8 * len)) - 1ull));
+}
+// home slot of a key: 32-bit multiplies only (a 64-bit multiply is four of them on this part, and pass 1
+// is bound by instruction issue, not by memory)
+__device__ __forceinline__ uint32_t key_home(unsigned long long key, uint32_t tmask) {
+    uint32_t h = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h & tmask;
+}
+// find the key's slot or claim an empty one; ENC_NOSLOT after ENC_PROBES occupied slots
+__device__ __forceinline__ uint32_t enc_probe(EncEntry *__restrict__ tab, uint32_t tmask, unsigned long long key, bool &claimed) {
+    uint32_t h = key_home(key, tmask);
+    claimed = false;
+    for (uint32_t probe = 0; probe < ENC_PROBES; probe++) {
+        // A key is written once and never changes: a cached copy that shows it is as good as memory.
+        // Only an empty-looking slot is read again past the caches (another CU's insert never
+        // refreshes this CU's L1), and claimed if it is still empty.
+        unsigned long long cur = tab[h].key;  // (plain: may come from this CU's L1)
+        if (cur == 0) cur = __hip_atomic_load((enc_gu64 *)&tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            cur = atomicCAS(&tab[h].key, 0ull, key);
+            claimed = cur == 0;
+        }
+        if (claimed || cur == key) return h;
+        h = (h + 1) & tmask;
+    }
+    return ENC_NOSLOT;
+}
+
+// Pass 1: the chunks that are their own key (up to ENC_KEYBYTES bytes: five in six under a GPT-style split)
+// -- one aligned word or two, a 32-bit hash, a probe; the thread whose claim succeeds is the owner, and
+// the owners of a wave are encoded by the whole wave, one after the other.  Every other short chunk (8..32
+// bytes; or all of them when the test option cuts the hash) only goes on the workgroup's list for the
+// workgroup's list -- lane numbers, packed -- and the workgroup's first wave(s) then hash them and find their
+// slots: full waves over a sixth of the chunks instead of one live lane in six carrying the 64-bit arithmetic
+// through every wave (pass 1 is bound by instruction issue).  Pass 2 works off the same list.
 __global__ void __launch_bounds__(ENC_THREADS)
 k_enc_pass1(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
             EncEntry *__restrict__ tab, uint32_t tmask, uint32_t *__restrict__ slot_of, unsigned long long hash_keep,
             const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t mask,
             const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
-            unsigned long long *__restrict__ long_list, unsigned long long *__restrict__ n_long) {
-    __shared__ TT s_tok[ENC_LMAX * ENC_THREADS];
-    __shared__ TT s_rk[ENC_LMAX * ENC_THREADS];
+            unsigned long long *__restrict__ long_list, unsigned long long *__restrict__ n_long,
+            uint8_t *__restrict__ mid_list, uint32_t *__restrict__ mid_cnt) {
+    __shared__ uint32_t s_wcnt[ENC_THREADS / 64];
+    __shared__ uint8_t s_mid[ENC_THREADS];
     const uint64_t c = (uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t s0 = off[c];
-    const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
-    uint32_t L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
-    if (L == 0 || L > ENC_LMAX) {  // (empty: nothing to encode; long: the stream-wide path)
-        slot_of[c] = ENC_NOSLOT;
-        outlen[c] = 0;
-        if (L) long_list[atomicAdd(n_long, 1ull)] = c;
-        return;
+    const int lane = lane_id();
+    uint64_t s0 = 0;
+    uint32_t L = 0, slot = ENC_NOSLOT;
+    unsigned long long w0 = 0;
+    bool own = false, mid = false;
+    if (c < n_chunks) {
+        s0 = off[c];
+        const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
+        L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
+        if (L == 0 || L > ENC_LMAX) {  // (empty: nothing to encode; long: the stream-wide path)
+            slot_of[c] = ENC_NOSLOT;
+            outlen[c] = 0;
+            if (L) long_list[atomicAdd(n_long, 1ull)] = c;
+        } else if (L <= ENC_KEYBYTES && hash_keep == ~0ull) {
+            w0 = chunk_word0(bytes, s0, L);
+            bool claimed;
+            slot = enc_probe(tab, tmask, w0 | ((unsigned long long)(0x80u | L) << 56), claimed);
+            slot_of[c] = slot;
+            own = slot == ENC_NOSLOT || claimed;  // (otherwise another occurrence owns the slot)
+        } else {
+            mid = true;
+        }
     }
+    // the owners among this wave's chunks, one after the other
+    for (unsigned long long ob = __ballot(own); ob; ob &= ob - 1) {
+        const int ol = __ffsll((long long)ob) - 1;
+        const unsigned long long ww = readlane_u64(w0, ol);
+        const uint32_t Lo = (uint32_t)__builtin_amdgcn_readlane((int)L, ol);
+        const uint32_t oslot = (uint32_t)__builtin_amdgcn_readlane((int)slot, ol);
+        const uint64_t oc = (uint64_t)blockIdx.x * ENC_THREADS + (threadIdx.x & ~63u) + (uint32_t)ol;
+        const uint64_t os0 = readlane_u64(s0, ol);
+        uint32_t tok = (uint32_t)((ww >> (8 * (lane & 7))) & 0xFFu);
+        const uint32_t Ln = encode_wave(tok, Lo, keys, vals, mask, merge_ids);
+        enc_store_wave(tok, Ln, tab, oslot, tmp, os0, outlen, oc);
+    }
+    // the hashed chunks of this workgroup, packed: its first waves find (or claim) their slots -- the slot's
+    // owner is the lowest chunk index that hashed there (atomicMin), settled when the launch ends -- and the
+    // list goes to pass 2
+    const unsigned long long mb = __ballot(mid);
+    if (lane == 0) s_wcnt[wave_id()] = (uint32_t)__popcll(mb);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int v = 0; v < ENC_THREADS / 64; v++) {
+        if (v < wave_id()) base += s_wcnt[v];
+        total += s_wcnt[v];
+    }
+    if (mid) s_mid[base + (uint32_t)__popcll(mb & ((1ull << lane) - 1ull))] = (uint8_t)threadIdx.x;
+    if (threadIdx.x == 0) mid_cnt[blockIdx.x] = total;
+    __syncthreads();
+    if (threadIdx.x >= total) return;
+    const uint32_t ml = s_mid[threadIdx.x];
+    mid_list[(uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x] = (uint8_t)ml;
+    const uint64_t cm = (uint64_t)blockIdx.x * ENC_THREADS + ml;
+    const uint64_t sm = off[cm];
+    const uint64_t em = (cm + 1 < n_chunks) ? off[cm + 1] : n;
+    const uint32_t Lm = (uint32_t)(em - sm);
     unsigned long long w[4];
-    chunk_words(bytes, s0, L, w);
-    const bool exact = L <= ENC_KEYBYTES && hash_keep == ~0ull;
-    // (hash_keep: all ones -- or, in tests, a few bits only: every chunk goes the hashed way and
-    // thousands of different ones collide, so that the byte comparison of pass 2 has to tell them apart)
-    const unsigned long long key = exact ? (w[0] | ((unsigned long long)(0x80u | L) << 56))
-                                         : ((chunk_hash(w, L) & hash_keep & 0x00FFFFFFFFFFFFFFull) | (0x40ull << 56));
-    uint32_t h = key_home(key, tmask);
-    uint32_t slot = ENC_NOSLOT;
-    bool claimed = false;
-    for (uint32_t probe = 0; probe < ENC_PROBES; probe++) {
-        unsigned long long cur = __hip_atomic_load((enc_gu64 *)&tab[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == 0) {
-            cur = atomicCAS(&tab[h].key, 0ull, key);
-            claimed = cur == 0;
-        }
-        if (claimed || cur == key) {
-            slot = h;
-            break;
-        }
-        h = (h + 1) & tmask;
+    chunk_words(bytes, sm, Lm, w);
+    // (hash_keep: all ones -- or, in tests, a few bits only: thousands of different chunks collide, so that
+    // the byte comparison of pass 2 has to tell them apart)
+    const unsigned long long key = (chunk_hash(w, Lm) & hash_keep & 0x00FFFFFFFFFFFFFFull) | (0x40ull << 56);
+    bool claimed;
+    const uint32_t mslot = enc_probe(tab, tmask, key, claimed);
+    slot_of[cm] = mslot;
+    if (mslot != ENC_NOSLOT) {
+        const uint32_t cur = __hip_atomic_load((enc_gu32 *)&tab[mslot].rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)cm < cur) atomicMin(&tab[mslot].rep, (uint32_t)cm);
     }
-    slot_of[c] = slot;
-    if (!exact) {
-        if (slot != ENC_NOSLOT) {  // the owner is settled when this launch ends: pass 2 goes on
-            const uint32_t cur = __hip_atomic_load((enc_gu32 *)&tab[slot].rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)c < cur) atomicMin(&tab[slot].rep, (uint32_t)c);
-        }
-        return;
-    }
-    if (slot != ENC_NOSLOT && !claimed) return;  // another occurrence owns the slot
-    TT *tok = s_tok + threadIdx.x;  // element i at tok[i * ENC_THREADS]
-    TT *rk = s_rk + threadIdx.x;
-    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = (TT)((w[0] >> (8 * i)) & 0xFFu);
-    L = encode_lane<TT>(tok, rk, L, keys, vals, mask, merge_ids);
-    if (slot != ENC_NOSLOT) tab[slot].rep = (uint32_t)c;
-    enc_store<TT>(tok, L, slot != ENC_NOSLOT ? &tab[slot] : nullptr, tmp, s0, outlen, c);
 }
 
-template <typename TT>
+// Pass 2, over pass 1's lists: the slot's owner encodes; every other occurrence compares its bytes with the
+// owner's (a different chunk behind the same hash: encoded on its own, uncached).
 __global__ void __launch_bounds__(ENC_THREADS)
 k_enc_pass2(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
-            EncEntry *__restrict__ tab, uint32_t *__restrict__ slot_of, unsigned long long hash_keep,
+            EncEntry *__restrict__ tab, uint32_t *__restrict__ slot_of,
             const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t mask,
-            const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen) {
-    __shared__ TT s_tok[ENC_LMAX * ENC_THREADS];
-    __shared__ TT s_rk[ENC_LMAX * ENC_THREADS];
-    const uint64_t c = (uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint64_t s0 = off[c];
-    const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
-    uint32_t L = (uint32_t)min(e0 - s0, (uint64_t)0xFFFFFFFFu);
-    if (L == 0 || L > ENC_LMAX) return;
-    if (L <= ENC_KEYBYTES && hash_keep == ~0ull) return;  // settled in pass 1
-    unsigned long long w[4];
-    chunk_words(bytes, s0, L, w);
-    uint32_t slot = slot_of[c];
-    if (slot != ENC_NOSLOT) {
-        const uint32_t r = tab[slot].rep;
-        if (r != (uint32_t)c) {
-            // same slot, same hash: the same bytes, unless the hash collided -- look
-            const uint64_t rs = off[r];
-            const uint64_t re = ((uint64_t)r + 1 < n_chunks) ? off[r + 1] : n;
-            bool same = (re - rs) == (uint64_t)L;
-            if (same) {
-                unsigned long long v[4];
-                chunk_words(bytes, rs, L, v);
-                same = (v[0] == w[0]) & (v[1] == w[1]) & (v[2] == w[2]) & (v[3] == w[3]);
+            const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
+            const uint8_t *__restrict__ mid_list, const uint32_t *__restrict__ mid_cnt) {
+    const uint32_t nmid = mid_cnt[blockIdx.x];
+    if ((threadIdx.x & ~63u) >= nmid) return;  // (whole waves without work leave)
+    const int lane = lane_id();
+    const bool act = threadIdx.x < nmid;
+    uint64_t c = 0, s0 = 0;
+    uint32_t L = 0, slot = ENC_NOSLOT;
+    unsigned long long w[4] = {0, 0, 0, 0};
+    bool own = false;
+    if (act) {
+        c = (uint64_t)blockIdx.x * ENC_THREADS + mid_list[(uint64_t)blockIdx.x * ENC_THREADS + threadIdx.x];
+        s0 = off[c];
+        const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
+        L = (uint32_t)(e0 - s0);
+        chunk_words(bytes, s0, L, w);
+        slot = slot_of[c];
+        own = true;
+        if (slot != ENC_NOSLOT) {
+            const uint32_t r = tab[slot].rep;
+            if (r != (uint32_t)c) {
+                // same slot, same hash: the same bytes, unless the hash collided -- look
+                const uint64_t rs = off[r];
+                const uint64_t re = ((uint64_t)r + 1 < n_chunks) ? off[r + 1] : n;
+                bool same = (re - rs) == (uint64_t)L;
+                if (same) {
+                    unsigned long long v[4];
+                    chunk_words(bytes, rs, L, v);
+                    same = (v[0] == w[0]) & (v[1] == w[1]) & (v[2] == w[2]) & (v[3] == w[3]);
+                }
+                if (same) {
+                    own = false;  // the owner's tokens are mine
+                } else {
+                    slot = ENC_NOSLOT;  // a different chunk behind the same hash: on its own
+                    slot_of[c] = ENC_NOSLOT;
+                }
             }
-            if (same) return;  // the owner's tokens are mine
-            slot = ENC_NOSLOT;   // a different chunk behind the same hash: on its own
-            slot_of[c] = ENC_NOSLOT;
         }
     }
-    TT *tok = s_tok + threadIdx.x;
-    TT *rk = s_rk + threadIdx.x;
-    for (uint32_t i = 0; i < L; i++) tok[i * ENC_THREADS] = (TT)((w[i >> 3] >> (8 * (i & 7))) & 0xFFu);
-    L = encode_lane<TT>(tok, rk, L, keys, vals, mask, merge_ids);
-    enc_store<TT>(tok, L, slot != ENC_NOSLOT ? &tab[slot] : nullptr, tmp, s0, outlen, c);
+    for (unsigned long long ob = __ballot(own); ob; ob &= ob - 1) {
+        const int ol = __ffsll((long long)ob) - 1;
+        const unsigned long long w0 = readlane_u64(w[0], ol), w1 = readlane_u64(w[1], ol), w2 = readlane_u64(w[2], ol),
+                                 w3 = readlane_u64(w[3], ol);
+        const uint32_t Lo = (uint32_t)__builtin_amdgcn_readlane((int)L, ol);
+        const uint32_t oslot = (uint32_t)__builtin_amdgcn_readlane((int)slot, ol);
+        const uint64_t oc = readlane_u64(c, ol), os0 = readlane_u64(s0, ol);
+        const unsigned long long wsel = (lane & 16) ? ((lane & 8) ? w3 : w2) : ((lane & 8) ? w1 : w0);  // (lanes 0..31)
+        uint32_t tok = (uint32_t)((wsel >> (8 * (lane & 7))) & 0xFFu);
+        const uint32_t Ln = encode_wave(tok, Lo, keys, vals, mask, merge_ids);
+        enc_store_wave(tok, Ln, tab, oslot, tmp, os0, outlen, oc);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_enc_tab_init(EncEntry *__restrict__ tab, uint64_t nslots) {
@@ -293,40 +411,216 @@ __global__ void __launch_bounds__(256) k_enc_tab_init(EncEntry *__restrict__ tab
     if (i < nslots) tab[i].rep = 0xFFFFFFFFu;  // (the rest of the table was zeroed)
 }
 
-// every cached chunk takes its slot's count (uncached, long and empty chunks have theirs already)
+// Output offsets and placement with the cache, two launches around k_scan_top:
+//   k_enc_lens   every cached chunk takes its slot's token count (uncached, long and empty chunks have
+//                theirs already); the sum of each tile of SCAN_TILE chunks
+//   k_enc_place  exclusive scan inside the tile (thread t owns SCAN_TILE / 256 consecutive chunks), the
+//                chunk's output offset, and its tokens: the first four sit in the slot itself
 __global__ void __launch_bounds__(256)
-k_enc_count(const EncEntry *__restrict__ tab, const uint32_t *__restrict__ slot_of, uint64_t n_chunks,
-            uint32_t *__restrict__ outlen) {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint32_t slot = slot_of[c];
-    if (slot != ENC_NOSLOT) outlen[c] = tab[slot].ntok;
+k_enc_lens(const EncEntry *__restrict__ tab, const uint32_t *__restrict__ slot_of, uint64_t n_chunks,
+           uint32_t *__restrict__ outlen, unsigned long long *__restrict__ bsum) {
+    __shared__ unsigned long long s_red[4];
+    constexpr int PER = SCAN_TILE / 256;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x;  // element j of this thread: base + 256 j
+    uint32_t sl[PER], len[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) sl[j] = (base + 256u * j < n_chunks) ? slot_of[base + 256u * j] : ENC_NOSLOT;
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        len[j] = (base + 256u * j < n_chunks) ? (sl[j] != ENC_NOSLOT ? tab[sl[j]].ntok : outlen[base + 256u * j]) : 0u;
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        if (sl[j] != ENC_NOSLOT) outlen[base + 256u * j] = len[j];
+        acc += len[j];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane_id() == 0) s_red[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
 }
-
-// final placement with the cache
+// (thread t owns elements 16 t .. 16 t + 15 of the tile for the scan, element 256 j + t for every global
+// access: the lengths go through LDS once each way, padded by one word per sixteen against bank conflicts)
 __global__ void __launch_bounds__(256)
 k_enc_place(const uint32_t *__restrict__ tmp, const uint64_t *__restrict__ off, const EncEntry *__restrict__ tab,
             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ outlen,
-            const unsigned long long *__restrict__ out_off, uint64_t n_chunks, int32_t *__restrict__ out) {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_chunks) return;
-    const uint32_t L = outlen[c];
-    if (L == 0) return;
-    const unsigned long long d0 = out_off[c];
-    const uint32_t slot = slot_of[c];
-    if (slot == ENC_NOSLOT) {
-        const uint64_t s0 = off[c];
-        for (uint32_t i = 0; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
-        return;
-    }
-    const uint4 t4 = *reinterpret_cast<const uint4 *>(tab[slot].tok);
-    const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+            const unsigned long long *__restrict__ bsum, unsigned long long *__restrict__ out_off, uint64_t n_chunks,
+            int32_t *__restrict__ out) {
+    constexpr int PER = SCAN_TILE / 256;
+    __shared__ uint32_t s_x[SCAN_TILE + SCAN_TILE / 16];
+    __shared__ uint32_t s_w[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x;
+    uint32_t x[PER], sl[PER];
 #pragma unroll
-    for (uint32_t i = 0; i < 4; i++)
-        if (i < L) out[d0 + i] = (int32_t)t[i];
-    if (L > 4) {
-        const uint64_t s0 = off[tab[slot].rep];
-        for (uint32_t i = 4; i < L; i++) out[d0 + i] = (int32_t)tmp[s0 + i];
+    for (int j = 0; j < PER; j++) {
+        const uint64_t c = base + 256u * j;
+        x[j] = c < n_chunks ? outlen[c] : 0u;
+        sl[j] = c < n_chunks ? slot_of[c] : ENC_NOSLOT;
+        const uint32_t e = 256u * j + threadIdx.x;
+        s_x[e + (e >> 4)] = x[j];
+    }
+    __syncthreads();
+    uint32_t mine[PER], acc = 0;  // (a tile's tokens: below 2^32)
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        mine[i] = s_x[threadIdx.x * 17u + i];
+        acc += mine[i];
+    }
+    uint32_t inc = wave_iscan_add(acc);
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    uint32_t run = inc - acc;
+    for (int v = 0; v < wave_id(); v++) run += s_w[v];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        s_x[threadIdx.x * 17u + i] = run;
+        run += mine[i];
+    }
+    __syncthreads();
+    const unsigned long long tile0 = bsum[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint64_t c = base + 256u * j;
+        if (c >= n_chunks) break;
+        const uint32_t e = 256u * j + threadIdx.x;
+        const unsigned long long d0 = tile0 + s_x[e + (e >> 4)];
+        out_off[c] = d0;
+        const uint32_t L = x[j];
+        if (L == 0) continue;
+        if (sl[j] == ENC_NOSLOT) {
+            const uint64_t s0 = off[c];
+            for (uint32_t k = 0; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
+            continue;
+        }
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(tab[sl[j]].tok);
+        const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (k < L) out[d0 + k] = (int32_t)t[k];
+        if (L > 4) {
+            const uint64_t s0 = off[tab[sl[j]].rep];
+            for (uint32_t k = 4; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
+        }
+    }
+}
+
+// The two launches above and k_scan_top in ONE pass: a tile takes its number from a ticket (so that every
+// tile before it has started), publishes its token count and looks back over its predecessors' descriptors
+// for its offset (a chained scan: descriptor = status << 62 | value, 1 = the tile's own count, 2 = the
+// count of everything up to and including the tile; agent-scope relaxed accesses, the data is the flag).
+// Each chunk's slot is read once -- token count and first four tokens sit in the same 32 bytes -- and the
+// per-chunk lengths never go through memory.  *total receives the batch's token count.
+typedef unsigned long long __attribute__((address_space(1))) enc_desc_t;
+constexpr int ENC_PLACE_TILE = 2048;  // chunks per tile of the chained pass (eight per thread: registers)
+__global__ void __launch_bounds__(256)
+k_enc_place_chained(const uint32_t *__restrict__ tmp, const uint64_t *__restrict__ off, const EncEntry *__restrict__ tab,
+                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ outlen,
+                    unsigned long long *__restrict__ desc, uint32_t *__restrict__ ticket,
+                    unsigned long long *__restrict__ out_off, uint64_t n_chunks, int32_t *__restrict__ out,
+                    unsigned long long *__restrict__ total) {
+    constexpr int PER = ENC_PLACE_TILE / 256;
+    __shared__ uint32_t s_x[ENC_PLACE_TILE + ENC_PLACE_TILE / PER];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_tile;
+    __shared__ unsigned long long s_excl;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t base = (uint64_t)tile * ENC_PLACE_TILE + threadIdx.x;  // element j of this thread: base + 256 j
+    uint32_t x[PER], sl[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) sl[j] = (base + 256u * j < n_chunks) ? slot_of[base + 256u * j] : ENC_NOSLOT;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint64_t c = base + 256u * j;
+        if (sl[j] != ENC_NOSLOT) {
+            x[j] = tab[sl[j]].ntok;  // (the tokens are read further down, from the same 32 bytes: cached by then)
+        } else {
+            x[j] = c < n_chunks ? outlen[c] : 0u;
+        }
+        const uint32_t e2 = 256u * j + threadIdx.x;
+        s_x[e2 + e2 / PER] = x[j];
+    }
+    __syncthreads();
+    uint32_t mine[PER], acc = 0;  // (a tile's tokens: below 2^32)
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        mine[i] = s_x[threadIdx.x * (PER + 1u) + i];
+        acc += mine[i];
+    }
+    const uint32_t inc = wave_iscan_add(acc);
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    uint32_t run = inc - acc;
+    for (int v = 0; v < wave_id(); v++) run += s_w[v];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        s_x[threadIdx.x * (PER + 1u) + i] = run;
+        run += mine[i];
+    }
+    const unsigned long long tile_total = (unsigned long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    // ---- the tile's offset: look back ---------------------------------------------------------------
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        constexpr unsigned long long VAL = (1ull << 62) - 1ull;
+        if (lane == 0)
+            __hip_atomic_store((enc_desc_t *)&desc[tile], ((tile == 0 ? 2ull : 1ull) << 62) | tile_total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long excl = 0;
+        long long idx = (long long)tile - 1;  // the nearest tile not yet accounted for
+        while (idx >= 0) {
+            const long long mine_i = idx - lane;
+            unsigned long long d = 2ull << 62;  // (before the first tile: a prefix of nothing)
+            if (mine_i >= 0) {
+                do {
+                    d = __hip_atomic_load((enc_desc_t *)&desc[mine_i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d >> 62) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (true);
+            }
+            const unsigned long long pre = __ballot((d >> 62) == 2ull);
+            const int stop = pre ? __ffsll((long long)pre) - 1 : 64;  // the nearest tile that knows its prefix
+            unsigned long long v = lane <= stop ? (d & VAL) : 0ull;
+#pragma unroll
+            for (int k = 32; k >= 1; k >>= 1) v += __shfl_xor(v, k);
+            excl += v;
+            if (pre) break;
+            idx -= 64;
+        }
+        if (lane == 0) {
+            if (tile != 0)
+                __hip_atomic_store((enc_desc_t *)&desc[tile], (2ull << 62) | (excl + tile_total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if ((uint64_t)(tile + 1) * ENC_PLACE_TILE >= n_chunks) *total = excl + tile_total;
+        }
+    }
+    __syncthreads();
+    const unsigned long long tile0 = s_excl;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint64_t c = base + 256u * j;
+        if (c >= n_chunks) break;
+        const uint32_t e2 = 256u * j + threadIdx.x;
+        const unsigned long long d0 = tile0 + s_x[e2 + e2 / PER];
+        out_off[c] = d0;
+        const uint32_t L = x[j];
+        if (L == 0) continue;
+        if (sl[j] == ENC_NOSLOT) {
+            const uint64_t s0 = off[c];
+            for (uint32_t k = 0; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
+            continue;
+        }
+        const uint4 t4 = *reinterpret_cast<const uint4 *>(tab[sl[j]].tok);
+        const uint32_t t[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (k < L) out[d0 + k] = (int32_t)t[k];
+        if (L > 4) {
+            const uint64_t s0 = off[tab[sl[j]].rep];
+            for (uint32_t k = 4; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
+        }
     }
 }
 

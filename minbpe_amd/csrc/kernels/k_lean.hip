@@ -134,20 +134,6 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
 }
 
 // ---------------------------------------------------------------------------
-// unsigned maximum over the wave, every lane gets it (DPP scan + readlane: VALU speed)
-__device__ __forceinline__ uint32_t wave_umax_dpp(uint32_t x) {
-    int v = (int)x;
-    auto umax = [](int p, int q) { return (int)max((uint32_t)p, (uint32_t)q); };
-    v = umax(v, dpp_mov<0x111>(0, v));
-    v = umax(v, dpp_mov<0x112>(0, v));
-    v = umax(v, dpp_mov<0x114>(0, v));
-    v = umax(v, dpp_mov<0x118>(0, v));
-    v = umax(v, dpp_mov<0x142, 0xA>(0, v));
-    v = umax(v, dpp_mov<0x143, 0xC>(0, v));
-    return lane_last((uint32_t)v);
-}
-
-// ---------------------------------------------------------------------------
 // table update, a != b (delta format B: vector 0 = SL, vector 1 = SR, st->adj; see k_slots2.hip).
 // Workgroups [0, na): one token per thread.  Workgroups [na, grid): commit the staged headers; the
 // first of them also makes the new stream length and the iteration's record.

@@ -304,13 +304,15 @@ def _train_pairs(native, n, nm, seed, kind):
 
 
 # cache: (enc_cache, enc_hash_bits) -- the chunk cache on (default) / off; on with the chunk hash cut to 3 bits,
-# so that thousands of different chunks share a slot and only the byte comparison keeps them apart
-ENC_VARIANTS = [(1, 0), (0, 0), (1, 3)]
+# so that thousands of different chunks share a slot and only the byte comparison keeps them apart; bits = -1:
+# the default cache with the three-launch offsets + placement instead of the chained pass (enc_chain = 0)
+ENC_VARIANTS = [(1, 0), (0, 0), (1, 3), (1, -1)]
 
 
 def _enc_variant(engine, cache, bits):
     engine.set_option("enc_cache", cache)
-    engine.set_option("enc_hash_bits", bits)
+    engine.set_option("enc_hash_bits", max(bits, 0))
+    engine.set_option("enc_chain", 0 if bits < 0 else 1)
 
 
 @pytest.mark.parametrize("cache,bits", ENC_VARIANTS)

@@ -39,6 +39,13 @@ bench)
 encode)
     timeout -k 5 600 python bench.py --workload encode --steps 3 --warmup 1 ${ENCODE_ARGS} > gpurun_out/${TAG}_encode.json 2> gpurun_out/${TAG}_encode.err
     echo "encode rc=$?"; cut -c1-1800 gpurun_out/${TAG}_encode.json; tail -3 gpurun_out/${TAG}_encode.err ;;
+encprof)  # rocprofv3 kernel trace of the encode workload
+    rm -rf gpurun_out/${TAG}_eprof
+    timeout -k 5 500 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_eprof -o run -- python bench.py --workload encode --steps 2 --warmup 1 --cpu-iters 0 > gpurun_out/${TAG}_eprof.log 2>&1
+    echo "encprof rc=$?"
+    db=$(ls gpurun_out/${TAG}_eprof/*/*.db gpurun_out/${TAG}_eprof/*.db 2>/dev/null | head -1)
+    [ -n "$db" ] && python tools/rocpd_stats.py $db > gpurun_out/${TAG}_encode_kernel_stats.csv && grep -i "k_enc\|k_scan\|k_encode" gpurun_out/${TAG}_encode_kernel_stats.csv | sed 's/(.*)"/"/' | cut -c1-120
+    rm -rf gpurun_out/${TAG}_eprof ;;
 py)     # PY="tools/x.py args": any bounded python step
     timeout -k 5 ${PY_TIMEOUT:-600} python $PY > gpurun_out/${TAG}_py.log 2>&1; echo "py rc=$?"; tail -${PY_TAIL:-30} gpurun_out/${TAG}_py.log ;;
 esac
