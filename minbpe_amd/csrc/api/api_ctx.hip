@@ -812,9 +812,15 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
 // sparse one -- tests drive the sparse kernel and the index through streams of a few slots.)
 int plan_pass2(bpe_ctx *c, bool *sparse_out) {
     const uint32_t T = (uint32_t)c->slot_T;
-    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || T > 16 * SPARSE_GRID);
-    const bool sparse = can_index && (c->use_sparse == 2 || (c->last_count != ~0ull &&
-                                                             c->last_count * (uint64_t)c->sparse_ratio < T));
+    // A stream of a few thousand slots: visiting them all costs nothing, an iteration is launches and round
+    // trips only -- and the index is what lets a lean iteration select from the table update's records and
+    // chain tied merges (k_sel_lean): indexed as soon as the iterations are lean ones (measured on the
+    // de-duplicated 1 GB input, 1127 slots: 27.7 k -> 48.2 k merges/s)
+    const bool small = T <= 16 * SPARSE_GRID;
+    const bool can_index = c->use_sparse && T > 0 && (c->use_sparse == 2 || !small || c->lean);
+    const bool rare = c->last_count != ~0ull && (small ? c->last_count <= (uint64_t)c->lean_count
+                                                       : c->last_count * (uint64_t)c->sparse_ratio < T);
+    const bool sparse = can_index && (c->use_sparse == 2 || rare);
     // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
     // one go by, the index is rebuilt so that those marks do not pile up)
     if (sparse && (!c->idx_live || c->idx_rebuild)) TRY(index_build(c));
