@@ -142,6 +142,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->prof_stride = (int)value;
     } else if (!strcmp(name, "lean_select")) {
         c->lean_select = value != 0;
+    } else if (!strcmp(name, "aa_sparse")) {
+        c->aa_sparse = value != 0;
     } else if (!strcmp(name, "lean_chain")) {
         c->lean_chain = value != 0;
     } else if (!strcmp(name, "lean_sum")) {

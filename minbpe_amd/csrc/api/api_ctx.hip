@@ -68,6 +68,7 @@ struct bpe_ctx {
     uint32_t *d_removed = nullptr;            // [256 * REMOVED_STRIDE] removal counters of a merge pass
     uint64_t idx_cap_words = 0;               // index groups allocated
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
+    bool last_aa_indexed = false;             // the last general-path iteration enqueued had its a == b pass keep the index current
     bool idx_live = false;                    // the index describes the current slots
     int use_sparse = 1;                       // 0: never take the sparse pass (experiments)
     int rep_max = 8;                          // log2 of the most delta-vector replicas a pass may use (experiments)
@@ -86,6 +87,7 @@ struct bpe_ctx {
     int lean_grid = 256;                      // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
+    int aa_sparse = 1;                        // option "aa_sparse": a sparse iteration's a == b pass works through a candidate list and keeps the index current itself (no rebuild after it)
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
     int lean_sum = 1;                         // option "lean_sum": 1 = k_sel_lean (selection from the table update's per-wave records) whenever they are current
     uint4 *d_lean_sum = nullptr;              // [4][LEAN_SUM_CAP] those records (k_lean.hip)
@@ -468,6 +470,10 @@ SlotRefH stream_ref_h(const bpe_ctx *c) {
     return r;
 }
 
+// single-GPU training, index live: the a == b pass of a sparse iteration visits the slots k_select lists
+// for it and adds the pairs it creates to the index (no "visit always" marks, no rebuild afterwards)
+inline bool aa_through_index(const bpe_ctx *c) { return c->aa_sparse && c->idx_live && !c->dp_active; }
+
 // K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
 // this rank's candidate)
 int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
@@ -488,6 +494,7 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     C.enable = sparse_next ? 1u : 0u;  // the block that makes the pair final lists the slots a sparse pass visits
     C.tie_index = (c->slotted && c->slot2 && c->idx_live && c->tie_index) ? 1u : 0u;
     C.tie_window = c->tie_window ? 1u : 0u;
+    C.aa = (sparse_next && aa_through_index(c)) ? 1u : 0u;
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
@@ -514,6 +521,7 @@ int launch_rowsel_lean(bpe_ctx *c) {
     C.enable = 0;
     C.tie_index = 1;
     C.tie_window = 0;
+    C.aa = 0;
     hipLaunchKernelGGL(k_rowsel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag);
     LAUNCHCHK(c, "k_rowsel_lean");
@@ -534,6 +542,7 @@ int launch_sel_lean(bpe_ctx *c) {
     C.enable = 0;
     C.tie_index = 1;
     C.tie_window = 0;
+    C.aa = 0;
     // the update before this selection made token vcur - 1: one record per wave of its token workgroups
     const uint32_t nwv = ((c->vcur + 255u) / 256u) * 4u;
     hipLaunchKernelGGL(k_sel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
@@ -893,8 +902,13 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     B.vcap = dl;
     B.sdesc = c->d_desc;
     B.epoch = c->epoch;
-    B.dirty = c->idx_live ? c->d_idx_dirty : nullptr;
+    const bool aas = sparse && aa_through_index(c);
+    B.dirty = (c->idx_live && !aas) ? c->d_idx_dirty : nullptr;
     B.removed = c->d_removed;
+    B.cand = aas ? c->d_cand : nullptr;
+    B.idx = aas ? c->d_idx : nullptr;
+    B.istride = (uint32_t)c->idx_cap_words;
+    c->last_aa_indexed = aas;
     // (a resident grid of single-wave workgroups -- a slot may wait for its predecessor's carry:
     // ~140 VGPRs admit three waves per SIMD, twelve per CU; eight are launched)
     hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 8u * (unsigned)c->num_cus))), dim3(64), 0,

@@ -109,6 +109,7 @@ extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
             C.T = (uint32_t)c->slot_T;
             C.enable = 1;
             C.tie_index = C.tie_window = 0;
+            C.aa = 0;
             hipLaunchKernelGGL(k_dp_cand, dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
             LAUNCHCHK(c, "k_dp_cand");
         }

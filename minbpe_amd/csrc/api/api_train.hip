@@ -60,6 +60,9 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     // second form: which iterations flipped the header arrays (a sparse pass does not), so that an
     // early stop can undo the flips of the no-op iterations enqueued behind the failing one
     std::vector<uint8_t> hdr_flip(form2 ? (size_t)num_merges : 0, 0);
+    // ... and which general-path iterations had an a == b pass that keeps the index current by itself (if the
+    // pair turns out to have a == b, no rebuild is owed)
+    std::vector<uint8_t> aa_indexed(form2 ? (size_t)num_merges : 0, 0);
     if (slots) TRY(form2 ? slots2_enter(c) : slots_enter(c));
     // The device writes one IterRec per iteration into pinned host memory; the
     // host runs up to `depth` iterations ahead and only ever waits on those
@@ -105,7 +108,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         cur_len = r->new_len;
         c->n = cur_len;  // tighter launch bound for what is enqueued next
         c->last_count = r->count;  // counts never grow: an upper bound for every later merge
-        if (r->a == r->b && c->idx_live) c->idx_rebuild = true;
+        if (r->a == r->b && c->idx_live && !(form2 && aa_indexed[(size_t)j])) c->idx_rebuild = true;
         // sites per pass ~ the merged pair's count: fewer sites, fewer replicas to fold
         // few sites -> few same-address atomics -> fewer replicas to fold (measured: going
         // below 32 while a pass still has tens of thousands of sites slows the merge pass)
@@ -175,6 +178,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 TRY(launch_merge2(c, 256u + (uint32_t)i, i, c->h_rec, sparse));
                 hdr_flip[(size_t)i] = (uint8_t)(c->mq != mq0);
                 lean_kind[(size_t)i] = 0;
+                aa_indexed[(size_t)i] = (uint8_t)c->last_aa_indexed;
             } else if (c->slotted)
                 TRY(launch_merge_slot(c, 256u + (uint32_t)i, i, c->h_rec));
             else

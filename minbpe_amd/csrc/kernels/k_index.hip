@@ -46,7 +46,10 @@ struct CandArgs {
     uint32_t enable;     // 0: this iteration's a != b pass is a dense one
     uint32_t tie_index;  // the index is live: block 0 of k_select breaks ties through it
     uint32_t tie_window; // block 0 first looks through the first TIE_WIN slots by itself (experiment)
+    uint32_t aa;         // a list for a pair with a == b too (its pass then works through the list, k_merge_aa)
 };
+// a == b: the pass charges every pair to its LEFT element, so the slot before a candidate owes table
+// updates too (the pair that ends at the candidate's first word): the list holds both.
 __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st, uint32_t a, uint32_t b) {
     __shared__ uint32_t s_wtot[16];
     __shared__ uint32_t s_base;
@@ -62,6 +65,10 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
         uint32_t m[GP] = {0, 0, 0, 0};
         uint32_t c = 0;
         const uint32_t w4 = base + GP * threadIdx.x;
+        uint32_t mnext = 0;  // (a == b) the mask word after my four
+        if (a == b && w4 + GP < nwords && !all)
+            mnext = (C.idx[(size_t)h1 * C.stride + w4 + GP] & C.idx[(size_t)h2 * C.stride + w4 + GP] &
+                     C.idx[(size_t)h3 * C.stride + w4 + GP]) | C.dirty[w4 + GP];
         if (w4 < nwords && !all) {
             // (rows are 16-byte aligned and padded: the stride is a multiple of 4 groups)
             const uint4 r1 = *reinterpret_cast<const uint4 *>(C.idx + (size_t)h1 * C.stride + w4);
@@ -72,6 +79,12 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
             m[1] = (r1.y & r2.y & r3.y) | d.y;
             m[2] = (r1.z & r2.z & r3.z) | d.z;
             m[3] = (r1.w & r2.w & r3.w) | d.w;
+            if (a == b) {  // slot s is visited if s or s + 1 is a candidate
+                m[0] |= (m[0] >> 1) | (m[1] << 31);
+                m[1] |= (m[1] >> 1) | (m[2] << 31);
+                m[2] |= (m[2] >> 1) | (m[3] << 31);
+                m[3] |= (m[3] >> 1) | (mnext << 31);
+            }
         }
 #pragma unroll
         for (int u = 0; u < GP; u++) {

@@ -6,6 +6,7 @@
 
 #include "../bpe_device.h"
 #include "k_common.hip"
+#include "k_index.hip"
 #include "k_select.hip"
 
 namespace bpe {
@@ -391,7 +392,9 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                                              uint32_t newid, uint32_t *__restrict__ dst_tile,
                                              uint32_t *s_wsum, uint32_t *__restrict__ delta,
                                              uint32_t vcap, int own_len, uint32_t *kept_out,
-                                             bool *changed_out, uint32_t *__restrict__ hdr4 = nullptr) {
+                                             bool *changed_out, uint32_t *__restrict__ hdr4 = nullptr,
+                                             uint32_t *__restrict__ idx = nullptr, uint32_t istride = 0,
+                                             uint32_t tself = 0, uint32_t tnext = 0xFFFFFFFFu) {
     const int lane = lane_id(), wave = wave_id();
     uint32_t mb[MJ], mp[MJ], kb[MJ], ex[MJ];
     uint32_t carry = 0, chg = 0;
@@ -518,8 +521,24 @@ __device__ __forceinline__ void tile_rewrite(const Tile &t, uint32_t s, uint32_t
                         const uint32_t Xq = Mk ? X[k + 2] : X[k + 1];
                         const uint32_t Mq = Mk ? ((Mx >> (k + 3)) & 1u) : Mkp1;
                         if (!(Xq & FLAG)) {
-                            if (Mk) atomicAdd(&delta[3 * (size_t)vcap + (Mq ? newid : (Xq & IDMASK))], wt);
-                            else if (Mq) atomicAdd(&delta[2 * (size_t)vcap + (X[k] & IDMASK)], wt);
+                            // idx: the inverted slot index (k_index.hip) learns the pair this creates -- in
+                            // the filter of the slot that owns its left element (tself) and, when its right
+                            // element is the next slot's, in that one's too (a boundary pair is known to both)
+                            const int qpos = qw + j * 256 + k;
+                            if (Mk) {
+                                const uint32_t y = Mq ? newid : (Xq & IDMASK);
+                                atomicAdd(&delta[3 * (size_t)vcap + y], wt);
+                                if (idx) {
+                                    index_add(idx, istride, tself, newid, y);
+                                    if (qpos + 2 >= own_len && tnext != 0xFFFFFFFFu) index_add(idx, istride, tnext, newid, y);
+                                }
+                            } else if (Mq) {
+                                atomicAdd(&delta[2 * (size_t)vcap + (X[k] & IDMASK)], wt);
+                                if (idx) {
+                                    index_add(idx, istride, tself, X[k] & IDMASK, newid);
+                                    if (qpos + 1 >= own_len && tnext != 0xFFFFFFFFu) index_add(idx, istride, tnext, X[k] & IDMASK, newid);
+                                }
+                            }
                         }
                     }
                 }

@@ -505,7 +505,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
             s_pair[2] = (uint32_t)st->b;
         }
         __syncthreads();
-        if (C.enable && s_pair[0] && s_pair[1] != s_pair[2]) build_cand_list(C, st, s_pair[1], s_pair[2]);
+        if (C.enable && s_pair[0] && (s_pair[1] != s_pair[2] || C.aa)) build_cand_list(C, st, s_pair[1], s_pair[2]);
     } else if (threadIdx.x == 0) {
         bool ok = false, leave = false;
         for (uint32_t spins = 0; spins < LOOKBACK_SPINS; spins++) {
@@ -592,7 +592,7 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
         }
     }
     __syncthreads();
-    if (C.enable && s_pair[0] && s_pair[1] != s_pair[2]) build_cand_list(C, st, s_pair[1], s_pair[2]);
+    if (C.enable && s_pair[0] && (s_pair[1] != s_pair[2] || C.aa)) build_cand_list(C, st, s_pair[1], s_pair[2]);
 }
 
 // K2 for lean iterations (k_lean.hip) with the index live: ONE workgroup, and nothing of the

@@ -519,8 +519,12 @@ struct AaArgs {
     uint32_t vcap;
     unsigned long long *sdesc;
     uint32_t epoch;
-    uint32_t *dirty;          // index live: [slot / 32], set for the slots this pass rewrites
+    uint32_t *dirty;          // index live and not kept current by this pass: [slot / 32], set for the slots it rewrites
     uint32_t *removed;        // [256]
+    const uint32_t *cand;     // the slots to visit (st->ncand of them, from k_select: the slots whose filter admits
+                              // (a,a), the slot before each, the marked ones), or nullptr: every slot
+    uint32_t *idx;            // the index, kept current by this pass (the pairs it creates enter the filters), or nullptr
+    uint32_t istride;
 };
 
 __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A, const uint32_t a) {
@@ -658,7 +662,8 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
     uint32_t kept = 0;
     bool changed = false;
     uint32_t *dst = (cur ? A.w0 : A.w1) + (size_t)t * TILE2;  // the OTHER buffer
-    tile_rewrite<true, true, 1>(tl, s, a, b, A.newid, dst, s_wsum, A.delta, A.vcap, len, &kept, &changed, s_hdr);
+    tile_rewrite<true, true, 1>(tl, s, a, b, A.newid, dst, s_wsum, A.delta, A.vcap, len, &kept, &changed, s_hdr, A.idx,
+                                A.istride, t, s_ctx[6]);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (changed) {
@@ -703,6 +708,14 @@ k_merge_aa(AaArgs A) {
     if (st->status || !st->found) return;  // (a missing decision is reported by the a != b kernel)
     const uint32_t a = (uint32_t)st->a;
     if (a != (uint32_t)st->b) return;
+    if (A.cand) {  // (ascending, like the slots themselves: a wait for a predecessor's carry ends)
+        const uint32_t n = st->ncand;
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+            merge_aa_tile(A.cand[i], A, a);
+            __syncthreads();
+        }
+        return;
+    }
     for (uint32_t t = blockIdx.x; t < A.T; t += gridDim.x) {
         merge_aa_tile(t, A, a);
         __syncthreads();

@@ -85,8 +85,8 @@ def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golde
 # defers them); the general path alone, without and with the index
 # (lean 3: lean iterations that select from the whole row-maxima array, k_rowsel_lean, not from the table
 # update's per-wave records)
-# (lean 4: every lean iteration selects, no chained merges)
-FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4)]
+# (lean 4: every lean iteration selects, no chained merges; lean 5: a == b passes over every slot + index rebuild)
+FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5)]
 
 
 @pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
@@ -107,6 +107,7 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
     engine.set_option("lean", 1 if lean >= 3 else lean)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
+    engine.set_option("aa_sparse", 0 if lean == 5 else 1)
     try:
         engine.load_bytes(data, offs)
         _check_digests(engine.train(g["merges"]), g)
@@ -115,6 +116,7 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
         engine.set_option("lean", 1)
         engine.set_option("lean_sum", 1)
         engine.set_option("lean_chain", 1)
+        engine.set_option("aa_sparse", 1)
 
 
 def test_cross_mode_large_chunked(native, engine):

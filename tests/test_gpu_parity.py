@@ -120,10 +120,11 @@ def test_train_golden_cases(golden, engine, native):
 # general path) once the host has seen a count <= lean_count, 2 = from the first merge on, 0 = never,
 # 3 = as 2 but every selection reads the whole row-maxima array (k_rowsel_lean; option lean_sum = 0)
 # instead of the previous table update's per-wave records (k_sel_lean, the default), 4 = as 2 but every
-# iteration selects (option lean_chain = 0: no tied pair is merged off an earlier selection's list)
+# iteration selects (option lean_chain = 0: no tied pair is merged off an earlier selection's list), 5 = as 2
+# but a == b passes visit every slot and mark what they rewrite for an index rebuild (option aa_sparse = 0)
 VARIANTS = [(0, 0, 0, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 1), (1, 1, 0, 1, 1), (0, 1, 0, 1, 1), (1, 0, 2, 1, 1),
             (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2),
-            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4)]
+            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4), (1, 0, 2, 2, 5)]
 
 
 def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
@@ -134,6 +135,7 @@ def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
     engine.set_option("lean", 2 if lean >= 3 else lean)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
+    engine.set_option("aa_sparse", 0 if lean == 5 else 1)
 
 
 def reset_variant(engine):
