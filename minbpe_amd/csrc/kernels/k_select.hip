@@ -595,68 +595,6 @@ k_select(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, 
     if (C.enable && s_pair[0] && (s_pair[1] != s_pair[2] || C.aa)) build_cand_list(C, st, s_pair[1], s_pair[2]);
 }
 
-// K2 for lean iterations (k_lean.hip) with the index live: ONE workgroup, and nothing of the
-// decision goes through memory until it is final -- the status words are read together with the row
-// maxima, ties are broken through the index (tie_by_index), one burst of stores ends the kernel.
-// What this workgroup cannot settle alone (more than TIE_CAP tied pairs, short slots about, a tied
-// pair the index does not lead to) is handed to the general path: st->defer = 2, as for a == b.
-__global__ void __launch_bounds__(1024)
-k_select_lean(const uint32_t *__restrict__ rowmax, const uint32_t *__restrict__ mat, uint32_t stride,
-              uint32_t vcur, DevState *st, SlotRefH ref, CandArgs C) {
-    __shared__ int32_t s_tied[2 * TIE_CAP];
-    __shared__ uint32_t s_bits[2048];
-    __shared__ uint32_t s_state[3];
-    if (threadIdx.x == 0) {
-        s_state[0] = st->status;
-        s_state[1] = st->defer;
-        s_state[2] = st->gap;
-    }
-    for (uint32_t i = threadIdx.x; i < 2048; i += 1024) s_bits[i] = 0;
-    uint32_t M, nt;
-    uint32_t rm[SEL_RPT];
-    select_load(rowmax, vcur, rm);
-    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm,
-                SelExtra{nullptr, 0u, nullptr, nullptr, nullptr});  // (its barriers publish s_state too)
-    if (s_state[0] || s_state[1]) return;
-    if (M == 0) {
-        if (threadIdx.x == 0) {
-            st->status = ST_EMPTY;
-            st->count = 0;
-            st->found = 0;
-            st->sel_tie = 0;
-        }
-        return;
-    }
-    uint32_t pi = 0;
-    unsigned long long pos = NOPOS;
-    bool decided = (nt == 1);
-    if (!decided && nt <= TIE_CAP && s_state[2] == 0) {
-        const unsigned long long key = tie_by_index(ref, C, s_tied, nt);
-        if (key != NOPOS) {
-            pi = (uint32_t)(key & 127u);
-            pos = key >> 7;
-            decided = true;
-        }
-    }
-    if (threadIdx.x == 0) {
-        st->adj = 0;  // (the previous pass's format-B "adjacent sites" count was folded into the table)
-        st->count = M;
-        st->ntied = nt;
-        st->firstpos = pos;
-        st->sel_tie = 0;
-        if (decided) {
-            st->a = s_tied[2 * pi];
-            st->b = s_tied[2 * pi + 1];
-            st->fin_a = s_tied[2 * pi];
-            st->fin_b = s_tied[2 * pi + 1];
-            st->found = 1;
-        } else {
-            st->found = 0;
-            st->defer = 2;
-        }
-    }
-}
-
 // The pair to merge as every kernel after K2 sees it: decided by k_select, or (sharded streams)
 // the pair found at the earliest tied position.
 __device__ __forceinline__ bool resolved_pair(const DevState *st, const uint32_t *__restrict__ ids,

@@ -194,7 +194,7 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
                 assert stats["lean"] == 0 and stats["deferred"] == 0
             elif lean >= 2:
                 # every merge is a lean iteration or was handed back to the general path: all a == b ones
-                # are, and (index live) those whose tie k_select_lean could not settle by itself
+                # are, and (index live) those whose tie the lean selection could not settle by itself
                 assert stats["lean"] + stats["deferred"] == nm and stats["deferred"] >= n_same
                 if sparse != 2:
                     assert stats["deferred"] == n_same
