@@ -51,8 +51,14 @@ int bpe_set_stream(bpe_ctx *ctx, void *hip_stream);
  * cross-checks and measurement; the defaults are the fast ones):
  *   "slots"  0 contiguous stream | 1 4096-id slots | 2 one-wave slots, in place (default)
  *   "sparse" 0 every pass visits every slot | 1 auto (default) | 2 always through the index
- *   "sparse_ratio" (2), "tie_index" (1), "rep_min" (4), "rep_max" (8: log2 of delta replicas),
- *   "lds_delta" (1), "depth" (8: iterations the host runs ahead), "merge", "k1", "lb_tune". */
+ *   "lean"   0 every iteration takes the general five-launch path | 1 three-launch lean iterations once a
+ *            pair's count is <= "lean_count" (2^20; default) | 2 from the first merge on (tests)
+ *   "lean_sum" (1: a lean selection works from the previous table update's per-wave records),
+ *   "lean_chain" (1: tied pairs are merged off the list one selection made), "aa_sparse" (1: an a == b
+ *   pass visits the slots the index names and keeps the index current), "enc_cache" (1), "enc_chain" (1),
+ *   "sparse_ratio" (1), "tie_index" (1), "rep_min" (4), "rep_max" (8: log2 of delta replicas),
+ *   "lds_delta" (1), "depth" (8: iterations the host runs ahead), "prof_stride" (64), "merge", "k1",
+ *   "lb_tune". */
 int bpe_set_option(bpe_ctx *ctx, const char *name, int64_t value);
 
 /* ---- input ----------------------------------------------------------------- */
