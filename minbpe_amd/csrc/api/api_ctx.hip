@@ -975,10 +975,11 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
     const uint32_t nwords = (T + 31) / 32;
-    // a resident grid: one 1024-thread workgroup per CU at most; a workgroup takes at least 16 mask
-    // words (index) or 16 slots (no index)
-    const uint32_t units = use_index ? nwords : T;
-    const unsigned g = std::max(1u, std::min((units + 15) / 16, (unsigned)c->lean_grid));
+    // a resident grid: one 1024-thread workgroup per CU at most; a workgroup takes at least one mask word
+    // (index: 32 slots, two per wave -- a stream of 40 k slots must not end up on a third of the CUs: cfg2's
+    // lean passes were 1.4x slower than the sparse kernel they replaced while a workgroup took 16 words) or
+    // 16 slots (no index: one per wave)
+    const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->idx_live)
         hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
