@@ -115,16 +115,21 @@ k_encode_short(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ o
 // is keyed by a hash and compared byte for byte with the slot's owner -- and a chunk the table has
 // no room for is simply encoded on its own.
 //   k_enc_pass1  every chunk finds (or claims, compare-and-swap) its slot of an open-addressing
-//                table.  Up to 7 bytes: the thread whose claim succeeds is the owner and encodes on
-//                the spot (one chunk per lane, as k_encode_short).  8..32 bytes: the slot's owner is
-//                the lowest chunk index that hashed there (atomicMin), settled when the launch ends
-//   k_enc_pass2  8..32 bytes: the owner encodes; every other occurrence compares its bytes with
+//                table.  Up to 7 bytes: the thread whose claim succeeds is the owner, and the wave
+//                encodes its owners one after the other (encode_wave).  8..32 bytes: packed into a
+//                per-workgroup list, hashed and probed by the workgroup's first waves; the slot's
+//                owner is the lowest chunk index that hashed there (atomicMin), settled when the
+//                launch ends
+//   k_enc_pass2  over those lists: the owner encodes; every other occurrence compares its bytes with
 //                the owner's (a different chunk behind the same hash: encoded on its own)
-//   k_enc_count  per chunk, the token count of its slot; then the usual scan, and
-//   k_enc_place  copies the tokens: the first four sit in the slot itself
-// Hot words: a slot is read before it is written (relaxed agent-scope loads: L2-served, past the
-// per-CU L1 that another CU's insert never refreshes), so a word that occurs five million times
-// costs a handful of atomics, not five million on one address.
+//   k_enc_place_chained  per chunk, the token count of its slot; the scan over the counts (a chained
+//                scan over tiles) and the copy of the tokens, the first four of which sit in the slot
+//                itself -- one pass.  (k_enc_lens + k_scan_top + k_enc_place: the same in three
+//                launches, option enc_chain = 0.)
+// Hot words: a slot is read before it is written -- a plain load first (a key never changes once it is
+// there, so a cached copy that shows it is as good as memory), a relaxed agent-scope load past the
+// per-CU L1 only when the slot looks empty -- so a word that occurs five million times costs a handful
+// of atomics, not five million on one address.
 constexpr uint32_t ENC_NOSLOT = 0xFFFFFFFFu;
 constexpr uint32_t ENC_PROBES = 64;  // slots tried before a chunk goes uncached
 constexpr uint32_t ENC_KEYBYTES = 7;  // chunks up to this length are their own key

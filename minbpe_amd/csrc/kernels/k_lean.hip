@@ -1,7 +1,7 @@
-// k_lean.hip -- the training iteration once a merged pair has few sites ("lean" iterations: the
-// last ~29,000 of the 31,744 merges of a 1 GB / vocab-32000 run, where a pass rewrites a few
-// hundred slots and nothing is bound by bytes any more, only by the number of launches and of
-// dependent memory round trips inside them -- a launch costs ~2 us plus ~1.7 us per round trip).
+// k_lean.hip -- the training iteration once a merged pair has few sites ("lean" iterations: 31,445
+// of the 31,744 merges of a 1 GB / vocab-32000 run; for most of them a pass rewrites a few hundred
+// slots and nothing is bound by bytes any more, only by the number of launches and of dependent
+// memory round trips inside them -- a launch costs ~2 us plus ~1.7 us per round trip).
 // Three launches instead of five, each a short chain:
 //   k_sel_lean       the pair of this merge from a TWO-LEVEL view of the row maxima: the table update
 //                    of the previous merge left one record per 64 rows (their maximum, who attains
@@ -11,7 +11,10 @@
 //                    five): workgroups 1.. re-scan those and hand each result over as two tagged
 //                    8-byte words (no fence, no flag: the data is the flag).  Ties through the index
 //                    (tie_by_index, k_select.hip); nothing of the decision goes through memory until
-//                    it is final.
+//                    it is final.  When the tie is among few pairs it lines ALL of them up in the
+//                    order of their first occurrences (the chain, DevState::chain): the reference
+//                    merges them in that order for as long as their counts stand, so the launches
+//                    of the following iterations only take the next pair off the chain.
 //   k_rowsel_lean    the same without the records (the first lean iteration after one of the general
 //                    path): workgroups 1.. re-scan rows a, b, Z and the flagged rows, workgroup 0
 //                    reads the whole row-maxima array meanwhile and leaves those rows out.
@@ -43,7 +46,7 @@ namespace bpe {
 
 constexpr uint32_t NOROW = 0xFFFFFFFFu;
 constexpr int DBITS_WORDS = 2048;     // one bit per row (vocab <= 65536)
-constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one k_rowsel_lean launch hands to its deciding workgroup
+constexpr uint32_t LEAN_EX_CAP = 1024;  // rows one selection launch (k_sel_lean, k_rowsel_lean) hands to its deciding workgroup
 // Per-wave records of k_apply_lean (wave w of the token workgroups = tokens [64w, 64w + 64)), read by
 // k_sel_lean: four arrays of LEAN_SUM_CAP uint4,
 //   [0][w] = {maximum of the row maxima of rows 64w.. (rows a, b, Z and the rows flagged by this update
