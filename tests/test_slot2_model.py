@@ -203,3 +203,108 @@ def test_slot_pass_equals_plain_merge_and_recount(seed):
         assert all(v >= 0 for v in table.values())
         assert {p: c for p, c in table.items() if c} == get_stats(got), (seed, step)
         next_id += 1
+
+
+# ---------------------------------------------------------------------------
+# a == b passes over a candidate list (k_merge_aa with AaArgs::cand, k_index.hip build_cand_list): format A
+# charges every destroyed / created pair to its LEFT element, so besides the slots that hold a pair (a,a)
+# -- a boundary pair is in the filter of both slots it touches -- the slot BEFORE each of them can owe a
+# table update.  The claim: no other slot changes or owes anything.
+
+def aa_mbits(ids, a):
+    """m[k] = 1 iff a site (a,a) starts at k under the reference's left-to-right pairing (base.py:25-41)"""
+    m, k = [0] * len(ids), 0
+    while k + 1 < len(ids):
+        if ids[k] == a and ids[k + 1] == a:
+            m[k] = 1
+            k += 2
+        else:
+            k += 1
+    return m
+
+
+def aa_slot_effects(ids, m, cuts, Z):
+    """per slot: (changed, format-A delta entries) with every position's share charged as tile_rewrite does"""
+    n = len(ids)
+    owner = []
+    for t, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+        owner += [t] * (hi - lo)
+    T = len(cuts) - 1
+    changed = [False] * T
+    delta = [dict() for _ in range(T)]
+
+    def add(t, vec, tok):
+        delta[t][(vec, tok)] = delta[t].get((vec, tok), 0) + 1
+
+    for k in range(n):
+        t = owner[k]
+        mk, mkm1 = m[k], (m[k - 1] if k > 0 else 0)
+        mkp1 = m[k + 1] if k + 1 < n else 0
+        if mk or mkm1:
+            changed[t] = True  # the slot holds a site's first word, or drops its second
+        if k + 1 < n and not mk:  # an old pair that is not the site itself
+            if mkm1:
+                add(t, "decR", ids[k + 1])
+            elif mkp1:
+                add(t, "decL", ids[k])
+        if not mkm1:  # an output element: the pair it forms with the next output element
+            q = k + (2 if mk else 1)
+            if q < n:
+                mq = m[q]
+                if mk:
+                    add(t, "incR", Z if mq else ids[q])
+                elif mq:
+                    add(t, "incL", ids[k])
+    return changed, delta
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_aa_pass_candidates_are_the_filter_hits_and_their_predecessors(seed):
+    rng = random.Random(9000 + seed)
+    k = rng.choice([2, 3, 5])
+    n = rng.randrange(40, 400)
+    ids = [rng.randrange(k) for _ in range(n)]
+    a, Z = 0, 99
+    cuts = [0]
+    while cuts[-1] < n:  # slots of 3..9 words (no short slots: the kernels visit everything otherwise)
+        cuts.append(min(n, cuts[-1] + rng.randrange(3, 10)))
+    if cuts[-1] - cuts[-2] < 3 and len(cuts) > 2:
+        cuts.pop(-2)
+    T = len(cuts) - 1
+    owner = []
+    for t, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+        owner += [t] * (hi - lo)
+    # the index: slot t knows pair (x, y) at positions (p, p + 1) if it owns p -- and p + 1's slot knows it too
+    cand = set()
+    for p in range(n - 1):
+        if ids[p] == a and ids[p + 1] == a:
+            cand.add(owner[p])
+            cand.add(owner[p + 1])
+    visit = cand | {t - 1 for t in cand if t > 0}
+    m = aa_mbits(ids, a)
+    changed, delta = aa_slot_effects(ids, m, cuts, Z)
+    for t in range(T):
+        if t not in visit:
+            assert not changed[t] and not delta[t], (seed, t, delta[t])
+    # ... and the deltas of the visited slots alone are the whole table update (brute-force recount)
+    before, after = {}, {}
+    for x, y in zip(ids, ids[1:]):
+        before[(x, y)] = before.get((x, y), 0) + 1
+    out, p = [], 0
+    while p < n:
+        if m[p]:
+            out.append(Z)
+            p += 2
+        else:
+            out.append(ids[p])
+            p += 1
+    for x, y in zip(out, out[1:]):
+        after[(x, y)] = after.get((x, y), 0) + 1
+    got = dict(before)
+    for t in visit:
+        for (vec, tok), c in delta[t].items():
+            pair = {"decL": (tok, a), "decR": (a, tok), "incL": (tok, Z), "incR": (Z, tok)}[vec]
+            got[pair] = got.get(pair, 0) + (c if vec.startswith("inc") else -c)
+    got.pop((a, a), None)  # (the merged pair itself is retired by the row scan, not by the delta vectors)
+    after_wo = {p_: c for p_, c in after.items() if p_ != (a, a)}
+    assert {p_: c for p_, c in got.items() if c} == after_wo, seed
