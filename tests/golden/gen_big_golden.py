@@ -6,8 +6,8 @@ consumed by tests/test_gpu_big.py and bench.py.
 
     python tests/golden/gen_big_golden.py cfg2      # Basic, 100 MB, 3840 merges
     python tests/golden/gen_big_golden.py cfg3s     # GPT-4 split, 150 MB, 8192 merges
-    python tests/golden/gen_big_golden.py basic1g   # Basic, 1 GB, first 1024 merges
-    python tests/golden/gen_big_golden.py regex1g   # GPT-4 split, 1 GB, first 1024 merges (the headline input)
+    python tests/golden/gen_big_golden.py basic1g   # Basic, 1 GB, first 2048 merges
+    python tests/golden/gen_big_golden.py regex1g   # GPT-4 split, 1 GB, first 2048 merges (the headline input)
     python tests/golden/gen_big_golden.py full16r   # GPT-4 split, 16 MB, ALL 31,744 merges of vocab 32000
     python tests/golden/gen_big_golden.py full12b   # Basic, 12 MB, ALL 31,744 merges
 
@@ -40,8 +40,8 @@ CASES = {
     # name: (bytes, seed, merges, chunked)
     "cfg2": (100_000_000, 1, 3840, False),
     "cfg3s": (150_000_000, 2, 8192, True),
-    "basic1g": (1_000_000_000, 2, 1024, False),
-    "regex1g": (1_000_000_000, 2, 1024, True),
+    "basic1g": (1_000_000_000, 2, 2048, False),
+    "regex1g": (1_000_000_000, 2, 2048, True),
     # the WHOLE vocab range of the headline (31,744 merges) on inputs the oracle finishes in
     # under an hour: mass low-count ties, V > 8448, every select/apply path above merge 8192
     "full16r": (16_000_000, 11, 31744, True),
