@@ -10,6 +10,7 @@ consumed by tests/test_gpu_big.py and bench.py.
     python tests/golden/gen_big_golden.py regex1g   # GPT-4 split, 1 GB, first 2048 merges (the headline input)
     python tests/golden/gen_big_golden.py full16r   # GPT-4 split, 16 MB, ALL 31,744 merges of vocab 32000
     python tests/golden/gen_big_golden.py full12b   # Basic, 12 MB, ALL 31,744 merges
+    python tests/golden/gen_big_golden.py full8r    # GPT-4 split, 8 MB (another seed), ALL 31,744 merges
 
 The GPT-4 split of `cfg3s` is done here with the `regex` module exactly as the
 reference does (regex.py:19,41), NOT with the native splitter: the digest of the
@@ -46,6 +47,7 @@ CASES = {
     # under an hour: mass low-count ties, V > 8448, every select/apply path above merge 8192
     "full16r": (16_000_000, 11, 31744, True),
     "full12b": (12_000_000, 12, 31744, False),
+    "full8r": (8_000_000, 21, 31744, True),   # a second text for the whole range (made after the chained merges went in)
 }
 STEP = {"basic1g": 16, "regex1g": 16}
 

@@ -90,7 +90,7 @@ FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5)]
 
 
 @pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
-@pytest.mark.parametrize("name", ["full16r", "full12b"])
+@pytest.mark.parametrize("name", ["full16r", "full12b", "full8r"])
 def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_golden, name, sparse, lean):
     """The headline's whole vocabulary range (vocab 32000 = 31,744 merges) on inputs the oracle finishes in
     half an hour: 16 MB with the GPT-4 split (regex.py:49-63) and 12 MB as one stream (basic.py:31-42).
