@@ -43,6 +43,10 @@ def _load():
     lib.orc_merge_chunks.argtypes = [p, p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32]
     lib.orc_train.restype = C.c_int64
     lib.orc_train.argtypes = [p, C.c_uint64, p, C.c_uint64, C.c_int32, p, p, p, p]
+    lib.orc_train_weighted.restype = C.c_int64
+    lib.orc_train_weighted.argtypes = [p, C.c_uint64, p, C.c_uint64, p, C.c_int32, p, p, p, p]
+    lib.orc_dedup.restype = C.c_int64
+    lib.orc_dedup.argtypes = [p, p, C.c_uint64, p, p, C.c_uint64]
     lib.orc_encode.restype = C.c_int64
     lib.orc_encode.argtypes = [p, C.c_int32, p, C.c_uint64, p, C.c_uint64, p, p]
     _lib = lib
@@ -97,9 +101,36 @@ def merge_chunks(ids, offsets, pair, idx):
     return buf[:n].copy(), off
 
 
-def train(data: bytes, num_merges: int, offsets=None, raise_on_empty=True):
+def dedup(data: bytes, offsets):
+    """Distinct chunks of a chunk list in order of first appearance: returns
+    (data of the distinct chunks, their start offsets, weights[uint64], first_idx[uint64])."""
+    lib = _load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    off = _offsets(len(buf), offsets)
+    nc = len(off) - 1
+    first = np.empty(max(nc, 1), np.uint64)
+    wt = np.empty(max(nc, 1), np.uint64)
+    nd = lib.orc_dedup(_ptr(buf) if len(buf) else None, _ptr(off), nc, _ptr(first), _ptr(wt), nc)
+    if nd < 0:
+        raise RuntimeError(f"orc_dedup failed: {nd}")
+    first, wt = first[:nd].copy(), wt[:nd].copy()
+    starts = off[first.astype(np.int64)]
+    lens = off[first.astype(np.int64) + 1] - starts
+    doff = np.zeros(nd, np.uint64)
+    if nd > 1:
+        np.cumsum(lens[:-1], out=doff[1:])
+    out = np.empty(int(lens.sum()), np.uint8)
+    # gather the distinct chunks' bytes (vectorised: position j of the output belongs to chunk d)
+    if nd:
+        owner = np.repeat(np.arange(nd), lens.astype(np.int64))
+        out[:] = buf[(starts[owner] + (np.arange(len(out), dtype=np.uint64) - doff[owner])).astype(np.int64)]
+    return out.tobytes(), doff, wt, first
+
+
+def train(data: bytes, num_merges: int, offsets=None, raise_on_empty=True, weights=None):
     """Returns (pairs[(a,b)...], counts[...], lens[...]).  `offsets` = chunk
-    start offsets into data (None = one chunk = BasicTokenizer)."""
+    start offsets into data (None = one chunk = BasicTokenizer).  `weights` (one uint64 per
+    chunk): chunk c stands for weights[c] identical copies (orc_train_weighted)."""
     lib = _load()
     buf = np.frombuffer(data, dtype=np.uint8)
     off = _offsets(len(buf), offsets)
@@ -108,9 +139,16 @@ def train(data: bytes, num_merges: int, offsets=None, raise_on_empty=True):
     counts = np.zeros(nm, np.uint64)
     lens = np.zeros(nm, np.uint64)
     status = C.c_int32(0)
-    done = lib.orc_train(_ptr(buf) if len(buf) else None, len(buf), _ptr(off), len(off) - 1,
-                         num_merges, _ptr(pairs), _ptr(counts), _ptr(lens),
-                         C.byref(status))
+    if weights is not None:
+        wt = np.ascontiguousarray(weights, dtype=np.uint64)
+        assert len(wt) == len(off) - 1
+        done = lib.orc_train_weighted(_ptr(buf) if len(buf) else None, len(buf), _ptr(off),
+                                      len(off) - 1, _ptr(wt), num_merges, _ptr(pairs),
+                                      _ptr(counts), _ptr(lens), C.byref(status))
+    else:
+        done = lib.orc_train(_ptr(buf) if len(buf) else None, len(buf), _ptr(off), len(off) - 1,
+                             num_merges, _ptr(pairs), _ptr(counts), _ptr(lens),
+                             C.byref(status))
     if status.value == -2 and raise_on_empty:
         raise OracleEmptyStats("max() arg is an empty sequence")
     if status.value not in (0, -2):

@@ -11,6 +11,12 @@ consumed by tests/test_gpu_big.py and bench.py.
     python tests/golden/gen_big_golden.py full16r   # GPT-4 split, 16 MB, ALL 31,744 merges of vocab 32000
     python tests/golden/gen_big_golden.py full12b   # Basic, 12 MB, ALL 31,744 merges
     python tests/golden/gen_big_golden.py full8r    # GPT-4 split, 8 MB (another seed), ALL 31,744 merges
+    python tests/golden/gen_big_golden.py regex1g_w # the headline input, ALL 31,744 merges, through the WEIGHTED
+                                                    # oracle (orc_train_weighted on the distinct chunks, in order
+                                                    # of first appearance, each with its multiplicity); the
+                                                    # `regex1g` digests above (plain loop, 2.6 h) are its first
+                                                    # 2048 merges and must come out identical -- checked here
+    python tests/golden/gen_big_golden.py cfg3s_w   # the same cross-check at 150 MB: weighted == plain, all 8192
 
 The GPT-4 split of `cfg3s` is done here with the `regex` module exactly as the
 reference does (regex.py:19,41), NOT with the native splitter: the digest of the
@@ -47,7 +53,10 @@ CASES = {
     # under an hour: mass low-count ties, V > 8448, every select/apply path above merge 8192
     "full16r": (16_000_000, 11, 31744, True),
     "full12b": (12_000_000, 12, 31744, False),
-    "full8r": (8_000_000, 21, 31744, True),   # a second text for the whole range (made after the chained merges went in)
+    "full8r": (8_000_000, 21, 31744, True),
+    # the weighted form: (bytes, seed, merges, chunked, name of the plain case whose digests it must reproduce)
+    "regex1g_w": (1_000_000_000, 2, 31744, True, "regex1g"),
+    "cfg3s_w": (150_000_000, 2, 8192, True, "cfg3s"),   # a second text for the whole range (made after the chained merges went in)
 }
 STEP = {"basic1g": 16, "regex1g": 16}
 
@@ -67,8 +76,60 @@ def regex_offsets(data: bytes) -> np.ndarray:
     return np.frombuffer(offs, dtype=np.uint64).copy()
 
 
+def main_weighted(name):
+    """All merges of a chunked case through orc_train_weighted.  The split comes from the native
+    scanner here (the `regex` module needs > 10 minutes and tens of GB for 1 GB of text) and must
+    reproduce the offsets digest the `regex` module gave for the plain case."""
+    from helpers import first_divergence
+    from minbpe_amd import _native
+    nbytes, seed, merges, _, plain = CASES[name]
+    with open(OUT) as f:
+        allg = json.load(f)
+    ref = allg[plain]
+    t0 = time.time()
+    data = synth_text(nbytes, seed)
+    assert hashlib.sha256(data).hexdigest() == ref["data_sha256"]
+    offs = np.ascontiguousarray(_native.split_offsets(data, 4), dtype=np.uint64)   # 4 = the GPT-4 pattern
+    assert len(offs) == ref["n_chunks"]
+    assert hashlib.sha256(offs.tobytes()).hexdigest() == ref["offsets_sha256"], "split differs from the regex module's"
+    print(f"{name}: {len(offs)} chunks == the regex module's, {time.time() - t0:.0f}s", flush=True)
+    t1 = time.time()
+    ddata, doffs, wts, _first = oracle.dedup(data, offs)
+    entry = {"bytes": nbytes, "seed": seed, "merges": merges, "chunked": True, "weighted": True,
+             "data_sha256": ref["data_sha256"], "n_chunks": ref["n_chunks"],
+             "offsets_sha256": ref["offsets_sha256"], "n_distinct": int(len(doffs)),
+             "distinct_bytes": len(ddata), "weight_sum": int(wts.sum()),
+             "dedup_seconds": round(time.time() - t1, 1)}
+    assert entry["weight_sum"] == ref["n_chunks"]
+    print(f"{name}: {len(doffs)} distinct chunks, {len(ddata)} bytes, {entry['dedup_seconds']}s", flush=True)
+    del data, offs
+    t1 = time.time()
+    pairs, counts, lens = oracle.train(ddata, merges, doffs, weights=wts)
+    entry["oracle_seconds"] = round(time.time() - t1, 1)
+    entry["done"] = len(pairs)
+    entry["first"] = [list(p) for p in pairs[:4]]
+    entry["last"] = [list(p) for p in pairs[-2:]]
+    entry["final_len"] = lens[-1]
+    entry["step"] = 256
+    entry["digests"] = checkpoint_digests(pairs, counts, lens, 256)
+    # the plain oracle's digests of the same input (the reference's own loop, hours of CPU) must be a prefix
+    k = ref["done"]
+    same = checkpoint_digests(pairs[:k], counts[:k], lens[:k], ref["step"])
+    bad = first_divergence(same, ref["digests"])
+    assert bad is None and same[-1] == ref["digests"][-1], f"weighted oracle != plain oracle at merge {bad}"
+    entry["equals_plain_oracle_first"] = k
+    allg[name] = entry
+    with open(OUT + ".tmp", "w") as f:
+        json.dump(allg, f, indent=1)
+    os.replace(OUT + ".tmp", OUT)
+    print(f"{name}: {len(pairs)} merges, weighted oracle {entry['oracle_seconds']}s, first {k} == plain oracle, "
+          f"final digest {entry['digests'][-1][1]}", flush=True)
+
+
 def main():
     name = sys.argv[1]
+    if len(CASES[name]) == 5:
+        return main_weighted(name)
     nbytes, seed, merges, chunked = CASES[name]
     t0 = time.time()
     data = synth_text(nbytes, seed)
