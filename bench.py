@@ -41,6 +41,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
 HBM_COPY_GBPS = 6290.0  # measured float4 copy, same guide
+PROFILE_ROUND = "r4"      # prefix of the committed rocprofv3 summaries under profiles/ this line attaches
 
 WORKLOADS = {
     "regex1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=True,
@@ -246,12 +247,12 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     whole = {"device_ms_per_iteration": None, "traffic": None, "frac": None}
     dev_ms = sum(v["ms"] for v in breakdown.values())
     whole["device_ms_per_iteration"] = round(dev_ms / num_merges, 5)
-    pmc_file = os.path.join(ROOT, "profiles", f"r3_{name}_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}_pmc.json")
     if os.path.exists(pmc_file):
         with open(pmc_file) as f:
             pmc = json.load(f)
         if pmc.get("source_hash") == source_hash() and pmc.get("launches"):
-            src = f"profiles/r3_{name}_pmc.json (source_hash {pmc['source_hash']})"
+            src = f"profiles/{PROFILE_ROUND}_{name}_pmc.json (source_hash {pmc['source_hash']})"
             if hot == "merge":
                 per = pmc["hbm_bytes_total"] / pmc["launches"]
                 roofline["traffic"] = int(per)
@@ -375,72 +376,125 @@ def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters):
     return out
 
 
-def run_encode_workload(eng, steps, warmup, barrier):
-    """configs[4] shape: batch encode of documents with an own vocabulary (cl100k ranks are
-    not available offline).  Device-only and PCIe-inclusive rates; cpu_baseline = oracle.encode."""
+ENCODE_DOCS = 1_000_000   # BASELINE.json configs[4] / SURVEY 8d cfg5: a batch of 1M documents
+ENCODE_TEXT_BYTES = 760_000_000  # synth_text(seed 4) holds ~1.45 documents per KB: a little over 1M documents
+
+
+def encode_docs():
+    """1,000,000 documents = synth_text (seed 4) cut at its blank lines."""
     import numpy as np
-    import minbpe_amd
-    from minbpe_amd import _native
-    import oracle
-    train_bytes, vocab = 50_000_000, 16384
-    tdata = minbpe_amd.synth_text(train_bytes, 4)
-    toffs = _native.split_offsets(tdata, 4)
-    eng.load_bytes(tdata, toffs)
-    pairs = eng.train(vocab - 256)["pairs"]
-    data = minbpe_amd.synth_text(600_000_000, 5)
+    data = synth_cached(ENCODE_TEXT_BYTES, 4)
     arr = np.frombuffer(data, dtype=np.uint8)
     nl = np.flatnonzero((arr[:-1] == 10) & (arr[1:] == 10)).astype(np.uint64) + 2
     doc_offs = np.unique(np.concatenate([np.zeros(1, np.uint64), nl[nl < len(data)]]))
+    if len(doc_offs) > ENCODE_DOCS:
+        data = data[:int(doc_offs[ENCODE_DOCS])]
+        doc_offs = doc_offs[:ENCODE_DOCS]
+    return data, doc_offs
+
+
+def cfg3_merges(eng):
+    """the merges of BASELINE.json configs[2] (the headline training run), trained here when the headline did
+    not just produce them"""
+    wl = WORKLOADS["regex1g"]
+    data, offs, _ = make_input(wl)
+    eng.load_bytes(data, offs)
+    return eng.train(wl["vocab"] - 256)["pairs"]
+
+
+def run_encode_workload(eng, steps, warmup, barrier, pairs=None, tables=("cfg3", "cl100k_sized")):
+    """configs[4]: batch encode of 1,000,000 documents, GPT-4 split, with (1) the merges of configs[2]
+    (vocab 32000, as SURVEY 8d specifies: cl100k ranks are not available offline) and (2) a rank table of
+    cl100k_base's size built around them (100,000 merges, non-consecutive ids up to 301,000: tests/helpers.py
+    cl100k_shaped_table).  Device-only and PCIe-inclusive rates; the whole batch is compared with oracle.encode."""
+    import numpy as np
+    from minbpe_amd import _native
+    import oracle
+    from helpers import cl100k_shaped_table
+    if pairs is None:
+        pairs = cfg3_merges(eng)
+    data, doc_offs = encode_docs()
     offs, _first = _native.split_docs(data, doc_offs, 4)
     n_docs = len(doc_offs)
-    for _ in range(warmup):
-        eng.encode_batch(pairs, None, data, offs)
-    eng.set_option("profile", 2)
-    eng.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ids, out_offs = eng.encode_batch(pairs, None, data, offs)
-    barrier()
-    dt = (time.perf_counter() - t0) / steps
-    prof = eng.prof_read()["encode"]
-    eng.set_option("profile", 0)
-    dev_s = prof["ms"] * 1e-3 / max(steps, 1)
-    # the WHOLE batch against the oracle (oracle.encode does ~60 MB/s on one core: ~10 s for 600 MB),
-    # compared by digest of the ids and of the per-chunk output offsets
-    t0 = time.perf_counter()
-    oid, ooff = oracle.encode(pairs, data, offs)
-    ct = time.perf_counter() - t0
-    equal = bool(len(oid) == len(ids) and hashlib.sha256(np.ascontiguousarray(oid, dtype=np.int32).tobytes()).digest()
-                 == hashlib.sha256(np.ascontiguousarray(ids, dtype=np.int32).tobytes()).digest()
-                 and np.array_equal(np.asarray(ooff, dtype=np.uint64), np.asarray(out_offs, dtype=np.uint64)))
-    alg = int(len(data) + 4 * len(ids))
-    ach = alg / dev_s / 1e9 if dev_s else 0.0
-    return {
-        "workload": f"batch encode, {n_docs} documents / {len(data)} B synthetic UTF-8 / {len(offs)} GPT-4-split "
-                    f"chunks, own vocabulary of {vocab} trained on {train_bytes} B",
-        "docs_per_s_device": round(n_docs / dev_s, 1) if dev_s else None,
-        "tokens_per_s_device": round(len(ids) / dev_s, 1) if dev_s else None,
-        "text_GBps_device": round(len(data) / dev_s / 1e9, 2) if dev_s else None,
-        "docs_per_s_pcie_inclusive": round(n_docs / dt, 1), "tokens_per_s_pcie_inclusive": round(len(ids) / dt, 1),
-        "ms_per_step": round(dt * 1e3, 2), "device_ms_per_step": round(dev_s * 1e3, 3), "tokens": int(len(ids)),
-        "parity": {"bytes_checked": len(data), "chunks_checked": int(len(offs)), "tokens_checked": int(len(oid)),
-                   "equal_oracle": equal},
-        # algorithmic bytes of the encode loop (DESIGN 4): the text in, 4 bytes per token out
-        "alg_bytes_per_step": alg,
-        "roofline": {
-            "bound": "hbm", "kernel": "bpe_encode_batch on the device: k_enc_pass1 + k_enc_pass2 + k_enc_place_chained "
-                                      "(hipEvents around all of them)",
-            "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-            "achieved_kind": "algorithmic (text bytes in + 4 B per token out) / hipEvent time",
-            "traffic": None,
-            "note": "every distinct chunk is encoded once and copied to its other occurrences (DESIGN 4); what is left "
-                    "is one random 32-byte table access per chunk in each pass (its slot, then its owner's tokens) "
-                    "-- sectors served by L2 / Infinity Cache, not counted in the algorithmic bytes -- and pass 1's "
-                    "instruction issue"},
-        "cpu_baseline": {"value": round(len(data) / ct, 1), "unit": "bytes/s", "cores": 1, "kind": "port",
-                         "sample": f"oracle.encode on the whole batch ({len(data)} bytes in {ct:.1f} s)", **host_info()},
-    }
+    out = {}
+    for tname in tables:
+        if tname == "cfg3":
+            tp, mids = np.asarray(pairs, dtype=np.int32), None
+            tdesc = f"the {len(tp)} merges of the headline training run (vocab {256 + len(tp)})"
+        else:
+            tp, mids = cl100k_shaped_table(pairs, 100_000, 9, "sparse")
+            tdesc = (f"a rank table of cl100k_base's size: {len(tp)} merges (the headline's {len(pairs)} spread over "
+                     f"them, the rest pairs of tokens defined so far), ids 1000 + 3 rank (up to {int(mids.max())})")
+        for _ in range(warmup):
+            eng.encode_batch(tp, mids, data, offs)
+        eng.set_option("profile", 2)
+        eng.prof_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ids, out_offs = eng.encode_batch(tp, mids, data, offs)
+        barrier()
+        dt = (time.perf_counter() - t0) / steps
+        prof = eng.prof_read()["encode"]
+        eng.set_option("profile", 0)
+        dev_s = prof["ms"] * 1e-3 / max(steps, 1)
+        # the WHOLE batch against the oracle (oracle.encode does ~70 MB/s on one core), compared by digest of
+        # the ids and of the per-chunk output offsets
+        t0 = time.perf_counter()
+        oid, ooff = oracle.encode(tp, data, offs, merge_ids=mids)
+        ct = time.perf_counter() - t0
+        equal = bool(len(oid) == len(ids)
+                     and hashlib.sha256(np.ascontiguousarray(oid, dtype=np.int32).tobytes()).digest()
+                     == hashlib.sha256(np.ascontiguousarray(ids, dtype=np.int32).tobytes()).digest()
+                     and np.array_equal(np.asarray(ooff, dtype=np.uint64), np.asarray(out_offs, dtype=np.uint64)))
+        alg = int(len(data) + 4 * len(ids))
+        ach = alg / dev_s / 1e9 if dev_s else 0.0
+        traffic, tsrc = encode_traffic(tname)
+        r = {
+            "workload": f"batch encode, {n_docs} documents / {len(data)} B synthetic UTF-8 (seed 4) / {len(offs)} "
+                        f"GPT-4-split chunks, {tdesc}",
+            "docs_per_s_device": round(n_docs / dev_s, 1) if dev_s else None,
+            "tokens_per_s_device": round(len(ids) / dev_s, 1) if dev_s else None,
+            "text_GBps_device": round(len(data) / dev_s / 1e9, 2) if dev_s else None,
+            "docs_per_s_pcie_inclusive": round(n_docs / dt, 1), "tokens_per_s_pcie_inclusive": round(len(ids) / dt, 1),
+            "ms_per_step": round(dt * 1e3, 2), "device_ms_per_step": round(dev_s * 1e3, 3), "tokens": int(len(ids)),
+            "max_token_id": int(ids.max()) if len(ids) else None,
+            "parity": {"bytes_checked": len(data), "chunks_checked": int(len(offs)), "tokens_checked": int(len(oid)),
+                       "equal_oracle": equal},
+            # algorithmic bytes of the encode loop (DESIGN 4): the text in, 4 bytes per token out
+            "alg_bytes_per_step": alg,
+            "roofline": {
+                "bound": "hbm", "kernel": "bpe_encode_batch on the device: k_enc_pass1 + k_enc_pass2 + k_enc_place_chained "
+                                          "(hipEvents around all of them)",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "achieved_kind": "algorithmic (text bytes in + 4 B per token out) / hipEvent time",
+                "traffic": traffic, "traffic_source": tsrc,
+                "note": "every distinct chunk is encoded once and copied to its other occurrences (DESIGN 4); what is left "
+                        "is one random 32-byte table access per chunk in each pass (its slot, then its owner's tokens) "
+                        "-- sectors served by L2 / Infinity Cache, not counted in the algorithmic bytes -- and pass 1's "
+                        "instruction issue"},
+            "cpu_baseline": {"value": round(len(data) / ct, 1), "unit": "bytes/s", "cores": 1, "kind": "port",
+                             "sample": f"oracle.encode on the whole batch ({len(data)} bytes in {ct:.1f} s)", **host_info()},
+        }
+        del ids, out_offs, oid, ooff
+        out[tname] = r
+    first = out[tables[0]]
+    for tname in tables[1:]:
+        first[tname] = out[tname]
+    return first
+
+
+def encode_traffic(tname):
+    """HBM bytes of one encode step from the committed PMC pass of this command (profiles/), attached only
+    when it was measured on these library sources."""
+    f = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_encode_pmc.json")
+    if not os.path.exists(f):
+        return None, None
+    with open(f) as fh:
+        pmc = json.load(fh)
+    if pmc.get("source_hash") != source_hash() or tname not in pmc.get("hbm_bytes_per_step", {}):
+        return None, "committed PMC profile is from other library sources: not attached"
+    return int(pmc["hbm_bytes_per_step"][tname]), f"profiles/{PROFILE_ROUND}_encode_pmc.json (source_hash {pmc['source_hash']})"
 
 
 def main():
@@ -546,8 +600,8 @@ def main():
         secondary = {}
         for sname in [s for s in sec.split(",") if s and s != "none"]:
             try:
-                if sname == "encode":  # BASELINE.json configs[4] shape (see run_encode_workload)
-                    secondary[sname] = run_encode_workload(eng, 2, 1, barrier)
+                if sname == "encode":  # BASELINE.json configs[4] (see run_encode_workload)
+                    secondary[sname] = run_encode_workload(eng, 2, 1, barrier, plain_ref[0] if plain_ref else None)
                     continue
                 if WORKLOADS[sname].get("dedup"):
                     secondary[sname] = run_dedup_workload(dict(WORKLOADS[sname]), eng, args.secondary_steps,

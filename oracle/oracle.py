@@ -49,6 +49,8 @@ def _load():
     lib.orc_dedup.argtypes = [p, p, C.c_uint64, p, p, C.c_uint64]
     lib.orc_encode.restype = C.c_int64
     lib.orc_encode.argtypes = [p, C.c_int32, p, C.c_uint64, p, C.c_uint64, p, p]
+    lib.orc_encode_ids.restype = C.c_int64
+    lib.orc_encode_ids.argtypes = [p, p, C.c_int32, p, C.c_uint64, p, C.c_uint64, p, p]
     _lib = lib
     return lib
 
@@ -157,17 +159,25 @@ def train(data: bytes, num_merges: int, offsets=None, raise_on_empty=True, weigh
     return pl, [int(c) for c in counts[:done]], [int(x) for x in lens[:done]]
 
 
-def encode(merges, data: bytes, offsets=None):
-    """merges: list of (a, b) in rank order.  Returns (ids, out_offsets)."""
+def encode(merges, data: bytes, offsets=None, merge_ids=None):
+    """merges: list of (a, b) in rank order (an (M, 2) int32 array will do).  merge_ids: the id each
+    merge writes (None: 256 + rank).  Returns (ids, out_offsets)."""
     lib = _load()
     buf = np.frombuffer(data, dtype=np.uint8)
     off = _offsets(len(buf), offsets)
     m = np.ascontiguousarray(np.array(merges, dtype=np.int32).reshape(-1))
     out = np.empty(max(len(buf), 1), np.int32)
     oo = np.empty(len(off), np.uint64)
-    n = lib.orc_encode(_ptr(m) if len(m) else None, len(merges),
-                       _ptr(buf) if len(buf) else None, len(buf), _ptr(off),
-                       len(off) - 1, _ptr(out), _ptr(oo))
+    if merge_ids is not None:
+        mi = np.ascontiguousarray(merge_ids, dtype=np.int32)
+        assert len(mi) == len(merges)
+        n = lib.orc_encode_ids(_ptr(m) if len(m) else None, _ptr(mi) if len(mi) else None, len(merges),
+                               _ptr(buf) if len(buf) else None, len(buf), _ptr(off),
+                               len(off) - 1, _ptr(out), _ptr(oo))
+    else:
+        n = lib.orc_encode(_ptr(m) if len(m) else None, len(merges),
+                           _ptr(buf) if len(buf) else None, len(buf), _ptr(off),
+                           len(off) - 1, _ptr(out), _ptr(oo))
     if n < 0:
         raise RuntimeError(f"orc_encode failed: {n}")
     return out[:n].copy(), oo

@@ -49,6 +49,52 @@ def toy_rank_table(base_tok, seed):
     return perm, ranks
 
 
+def cl100k_shaped_table(base_pairs, total, seed, ids="rank"):
+    """A rank table of cl100k_base's SIZE (cl100k: 100,000 merges, ids up to 100,255; its ranks are not
+    available offline) around a trained merge list: the `base_pairs` (ids 256 + position) keep their order
+    but are spread over `total` ranks, the ranks in between are filled with merges of tokens defined so
+    far (half of them pairs of early tokens, which do occur in text and change how it encodes).
+    ids = "rank": merge r writes id 256 + r (RegexTokenizer; None is returned for the id list);
+    ids = "sparse": merge r writes 1000 + 3 r (a merges dict whose values are not consecutive, as
+    GPT4Tokenizer's are ranks: gpt4.py:65).  Returns (pairs as an (total, 2) int32 array, ids or None)."""
+    rng = np.random.default_rng(seed)
+    nb = len(base_pairs)
+    assert total >= nb
+    real_at = np.zeros(total, dtype=bool)
+    real_at[rng.choice(total, nb, replace=False)] = True
+    id_of = (lambda r: 256 + r) if ids == "rank" else (lambda r: 1000 + 3 * r)
+    new_of_old = list(range(256)) + [0] * nb      # old id (256 + k) -> id in the big table
+    old_of_new = {i: i for i in range(256)}
+    real_old = {tuple(p) for p in base_pairs}
+    defined = list(range(256))
+    used = set()
+    out = np.empty((total, 2), dtype=np.int32)
+    k = 0
+    coin = rng.random(total)
+    pick = rng.integers(0, 1 << 30, size=(total, 2))
+    for r in range(total):
+        if real_at[r]:
+            a, b = base_pairs[k]
+            pair = (new_of_old[a], new_of_old[b])
+            new_of_old[256 + k] = id_of(r)
+            old_of_new[id_of(r)] = 256 + k
+            k += 1
+        else:
+            j = 0
+            while True:
+                lim = min(len(defined), 400) if coin[r] < 0.5 else len(defined)
+                pair = (defined[(pick[r, 0] + j) % lim], defined[(pick[r, 1] + 7 * j) % lim])
+                old = (old_of_new.get(pair[0]), old_of_new.get(pair[1]))
+                if pair not in used and old not in real_old:
+                    break
+                j += 1
+        used.add(pair)
+        out[r] = pair
+        defined.append(id_of(r))
+    mids = None if ids == "rank" else np.array([id_of(r) for r in range(total)], dtype=np.int32)
+    return out, mids
+
+
 def checkpoint_digests(pairs, counts, lens, step):
     """[[k, sha256-prefix of the first k merges], ...] every `step` merges and at the end.
     The digest covers pairs, counts AND stream lengths, as little-endian int64 triples

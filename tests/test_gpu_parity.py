@@ -363,6 +363,55 @@ def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits)
     assert np.array_equal(out_off, exp_off)
 
 
+_BIG_TABLE = {}
+
+
+def _cl100k_sized(engine, native, kind):
+    """100,000 merges around 20,000 trained ones (trained on the GPU: training parity has its own tests;
+    what is compared below is encode against oracle.encode for the same table)."""
+    from helpers import cl100k_shaped_table
+    if "base" not in _BIG_TABLE:
+        text = native.synth_text(6_000_000, 41)
+        data, offs = text, native.split_offsets(text, 4)
+        engine.load_bytes(data, offs)
+        _BIG_TABLE["base"] = engine.train(20_000)["pairs"]
+    if kind not in _BIG_TABLE:
+        _BIG_TABLE[kind] = cl100k_shaped_table(_BIG_TABLE["base"], 100_000, 9, kind)
+    return _BIG_TABLE[kind]
+
+
+@pytest.mark.parametrize("cache,bits", ENC_VARIANTS)
+@pytest.mark.parametrize("ids_kind", ["rank", "sparse"])
+def test_encode_batch_with_a_cl100k_sized_rank_table(engine, native, cache, bits, ids_kind):
+    """BASELINE.json configs[4] is GPT4Tokenizer.encode with cl100k_base: 100,000 merges, token ids up to
+    100,255 (gpt4.py:60-79).  The ranks themselves are not available offline; a table of that size is
+    (helpers.cl100k_shaped_table): more than 65,535 ranks, ids >= 65,536 (ids_kind "rank": 256 + rank;
+    "sparse": a merges dict with non-consecutive values, ids up to 301,000), through every encoder variant."""
+    pairs, mids = _cl100k_sized(engine, native, ids_kind)
+    assert len(pairs) == 100_000 and native._lib.bpe_encode_uses_16bit(None, len(pairs)) == 0
+    text = native.synth_text(1_500_000, 43) + " don't  stop 12345 ünïcödé 😉 ".encode() * 50
+    offs = native.split_offsets(text, 4)
+    exp_ids, exp_off = oracle.encode(pairs, text, offs, merge_ids=mids)
+    assert int(exp_ids.max()) >= 65536 and len(np.unique(exp_ids)) > 5000
+    _enc_variant(engine, cache, bits)
+    try:
+        ids, out_off = engine.encode_batch(pairs, mids, text, offs)
+    finally:
+        _enc_variant(engine, 1, 0)
+    assert np.array_equal(ids, exp_ids)
+    assert np.array_equal(out_off, exp_off)
+
+
+def test_encode_one_stream_with_a_cl100k_sized_rank_table(engine, native):
+    """BasicTokenizer.encode (one chunk: the stream-wide rounds, k_min_rank + merge) with the same table"""
+    pairs, mids = _cl100k_sized(engine, native, "sparse")
+    text = native.synth_text(60_000, 44)
+    exp_ids, exp_off = oracle.encode(pairs, text, None, merge_ids=mids)
+    ids, out_off = engine.encode_batch(pairs, mids, text, None)
+    assert np.array_equal(ids, exp_ids) and np.array_equal(out_off, exp_off)
+    assert int(exp_ids.max()) >= 65536
+
+
 def test_encode_batch_long_and_short_chunks_mixed(engine, native):
     # chunk lengths around ENC_LMAX (32) and far beyond it, runs of one symbol, empty batch
     pairs = _train_pairs(native, 200_000, 500, 23, "regex")

@@ -239,3 +239,32 @@ def test_big_golden_weighted_entries_continue_the_plain_ones():
         assert common and all(pd[k] == d for k, d in common)
         assert w["equals_plain_oracle_first"] == p["done"] and w["done"] == w["merges"]
     assert big["regex1g_w"]["done"] == 31744
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_oracle_encode_with_a_cl100k_sized_table_against_live_reference(native):
+    """oracle.encode with 100,000 ranks -- ids 256 + rank up to 100,255, and a merges dict whose values are
+    not consecutive (what GPT4Tokenizer's are) -- against the reference's own _encode_chunk
+    (regex.py:92-121) given the same merges dict."""
+    import numpy as np
+    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from minbpe import RegexTokenizer as RefRegex
+    from helpers import cl100k_shaped_table, split_chunks
+    text = native.synth_text(400_000, 51).decode()
+    data, offs = split_chunks(text)
+    d2, o2, wts, _ = oracle.dedup(data, offs)
+    base = oracle.train(d2, 3000, o2, weights=wts)[0]
+    probe = native.synth_text(30_000, 52).decode() + " don't  stop 12345 ünïcödé 😉"
+    pd, po = split_chunks(probe)
+    for kind in ("rank", "sparse"):
+        pairs, mids = cl100k_shaped_table(base, 100_000, 5, kind)
+        ref = RefRegex()
+        vals = mids if mids is not None else 256 + np.arange(len(pairs))
+        ref.merges = {(int(a), int(b)): int(v) for (a, b), v in zip(pairs, vals)}
+        assert len(ref.merges) == len(pairs)  # (the table has no repeated pair)
+        want = ref.encode_ordinary(probe)
+        got, _ = oracle.encode(pairs, pd, po, merge_ids=mids)
+        assert got.tolist() == want
+        assert max(want) >= 65536 and len(set(want)) > 500
