@@ -174,6 +174,11 @@ int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_i
                      const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
                      uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
                      uint64_t *n_out);
+/* Whether bpe_encode_batch's encoder WITHOUT the chunk cache (option enc_cache = 0) keeps tokens and ranks
+ * in 16-bit columns for this merge table (host logic, no GPU): every rank below 65535 and every token id
+ * -- merge_ids[r], or 256 + r when merge_ids is NULL -- below 65536.  The default (cached) encoder is
+ * 32-bit throughout. */
+int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M);
 
 /* ---- decode -------------------------------------------------------- */
 /* `b"".join(vocab[idx] for idx in ids)` (basic.py:51-55, regex.py:78-90, gpt4.py:87-92)
@@ -208,9 +213,6 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
 /* How the last bpe_train ran its merge passes: out[0] = dense passes (every slot of the stream
  * is visited), out[1] = sparse passes (only the slots the inverted slot index cannot rule out),
  * out[2] = builds of that index, out[3] = slots of the stream at the end. */
-/* Whether bpe_encode_batch runs its 16-bit path for this merge table (host logic, no GPU): every
- * rank below 65535 and every token id -- merge_ids[r], or 256 + r when merge_ids is NULL -- below 65536. */
-int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M);
 int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
 /* The same, extended: out[4] = lean iterations among the passes above (three launches per merge, the
  * pair table updated at the merge sites themselves; option "lean"), out[5] = iterations a lean pass

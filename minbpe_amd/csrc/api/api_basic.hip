@@ -30,6 +30,9 @@ int bpe_create(int device_id, bpe_ctx **out) {
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
         return bail("hipGetDeviceProperties", e);
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // the lean iterations' kernels hold up to LEAN_LDS_BYTES of static LDS per workgroup (k_lean.hip): that is a
+    // gfx950 figure (160 KB per CU); on a part that offers less per workgroup the general path runs instead
+    if (prop.sharedMemPerBlock < (size_t)LEAN_LDS_BYTES) c->lean = 0;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     c->own_stream = true;
@@ -124,6 +127,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "lean")) {
         if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "lean must be 0 (never), 1 (auto) or 2 (always)");
         c->lean = (int)value;
+    } else if (!strcmp(name, "lean_backoff")) {
+        c->lean_backoff = value != 0;
     } else if (!strcmp(name, "lean_count")) {
         if (value < 0) return fail(c, BPE_E_ARG, "lean_count must be >= 0");
         c->lean_count = value;

@@ -84,6 +84,7 @@ struct bpe_ctx {
     uint64_t n_lean = 0, n_deferred = 0;      // ... of which lean iterations (k_lean.hip); iterations handed back to the general path
     int lean = 1;                             // option "lean": 0 never | 1 once the last seen count is <= lean_count | 2 always (tests)
     int64_t lean_count = 1 << 20;             // option "lean_count"
+    int lean_backoff = 1;                     // option "lean_backoff": general-path stretches after clustered deferrals (api_train.hip)
     int lean_grid = 256;                      // option "lean_grid": most workgroups of a lean merge pass
     int lean_scan = 31;                       // option "lean_scan": workgroups of k_rowmax_lean
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live

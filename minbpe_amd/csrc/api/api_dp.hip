@@ -16,6 +16,8 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     TRY(ensure_table(c, 256u + (uint32_t)num_merges));
     // (a pass that a device status cut short in an earlier call may have left partial sums behind)
     HIPCHK(c, hipMemsetAsync(c->d_delta, 0, ((size_t)c->vcap * 4 * DELTA_REPL + 256 * DELTA_SKEW) * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_rowmax, 0, (size_t)c->vcap * 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dbits, 0, DBITS_WORDS * sizeof(uint32_t), c->stream));
     TRY(ensure_rec(c, std::max(num_merges, 1)));
     memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
     if (c->d_dp_folded) (void)hipFree(c->d_dp_folded);

@@ -128,8 +128,6 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     const uint32_t mask = (uint32_t)(hs - 1);
     // 4. one chunk per lane -- with the cache, one DISTINCT chunk per lane
     TRY(prof_begin(c, BPE_PROF_ENCODE, n));
-    // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
-    const bool narrow = bpe_encode_uses_16bit(merge_ids, M) != 0;
     const unsigned gch = (unsigned)((n_chunks + ENC_THREADS - 1) / ENC_THREADS);
     if (cache) {
         const unsigned long long keep = c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull;
@@ -140,7 +138,7 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         hipLaunchKernelGGL(k_enc_pass2, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
                            c->d_enc_tab, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp,
                            c->d_enc_len, c->d_enc_mid, c->d_enc_midn);
-    } else if (narrow)
+    } else if (bpe_encode_uses_16bit(merge_ids, M))  // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
         hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3(gch),
                            dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,

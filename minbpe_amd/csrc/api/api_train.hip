@@ -34,6 +34,10 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
     // (a pass that a device status cut short in an earlier call may have left partial sums behind)
     HIPCHK(c, hipMemsetAsync(c->d_delta, 0, ((size_t)c->vcap * 4 * DELTA_REPL + 256 * DELTA_SKEW) * sizeof(uint32_t), c->stream));
+    // (a second train() on this ctx: rows beyond 255 still hold the previous run's maxima, and the flag
+    // words what its last table updates left)
+    HIPCHK(c, hipMemsetAsync(c->d_rowmax, 0, (size_t)c->vcap * 2 * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dbits, 0, DBITS_WORDS * sizeof(uint32_t), c->stream));
     TRY(prof_end(c));
     if (iter_ms_out) HIPCHK(c, hipEventRecord(evs[0], c->stream));
     const uint64_t n0 = c->n;
@@ -55,7 +59,13 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     // lean iterations (k_lean.hip): which ones were enqueued that way (1: candidates from the index, 2: every
     // slot), the iteration that reported ST_DEFER, and the one iteration that must take the general path
     std::vector<uint8_t> lean_kind(form2 ? (size_t)num_merges : 0, 0);
-    int deferred = -1, force_general = -1;
+    int deferred = -1;
+    // Iterations below general_until take the general path: the one a lean iteration handed back, and -- a
+    // deferral costs a stream synchronisation, up to `depth` no-op iterations and the re-run (~200 us against
+    // 25 us for a lean iteration and 44 us for a general one) -- the stretch after it when deferrals come
+    // thick (streams whose late counts are 2 or 3: hundreds of tied pairs per selection, each of them a
+    // deferral).  The stretch doubles while they keep coming, up to 1024 iterations, and halves otherwise.
+    int general_until = -1, defer_hold = 0, last_deferred_at = -(1 << 30);
     bool lean_on = false;  // latched: the general path's kernels do not know a deferred iteration
     // second form: which iterations flipped the header arrays (a sparse pass does not), so that an
     // early stop can undo the flips of the no-op iterations enqueued behind the failing one
@@ -149,7 +159,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             if (c->slotted && c->slot2) TRY(plan_pass2(c, &sparse));
             // lean iterations (k_lean.hip): every sparse pass whose pair is rare enough, and every pass of a
             // stream too small for the index (a few thousand slots: visiting them all costs nothing)
-            const bool lean = c->slotted && c->slot2 && c->lean && i != force_general &&
+            const bool lean = c->slotted && c->slot2 && c->lean && i >= general_until &&
                               (lean_on || c->lean == 2 ||
                                (c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count &&
                                 (sparse || c->slot_T <= 16 * SPARSE_GRID)));
@@ -207,7 +217,16 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 hipLaunchKernelGGL(k_clear_defer, dim3(1), dim3(1), 0, c->stream, c->d_st);
                 LAUNCHCHK(c, "k_clear_defer");
                 c->n_deferred++;
-                force_general = deferred;
+                // back-off: a deferral within 32 lean iterations of the last one lengthens the general stretch
+                // (nothing is in flight here, so the switch is safe; the general path then runs until a lean
+                // iteration is enqueued again, which is the ordinary general -> lean hand-over)
+                if (c->lean_backoff) {
+                    if (deferred - last_deferred_at <= defer_hold + 32) defer_hold = std::min(std::max(2 * defer_hold, 32), 1024);
+                    else defer_hold /= 2;
+                }
+                last_deferred_at = deferred;
+                general_until = deferred + 1 + defer_hold;
+                if (defer_hold) lean_on = false;
                 i = deferred;
                 deferred = -1;
             } else if (!stop) consumed++;

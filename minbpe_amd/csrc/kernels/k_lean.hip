@@ -67,6 +67,11 @@ constexpr uint32_t LEAN_BLK_CAP = 128;   // 64-row groups with several rows at t
 // pass's duration -- one wave in a few hundred draws five or six slots and everybody waits for it.)
 constexpr int LEAN_MT = 1024;
 constexpr uint32_t LEAN_SUB = 128;  // mask words per round of a workgroup: at most 4096 candidates listed
+// static LDS of k_merge_ab_lean: one slot of staging per wave + the candidate list.  More than the 64 KB a
+// workgroup gets on other parts: the build is gfx950-only (160 KB per CU), and bpe_create turns the lean
+// iterations off when the device reports less than this per workgroup.
+constexpr int LEAN_LDS_BYTES = (LEAN_MT / 64) * TILE2 * 4 + (int)LEAN_SUB * 32 * 4 + 8;
+static_assert(LEAN_LDS_BYTES <= 160 * 1024, "k_merge_ab_lean: staging + candidate list must fit the CU's LDS");
 template <bool INDEXED>
 __global__ void __launch_bounds__(LEAN_MT)
 k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
