@@ -136,6 +136,9 @@ def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
     engine.set_option("aa_sparse", 0 if lean == 5 else 1)
+    # lean >= 2 forces the lean iterations onto every merge (coverage of their kernels and of the hand-back):
+    # no general-path stretches after clustered deferrals there
+    engine.set_option("lean_backoff", 0 if lean >= 2 else 1)
 
 
 def reset_variant(engine):

@@ -1,0 +1,153 @@
+"""CPU model of the tied-pair LIST of the chain iterations (minbpe_amd/csrc/kernels/k_chain.hip).
+
+One full selection finds the maximum count M and every pair that attains it, sorted by first occurrence.  From
+then on no selection is needed while pairs remain at M:
+  * the next merges are the longest prefix of the list whose pairs have a != b and share no token -- a BATCH,
+    merged in one pass over the stream (the reference merges exactly these, in this order, whatever pairs the
+    merges create: a created pair can only reach M by taking over EVERY occurrence of a listed pair that shares
+    a token with the merged one, and it then stands where that pair stood in the order);
+  * after a batch, a listed pair (x, y) that shares no token with it is untouched; one that does has become, in
+    all of its M occurrences or not at all, one of (x, y), (Zx, y), (x, Zy), (Zx, Zy) -- Zx the token made from a
+    batch pair that ends in x, Zy the one made from a pair that starts with y.  The one of the four whose count
+    in the updated table is M replaces it IN PLACE; if none has M the pair leaves the list;
+  * an empty list means the maximum dropped: select again.
+Checked here against the reference semantics (`max(stats, key=stats.get)` over a fresh get_stats dict,
+base.py:13-22, basic.py:35) restated with numpy, on tie-heavy streams, chunked (regex.py:51-54) and not."""
+import random
+
+import numpy as np
+import pytest
+
+KMAX = 8
+
+
+def stats_in_order(chunks):
+    """(pairs in dict insertion order, counts) over a list of chunks sharing one dict (regex.py:51-54)"""
+    keys, base = [], 0
+    for ids in chunks:
+        if len(ids) >= 2:
+            keys.append((ids[:-1].astype(np.int64) << 32) | ids[1:].astype(np.int64))
+    if not keys:
+        return [], np.zeros(0, dtype=np.int64)
+    keys = np.concatenate(keys)
+    uniq, first, counts = np.unique(keys, return_index=True, return_counts=True)
+    order = np.argsort(first, kind="stable")
+    return [(int(u >> 32), int(u & 0xFFFFFFFF)) for u in uniq[order]], counts[order]
+
+
+def merge(ids, pair, idx):  # base.py:25-41
+    out, i, n = [], 0, len(ids)
+    a, b = pair
+    while i < n:
+        if ids[i] == a and i + 1 < n and ids[i + 1] == b:
+            out.append(idx)
+            i += 2
+        else:
+            out.append(int(ids[i]))
+            i += 1
+    return np.array(out, dtype=np.int64)
+
+
+def table_of(chunks):
+    pairs, counts = stats_in_order(chunks)
+    return dict(zip(pairs, (int(c) for c in counts)))
+
+
+def batch_of(tl, left):
+    """longest prefix of the list with a != b and no shared token (at most KMAX pairs, `left` merges to go)"""
+    batch, used = [], set()
+    for a, b in tl:
+        if a == b or a in used or b in used or len(batch) >= min(KMAX, left):
+            break
+        batch.append((a, b))
+        used.update((a, b))
+    return batch
+
+
+def maintain(tl, batch, znew, table, M):
+    """the list after `batch` was merged into tokens znew[j]: four-way replacement rule"""
+    ends = {b: z for (a, b), z in zip(batch, znew)}
+    starts = {a: z for (a, b), z in zip(batch, znew)}
+    out = []
+    for x, y in tl[len(batch):]:
+        cands = [(x, y)]
+        if x in ends:
+            cands.append((ends[x], y))
+        if y in starts:
+            cands.append((x, starts[y]))
+        if x in ends and y in starts:
+            cands.append((ends[x], starts[y]))
+        hit = [p for p in cands if table.get(p, 0) == M]
+        assert len(hit) <= 1
+        if hit:
+            out.append(hit[0])
+    return out
+
+
+def make_stream(name, k, n, seed):
+    rng = random.Random(seed)
+    if k:
+        ids = np.array([97 + rng.randrange(k) for _ in range(n)], dtype=np.int64)
+        return [ids]
+    words = [bytes(rng.randrange(97, 97 + 7) for _ in range(rng.randrange(1, 7))) for _ in range(60)]
+    if name == "words":
+        buf = b" ".join(rng.choice(words) for _ in range(n // 4))
+        return [np.frombuffer(buf, dtype=np.uint8).astype(np.int64)]
+    # chunked like a GPT-style split: " word" chunks, pairs never span chunks
+    return [np.frombuffer(b" " + rng.choice(words), dtype=np.uint8).astype(np.int64) for _ in range(n // 4)]
+
+
+STREAMS = [("k2", 2, 3000), ("k3", 3, 5000), ("k5", 5, 8000), ("k12", 12, 16000), ("words", 0, 12000),
+           ("chunks", 0, 12000)]
+
+
+@pytest.mark.parametrize("name,k,n", STREAMS)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_list_and_batches_are_the_references_merges(name, k, n, seed):
+    chunks = make_stream(name, k, n, 1000 * seed + n)
+    total = 260
+    next_id, done = 256, 0
+    selections = batched = replaced = 0
+    while done < total:
+        pairs, counts = stats_in_order(chunks)
+        if not len(counts) or counts.max() < 2:
+            break
+        # ---- full selection -------------------------------------------------------------------
+        M = int(counts.max())
+        tl = [p for p, c in zip(pairs, counts) if c == M]
+        selections += 1
+        while tl and done < total:
+            if tl[0][0] == tl[0][1]:
+                # a == b at the head: the general path's merge; the list is void afterwards
+                ref_pairs, ref_counts = stats_in_order(chunks)
+                assert ref_pairs[int(np.argmax(ref_counts))] == tl[0]
+                chunks = [merge(c, tl[0], next_id) for c in chunks]
+                next_id += 1
+                done += 1
+                break
+            batch = batch_of(tl, total - done)
+            znew = list(range(next_id, next_id + len(batch)))
+            for pair, z in zip(batch, znew):
+                # the reference, on the stream as it stands, picks exactly the batch's next pair, at count M
+                ref_pairs, ref_counts = stats_in_order(chunks)
+                j = int(np.argmax(ref_counts))
+                assert ref_pairs[j] == pair and int(ref_counts[j]) == M, (name, seed, done, pair, ref_pairs[j])
+                chunks = [merge(c, pair, z) for c in chunks]
+            next_id += len(batch)
+            done += len(batch)
+            batched += len(batch) - 1
+            table = table_of(chunks)
+            new_tl = maintain(tl, batch, znew, table, M)
+            replaced += sum(1 for p in new_tl if p not in tl)
+            # the maintained list IS the set of pairs at M, in dict order -- or the maximum dropped
+            now_pairs, now_counts = stats_in_order(chunks)
+            if len(now_counts) and int(now_counts.max()) == M:
+                assert new_tl == [p for p, c in zip(now_pairs, now_counts) if c == M], (name, seed, done)
+            else:
+                assert new_tl == []
+            tl = new_tl
+    assert done > 40 and selections < done
+    if name in ("k12", "words", "chunks"):
+        assert batched > 0, batched
+    if name in ("words", "chunks"):  # rigid sequences: a created pair takes over a listed one
+        assert replaced > 0, replaced
