@@ -214,11 +214,12 @@ int bpe_prof_read(bpe_ctx *ctx, double *ms, uint64_t *launches, uint64_t *alg_by
  * is visited), out[1] = sparse passes (only the slots the inverted slot index cannot rule out),
  * out[2] = builds of that index, out[3] = slots of the stream at the end. */
 int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
-/* The same, extended: out[4] = lean iterations among the passes above (three launches per merge, the
- * pair table updated at the merge sites themselves; option "lean"), out[5] = iterations a lean pass
- * handed back to the general path (pairs with a == b), out[6] = lean iterations that took their pair off
- * the list an earlier selection made (the tied pairs in order of first occurrence: the reference merges them
- * in that order while their counts stand) instead of selecting.  Writes min(n, 7) values. */
+/* The same, extended: out[4] = merges done by lean iterations or chain steps (three launches per merge or per
+ * batch of merges, the pair table updated at the merge sites themselves; options "lean", "chain"), out[5] =
+ * merges they handed back to the general path (pairs with a == b, ties they could not settle), out[6] = merges
+ * that needed no selection of their own (their pair came off the list of tied pairs an earlier selection made:
+ * the reference merges those in order of first occurrence while their counts stand), out[7] = chain steps,
+ * out[8] = chain steps that selected (the others took their pairs off the list).  Writes min(n, 9) values. */
 int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */

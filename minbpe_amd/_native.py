@@ -451,11 +451,14 @@ class Engine:
         self._check(_lib.bpe_prof_reset(self._h))
 
     def train_stats(self):
-        """dict(dense, sparse, index_builds, slots, lean, deferred, chained) of the last train() (bpe_train_stats_ex)."""
-        out = np.zeros(7, np.uint64)
-        self._check(_lib.bpe_train_stats_ex(self._h, _ptr(out), 7))
+        """dict(dense, sparse, index_builds, slots, lean, deferred, chained, steps, selections) of the last train()
+        (bpe_train_stats_ex): passes by kind, merges done by lean iterations / chain steps, merges handed back to the
+        general path, merges that needed no selection of their own, chain steps, chain steps that selected."""
+        out = np.zeros(9, np.uint64)
+        self._check(_lib.bpe_train_stats_ex(self._h, _ptr(out), 9))
         return dict(dense=int(out[0]), sparse=int(out[1]), index_builds=int(out[2]), slots=int(out[3]),
-                    lean=int(out[4]), deferred=int(out[5]), chained=int(out[6]))
+                    lean=int(out[4]), deferred=int(out[5]), chained=int(out[6]), steps=int(out[7]),
+                    selections=int(out[8]))
 
     def prof_read(self):
         k = len(PROF_KINDS)

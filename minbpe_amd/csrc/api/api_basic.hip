@@ -70,6 +70,7 @@ void bpe_destroy(bpe_ctx *c) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->h_srec) (void)hipHostFree(c->h_srec);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -149,6 +150,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lean_select = value != 0;
     } else if (!strcmp(name, "aa_sparse")) {
         c->aa_sparse = value != 0;
+    } else if (!strcmp(name, "chain")) {
+        c->chain = value != 0;
     } else if (!strcmp(name, "lean_chain")) {
         c->lean_chain = value != 0;
     } else if (!strcmp(name, "lean_sum")) {

@@ -90,6 +90,10 @@ struct bpe_ctx {
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     int aa_sparse = 1;                        // option "aa_sparse": a sparse iteration's a == b pass works through a candidate list and keeps the index current itself (no rebuild after it)
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
+    int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
+                                              // token-disjoint pairs merged in one pass) instead of lean iterations, wherever those would run with the index live
+    StepRec *h_srec = nullptr;                // pinned ring of step records (STEP_RING entries)
+    uint64_t n_steps = 0, n_full = 0, n_chained = 0;  // chain steps of the last train(), those that selected, merges that needed no selection
     int lean_sum = 1;                         // option "lean_sum": 1 = k_sel_lean (selection from the table update's per-wave records) whenever they are current
     uint4 *d_lean_sum = nullptr;              // [4][LEAN_SUM_CAP] those records (k_lean.hip)
     bool sum_valid = false;                   // ... describe the table as it stands (the last iteration enqueued was a lean one)
@@ -306,6 +310,12 @@ int ensure_rec(bpe_ctx *c, int n) {
     c->h_rec = nullptr;
     HIPCHK(c, hipHostMalloc((void **)&c->h_rec, sizeof(IterRec) * (size_t)n, hipHostMallocMapped));
     c->rec_cap = n;
+    return BPE_OK;
+}
+
+int ensure_srec(bpe_ctx *c) {
+    if (!c->h_srec) HIPCHK(c, hipHostMalloc((void **)&c->h_srec, sizeof(StepRec) * STEP_RING, hipHostMallocMapped));
+    memset(c->h_srec, 0, sizeof(StepRec) * STEP_RING);
     return BPE_OK;
 }
 
@@ -1004,6 +1014,71 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     c->stream_is_bytes = false;
     c->rows_pending = true;
     c->n_lean++;
+    if (use_index) c->n_sparse++; else c->n_dense++;
+    return BPE_OK;
+}
+
+// A chain step (k_chain.hip): selection or list look-ups, one merge pass for the whole batch, table update.
+// zhi: the largest token id the step can make (the device counts the merges; the host only knows a bound).
+// records: the last launch that touched the pair table was a k_apply_chain.
+int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, bool records) {
+    const uint32_t T = (uint32_t)c->slot_T;
+    const uint32_t dl = delta_layout(c, zhi);
+    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    CandArgs C;
+    C.idx = c->d_idx;
+    C.dirty = c->d_idx_dirty;
+    C.cand = nullptr;
+    C.stride = (uint32_t)c->idx_cap_words;
+    C.T = T;
+    C.enable = 0;
+    C.tie_index = 1;
+    C.tie_window = 0;
+    C.aa = 0;
+    if (records)
+        hipLaunchKernelGGL(k_chain_sel<true>, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                           c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
+    else
+        hipLaunchKernelGGL(k_chain_sel<false>, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                           c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
+    LAUNCHCHK(c, "k_chain_sel");
+    TRY(prof_end(c));
+    AbArgs A;
+    A.b0 = c->d_ids[0];
+    A.b1 = c->d_ids[1];
+    A.hdr_in = c->d_hdr2[c->mq];
+    A.hdr_out = nullptr;
+    A.stage = c->d_stage;
+    A.smask = c->d_smask;
+    A.T = T;
+    A.st = c->d_st;
+    A.newid = 0;  // (the device knows: st->bz0)
+    A.delta = c->d_delta;
+    A.vcap = dl;
+    A.idx = c->d_idx;
+    A.istride = (uint32_t)c->idx_cap_words;
+    A.cand = nullptr;
+    A.removed = c->d_removed;
+    A.dirty_n = c->d_dirty_n;
+    const uint32_t nwords = (T + 31) / 32;
+    const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
+    TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+    hipLaunchKernelGGL(k_merge_chain, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
+    LAUNCHCHK(c, "k_merge_chain");
+    TRY(prof_end(c));
+    TRY(prof_begin(c, BPE_PROF_TABLE, 0));
+    const uint32_t na = (zhi + 1 + 255) / 256;
+    const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
+    hipLaunchKernelGGL(k_apply_chain, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
+                       c->d_st, c->d_dbits, c->par, c->h_rec, c->h_srec, step, na, c->d_hdr2[c->mq], c->d_stage,
+                       c->d_removed, c->d_smask, nwords, c->d_lean_sum);
+    LAUNCHCHK(c, "k_apply_chain");
+    TRY(prof_end(c));
+    c->par ^= 1;  // (staged headers: the header arrays do not flip)
+    c->stats_valid = false;
+    c->stream_is_bytes = false;
+    c->rows_pending = true;
+    c->n_steps++;
     if (use_index) c->n_sparse++; else c->n_dense++;
     return BPE_OK;
 }

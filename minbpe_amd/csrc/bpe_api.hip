@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <deque>
 #include <string>
 #include <vector>
 

@@ -37,7 +37,8 @@ constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_selec
 constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches alone on a tie (0: all blocks sweep together)
 constexpr int TIE_BLOCKS = 256;     // k_select blocks: block 0 decides, all of them sweep the stream on a tie
 constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
-constexpr int DELTA_REPL = 32;     // replicas of the delta vectors (spreads hot atomics)
+constexpr int DELTA_REPL = 128;    // replica blocks of the delta vectors (spreads hot atomics; a chain step's batch
+                                   // gives each of its pairs CH_RSTRIDE of them, k_chain.hip)
 // Device-scope atomics execute at the memory channel that owns the address, ~11 ns apiece and ONE AT
 // A TIME per channel (measured: a pass whose atomics fall on few channels runs at a fraction of the
 // ~10 G atomics/s the whole chip sustains).  Replica r of the delta vectors starts at
@@ -52,6 +53,16 @@ constexpr int LDSD_CAP = 1920;
 __host__ __device__ inline size_t delta_rep_off(uint32_t r, uint32_t stride) {
     return (size_t)r * (4 * (size_t)stride + DELTA_SKEW);
 }
+
+// Chain steps (k_chain.hip): the tied pairs at the maximum are kept as a LIST in first-occurrence order, and the
+// longest prefix of it whose pairs have a != b and share no token -- at most CH_KMAX of them -- is merged in ONE pass.
+constexpr int CH_KMAX = 8;
+constexpr uint32_t CH_BATCH_COUNT = 1u << 14;  // a pair with more sites than this is merged alone (all delta replicas for it)
+constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per pair of a batch ...
+constexpr int CH_REP = 4;                      // ... of which a batch of two or more uses this many per pair
+static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must fit the replica blocks");
+static_assert(CH_KMAX * 32 <= 256, "removal counters: 32 per pair of a batch");
+constexpr uint32_t CH_FULL = 0, CH_LIST = 1;   // DevState::sel_mode
 
 // encode: one chunk per lane, token lists in lane-private LDS columns
 constexpr int ENC_THREADS = 256;
@@ -135,12 +146,30 @@ struct DevState {
     uint32_t chain_n, chain_pos, chain_cut;
     uint32_t chain_taken;         // iterations that took their pair off the chain since the stream was loaded (statistics)
     uint32_t sel_ran;             // the last selection launch re-scanned every flagged row: the next lean merge pass clears the flags
-    int32_t chain[2 * TIE_CAP];
+    int32_t chain[2 * TIE_CAP];   // (chain steps: the tied-pair list itself, tl_n entries)
+    // ---- chain steps (k_chain.hip): the device counts the merges itself, a step does 1..CH_KMAX of them ----
+    uint32_t iter;                // merges done; the next new token is 256 + iter
+    uint32_t num_merges;          // training stops there: later steps are no-ops
+    uint32_t sel_mode;            // CH_FULL: the next step selects | CH_LIST: it takes its pairs off the list.  Written by
+                                  // k_apply_chain / k_set_iter / k_clear_defer only, never by the launch that reads it
+    uint32_t tl_n, tl_M, tl_skip; // the list: entries, their common count, how many at its head the last batch merged
+    uint32_t bk, bz0;             // this step's batch: pairs, the new id of the first one
+    int32_t ba[CH_KMAX], bb[CH_KMAX];
+    uint32_t badj[CH_KMAX];       // delta format B, per pair of the batch: sites whose right neighbour starts a site of the SAME pair
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.
     alignas(128) uint32_t sel_flag;
     uint32_t pad_flag_[31];
+};
+
+constexpr uint32_t STEP_RING = 4096;  // step records form a ring (far more than the steps the host runs ahead: depth <= 64)
+// one per chain step, written by the device into pinned host memory (the IterRecs of its merges are final before it)
+struct StepRec {
+    uint32_t first_iter, k;      // the merges this step did: first_iter .. first_iter + k - 1 (k == 0: none)
+    uint32_t status, pad;        // ST_* (ST_DEFER: the general path must do merge first_iter); pad = the step's mode (CH_FULL / CH_LIST)
+    unsigned long long new_len;
+    unsigned long long seq;      // step + 1 once every field above is final
 };
 
 // one per training iteration, written by the device into pinned host memory

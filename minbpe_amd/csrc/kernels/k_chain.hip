@@ -1,0 +1,899 @@
+// k_chain.hip -- chain steps: the lean iteration (k_lean.hip) taken two steps further.
+//
+// Late in training almost every selection ends in a tie (93-97 % of them after merge 20,000 of the 1 GB
+// run), and a lean iteration is nothing but launches and dependent round trips (~25 us, whatever the pair).
+// Two facts about the reference's loop (get_stats -> max -> merge, base.py:13-41, basic.py:31-42,
+// regex.py:49-63) let one step do the work of several iterations, exactly:
+//
+//  (1) THE LIST.  Let M be the maximum count and T the pairs that attain it, in order of first occurrence
+//      (= dict order = the order max() breaks ties in).  A merge of (a,b) -> Z changes the counts of pairs
+//      that share a token with it and creates pairs with Z; nothing can rise above M, and a created pair
+//      reaches M only by taking over EVERY occurrence of a listed pair (L,a) or (b,R) -- it then stands
+//      exactly where that pair stood in the order.  So after any merges the set of pairs at M, in order,
+//      is the old list with some entries dropped and some replaced in place.  A listed pair (x,y) can only
+//      have become one of (x,y), (Zx,y), (x,Zy), (Zx,Zy) (Zx: the token made from a merged pair ending in
+//      x, Zy: from one starting with y): the one of the four whose count in the updated table is M takes
+//      its place, none -> it leaves the list.  ONE full selection per level M, then table look-ups until
+//      the list is empty.  (tests/test_list_model.py: CPU model against the reference semantics.)
+//  (2) THE BATCH.  The longest prefix of the list whose pairs have a != b and share no token is what the
+//      reference merges next, in that order, whatever those merges create (a pair that shares a token with
+//      a merged one is not in the prefix, so whatever takes its place comes after the prefix).  Their
+//      rewrites commute (no two sites overlap): ONE pass over the candidate slots merges them all, and
+//      charges every site its pair-table delta as the sequential merges would have
+//      (delta format B per pair j: a left neighbour that ends a site of pair i < j already reads Z_i, one of
+//      pair i > j still reads b_i; same on the right; i == j is format B's adj).
+//
+// A step is three launches, like a lean iteration:
+//   k_chain_sel    LIST mode (one workgroup): four-way replacement of the listed pairs the last batch touched,
+//                  then the next batch.  FULL mode: the maximum from k_apply_chain's per-wave records (or the
+//                  whole row-maxima array after a general iteration) while workgroups 1.. re-scan every
+//                  flagged row; all tied pairs (<= TIE_CAP) located through the index and sorted -> the list.
+//   k_merge_chain  every workgroup lists its candidate slots (the filter rows of ALL the batch's pairs) and
+//                  its waves rewrite them (merge_chain_wave).
+//   k_apply_chain  table update for every pair of the batch, one token per thread; rows a_j, b_j, Z_j and the
+//                  rows whose maximum may have dropped are flagged for the next FULL selection; the
+//                  iteration records of all k merges, the stream length, st->iter += k, the next step's mode.
+// The device counts the merges (st->iter): the host does not know how many a step will do.  What a step cannot
+// settle (more than TIE_CAP tied pairs, short slots about, a == b at the head of the list) is deferred to the
+// general path exactly as a lean iteration's is.
+// Part of bpe_kernels.hip, which includes the parts in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../bpe_device.h"
+#include "k_lean.hip"
+
+namespace bpe {
+
+constexpr uint32_t CH_EX_CAP = 2048;  // flagged rows one FULL selection takes from the re-scanning workgroups
+
+// index of the batch pair that (w0, w1) is a site of, or -1.  A word that starts a chunk carries its flag into
+// the comparison (no pair spans chunks); INVALID_WORD matches no id.
+__device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *pb, uint32_t K, uint32_t w0, uint32_t w1) {
+    const uint32_t x = w0 & IDMASK, y = w1 & NWMASK;
+    int hit = -1;
+    for (uint32_t p = 0; p < K; p++)
+        if (x == pa[p] && y == pb[p]) hit = (int)p;
+    return (w0 == INVALID_WORD) ? -1 : hit;
+}
+
+// One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip; sparse form, index live,
+// global delta replicas) for K token-disjoint pairs at once.  pa / pb: the pairs (LDS), z0: pair p becomes z0 + p.
+__device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, const uint32_t t, const AbArgs &A,
+                                                 const uint32_t *pa, const uint32_t *pb, const uint32_t K,
+                                                 const uint32_t z0) {
+    const int lane = lane_id();
+    const uint32_t Tl = min(A.T, A.st->tlive);
+    // ---- (1) every load that does not depend on another one -------------------------------
+    const uint32_t *src = A.b0 + (size_t)t * TILE2;
+    uint4 rv[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
+    uint4 hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
+                          : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    {
+        const long long hi = 2ll * (long long)t - 2 + lane;
+        if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
+    }
+    const uint32_t meta = bcast(hv.w, 2);
+    const uint32_t len = meta & 0x7FFFFFFFu, buf = meta >> 31;
+    if (len == 0) return;
+    if (buf) {  // (uniform) the slot lives in the other buffer: load again
+        src = A.b1 + (size_t)t * TILE2;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
+    }
+    // ---- (2) context: three words after the slot, two before it ----------------------------
+    const uint32_t first = bcast(hv.x, 2);
+    uint32_t halo0 = bcast(hv.x, 4), halo1 = bcast(hv.y, 4), halo2 = bcast(hv.z, 4);
+    uint32_t prev2 = bcast(hv.x, 1), prev1 = bcast(hv.y, 1);
+    uint32_t tprev = t - 1;
+    uint32_t tnext = t + 1;
+    {
+        const uint32_t nlen = bcast(hv.w, 4) & 0x7FFFFFFFu, plen = bcast(hv.w, 0) & 0x7FFFFFFFu;
+        if ((t + 1 < Tl && nlen < 3) || (t > 0 && plen < 2)) {  // (uniform, rare)
+            uint32_t ctx[7] = {0, 0, 0, 0, 0, 0, 0};
+            if (lane == 0) slot_context_walk(A.hdr_in, t, Tl, ctx);
+            halo0 = bcast(ctx[0], 0);
+            halo1 = bcast(ctx[1], 0);
+            halo2 = bcast(ctx[2], 0);
+            prev2 = bcast(ctx[3], 0);
+            prev1 = bcast(ctx[4], 0);
+            tprev = bcast(ctx[5], 0);
+            tnext = bcast(ctx[6], 0);
+        }
+    }
+    // ---- (3) my words: positions >= len come from the halo, then nothing -------------------
+    auto at = [&](int q, uint32_t own) -> uint32_t {
+        const int d = q - (int)len;
+        return d < 0 ? own : (d == 0 ? halo0 : (d == 1 ? halo1 : (d == 2 ? halo2 : INVALID_WORD)));
+    };
+    uint32_t x[MJ][4];
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const int q0 = j * 256 + lane * 4;
+        x[j][0] = at(q0 + 0, rv[j].x);
+        x[j][1] = at(q0 + 1, rv[j].y);
+        x[j][2] = at(q0 + 2, rv[j].z);
+        x[j][3] = at(q0 + 3, rv[j].w);
+    }
+    uint32_t tail[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) tail[i] = at(TILE2 + i, 0u);
+    // ---- (4) r bits and, per site, WHICH pair (a nibble per word: pair index + 1) -------------
+    uint32_t rb[MJ], jc[MJ], valid[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        rb[j] = 0;
+        jc[j] = 0;
+    }
+    uint32_t s = 0;  // carry: my first word is the second word of a site that starts at the previous slot's last word
+    for (uint32_t p = 0; p < K; p++) {
+        const uint32_t a = pa[p], b = pb[p];
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            // (the word after my four: recomputed per pair -- two cross-lane moves against a register held across the loop)
+            const uint32_t up = (j < MJ - 1) ? lane_first(x[(j + 1) % MJ][0]) : tail[0];
+            const uint32_t nxw = lane_next(x[j][0], up);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nxt = (k < 3) ? x[j][k + 1] : nxw;
+                const uint32_t m = (uint32_t)(((x[j][k] & IDMASK) == a) & ((nxt & NWMASK) == b));
+                rb[j] |= m << k;
+                jc[j] |= (m * (p + 1u)) << (4 * k);
+            }
+        }
+        s |= (uint32_t)((prev1 != INVALID_WORD) & ((prev1 & IDMASK) == a) & ((first & NWMASK) == b));
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const int nb = (int)len - (j * 256 + lane * 4);
+        valid[j] = nb >= 4 ? 0xFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
+    }
+    uint32_t anyr = 0;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) anyr |= rb[j] & valid[j];
+    const bool sites = __any(anyr != 0) != 0;
+    if (!sites && !s) return;  // nothing in this slot changes and it owes no table update
+    // ---- (5) kept flags, output offsets -------------------------------------------------------
+    uint32_t mb[MJ], kb[MJ], ex[MJ], cnt[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        mb[j] = rb[j] & valid[j];
+        const uint32_t upr = (j > 0) ? ((lane_last(rb[(j + MJ - 1) % MJ]) >> 3) & 1u) : s;
+        const uint32_t mp = (uint32_t)dpp_mov<0x138>((int)upr, (int)((rb[j] >> 3) & 1u));  // wave_shr:1, lane 0 keeps upr
+        kb[j] = ~((mb[j] << 1) | mp) & valid[j] & 0xFu;
+        cnt[j] = (uint32_t)__popc(kb[j]);
+    }
+    static_assert(MJ == 4, "packed scan below assumes four stripes");
+    const uint32_t i01 = wave_iscan_add(cnt[0] | (cnt[1] << 16));
+    const uint32_t i23 = wave_iscan_add(cnt[2] | (cnt[3] << 16));
+    const uint32_t t01 = lane_last(i01), t23 = lane_last(i23);
+    const uint32_t tot0 = t01 & 0xFFFFu, tot1 = t01 >> 16, tot2 = t23 & 0xFFFFu, tot3 = t23 >> 16;
+    ex[0] = (i01 & 0xFFFFu) - cnt[0];
+    ex[1] = tot0 + (i01 >> 16) - cnt[1];
+    ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
+    ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
+    const uint32_t total = tot0 + tot1 + tot2 + tot3;
+    // ---- (6) stage the compacted slot in LDS, then 16-byte stores back to its home -------------
+    uint32_t fstore = 0;  // a dropped first word moves everything
+    if (!s) {
+        uint32_t fc = 0x7FFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            if (mb[j]) {
+                const uint32_t k0 = (uint32_t)__ffs((int)mb[j]) - 1u;
+                fc = min(fc, ex[j] + (uint32_t)__popc(kb[j] & ((1u << k0) - 1u)));
+            }
+        }
+        fstore = (uint32_t)wave_min_i32((int)fc) & ~3u;
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        uint32_t o = ex[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((kb[j] >> k) & 1u) {
+                const uint32_t w = x[j][k];
+                const uint32_t z = z0 + ((jc[j] >> (4 * k)) & 15u) - 1u;
+                out[o++] = ((mb[j] >> k) & 1u) ? (z | (w & (FLAG | WMASK))) : w;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        uint32_t *dst = (buf ? A.b1 : A.b0) + (size_t)t * TILE2;
+        for (uint32_t i = fstore + (uint32_t)lane * 4; i < total; i += 256)
+            *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(&out[i]);
+    }
+    if (lane == 0) {
+        uint32_t h[8];
+        h[0] = total > 0 ? out[0] : INVALID_WORD;
+        h[1] = total > 1 ? out[1] : INVALID_WORD;
+        h[2] = total > 2 ? out[2] : INVALID_WORD;
+        h[3] = total | (buf << 31);
+        h[4] = total > 1 ? out[total - 2] : INVALID_WORD;
+        h[5] = total > 0 ? out[total - 1] : INVALID_WORD;
+        h[6] = h[7] = 0;
+        StageRec *r = A.stage + t;
+        r->t = t;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r->h[i] = h[i];
+        atomicOr(&A.smask[t >> 5], 1u << (t & 31));
+        if (total < 3 && t + 1 < Tl) A.st->gap = 1;
+    }
+    if (!sites) return;  // carry only: the site belongs to the previous slot
+    // ---- ids removed, per pair: every site is counted by the slot that owns its first word ----
+    for (uint32_t p = 0; p < K; p++) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) c += (uint32_t)(((mb[j] >> k) & 1u) & (((jc[j] >> (4 * k)) & 15u) == p + 1u));
+        }
+        if (!__any(c != 0)) continue;  // (uniform)
+        c = wave_sum_u32(c);
+        // (a pair merged alone can have 10^5 changed slots: all 256 counters, as a lean pass does)
+        if (lane == 0) atomicAdd(&A.removed[(K == 1 ? (t & 255u) : (p * 32u + (t & 31u))) * REMOVED_STRIDE], c);
+    }
+    // ---- (7) pair-table delta of my sites, as the sequential merges would charge it ------------
+    const uint32_t nrep = 1u << (A.vcap >> 24);
+    const uint32_t vc = A.vcap & 0xFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        if (!__any(mb[j] != 0)) continue;  // (uniform) no site in this stripe
+        uint32_t upm2, upm1, dn0, dn1, dn2;
+        if (j > 0) {
+            upm2 = lane_last(x[(j + MJ - 1) % MJ][2]);
+            upm1 = lane_last(x[(j + MJ - 1) % MJ][3]);
+        } else {
+            upm2 = prev2;
+            upm1 = prev1;
+        }
+        if (j < MJ - 1) {
+            dn0 = lane_first(x[(j + 1) % MJ][0]);
+            dn1 = lane_first(x[(j + 1) % MJ][1]);
+            dn2 = lane_first(x[(j + 1) % MJ][2]);
+        } else {
+            dn0 = tail[0];
+            dn1 = tail[1];
+            dn2 = tail[2];
+        }
+        uint32_t W[9];
+        W[0] = (uint32_t)dpp_mov<0x138>((int)upm2, (int)x[j][2]);  // (lane 0 keeps upm2 / upm1)
+        W[1] = (uint32_t)dpp_mov<0x138>((int)upm1, (int)x[j][3]);
+        W[2] = x[j][0];
+        W[3] = x[j][1];
+        W[4] = x[j][2];
+        W[5] = x[j][3];
+        W[6] = lane_next(x[j][0], dn0);
+        W[7] = lane_next(x[j][1], dn1);
+        W[8] = lane_next(x[j][2], dn2);
+        if (mb[j] == 0) continue;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (!((mb[j] >> k) & 1u)) continue;
+            const int q = j * 256 + lane * 4 + k;
+            const uint32_t p = ((jc[j] >> (4 * k)) & 15u) - 1u;
+            const uint32_t Z = z0 + p;
+            const uint32_t rho = (K == 1) ? (t & (nrep - 1u)) : (p * (uint32_t)CH_RSTRIDE + (t & (uint32_t)(CH_REP - 1)));
+            uint32_t *dl = A.delta + delta_rep_off(rho, vc);  // SL of pair p
+            uint32_t *dr = dl + vc;                             // SR of pair p
+            const uint32_t wa = W[k + 2];
+            const uint32_t wt = word_weight(wa);
+            const uint32_t Lw = W[k + 1], LL = W[k];
+            if (!(wa & FLAG) && Lw != INVALID_WORD) {
+                // the left neighbour ends a site of pair li: when pair p is merged it already reads Z_li
+                // (li < p) or still b_li (li > p); li == p is the same pair twice in a row -- format B's adj,
+                // charged by the left site
+                const int li = chain_match(pa, pb, K, LL, Lw);
+                if (li != (int)p) {
+                    const uint32_t Lseq = (li >= 0 && (uint32_t)li < p) ? z0 + (uint32_t)li : (Lw & IDMASK);
+                    const uint32_t Lfin = li >= 0 ? z0 + (uint32_t)li : (Lw & IDMASK);
+                    atomicAdd(&dl[Lseq], wt);
+                    index_add(A.idx, A.istride, t, Lfin, Z);
+                    if (q == 0) index_add(A.idx, A.istride, tprev, Lfin, Z);
+                }
+            }
+            const uint32_t R = W[k + 4], RR = W[k + 5];
+            if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
+                const int ri = chain_match(pa, pb, K, R, RR);
+                if (ri == (int)p) atomicAdd(&A.st->badj[p], wt);
+                else atomicAdd(&dr[(ri >= 0 && (uint32_t)ri < p) ? z0 + (uint32_t)ri : (R & IDMASK)], wt);
+                const uint32_t y = ri >= 0 ? z0 + (uint32_t)ri : (R & IDMASK);
+                index_add(A.idx, A.istride, t, Z, y);
+                if (q + 2 >= (int)len) index_add(A.idx, A.istride, tnext, Z, y);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// merge pass of a chain step: k_merge_ab_lean for the st->bk pairs of the batch (index live)
+__global__ void __launch_bounds__(LEAN_MT)
+k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[LEAN_MT / 64][TILE2];
+    __shared__ uint32_t s_list[LEAN_SUB * 32];
+    __shared__ uint32_t s_tot[2];
+    __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX];
+    DevState *st = A.st;
+    // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
+    const uint32_t ran = st->sel_ran;
+    if (blockIdx.x == 0 && ran) {
+        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) st->sel_ran = 0;
+    }
+    const uint32_t K = st->bk;
+    if (st->status || st->defer || K == 0) return;
+    const uint32_t z0 = st->bz0;
+    if (threadIdx.x < CH_KMAX) {
+        s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
+        s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t Tl = min(A.T, st->tlive);
+    constexpr uint32_t NWV = LEAN_MT / 64;
+    if (!use_index || st->gap != 0) {  // short slots about: visit everything
+        const uint32_t nw = gridDim.x * NWV;
+        for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw)
+            merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, K, z0);
+        return;
+    }
+    const uint32_t nwords = (Tl + 31) / 32;
+    const uint32_t per = (nwords + gridDim.x - 1) / gridDim.x;  // mask words of one workgroup
+    const uint32_t wlo = blockIdx.x * per, whi = min(nwords, wlo + per);
+    for (uint32_t sub = wlo; sub < whi; sub += LEAN_SUB) {
+        uint32_t mk = 0;
+        const uint32_t w = sub + threadIdx.x;
+        if (threadIdx.x < LEAN_SUB && w < whi) {
+            mk = idx_dirty[w];
+            for (uint32_t p = 0; p < K; p++) {
+                uint32_t h1, h2, h3;
+                pair_hash(s_pa[p], s_pb[p], h1, h2, h3);
+                mk |= A.idx[(size_t)h1 * A.istride + w] & A.idx[(size_t)h2 * A.istride + w] &
+                      A.idx[(size_t)h3 * A.istride + w];
+            }
+            const uint32_t left = Tl - w * 32;
+            if (left < 32) mk &= (1u << left) - 1u;
+        }
+        const uint32_t c = (uint32_t)__popc(mk);
+        const uint32_t inc = wave_iscan_add(c);
+        if (threadIdx.x < 128 && lane_id() == 63) s_tot[wave_id()] = inc;
+        __syncthreads();
+        const uint32_t n = s_tot[0] + s_tot[1];
+        if (threadIdx.x < LEAN_SUB) {
+            uint32_t o = inc - c + (wave_id() == 1 ? s_tot[0] : 0u);
+            while (mk) {
+                s_list[o++] = w * 32 + (uint32_t)__ffs((int)mk) - 1u;
+                mk &= mk - 1u;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = wave_id(); i < n; i += NWV)
+            merge_chain_wave(s_out[wave_id()], s_list[i], A, s_pa, s_pb, K, z0);
+        __syncthreads();  // (the list is rewritten by the next round)
+    }
+}
+
+// ---------------------------------------------------------------------------
+// table update of a chain step.  Workgroups [0, na): one token per thread, every pair of the batch.
+// Workgroups [na, grid): commit the staged headers; the first of them also makes the stream length, the
+// iteration records of the step's merges, the step record, and the next step's mode.
+__global__ void __launch_bounds__(256)
+k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
+              const uint32_t *__restrict__ rowmax, DevState *st, uint32_t *__restrict__ dbits, int par, IterRec *rec,
+              StepRec *srec, uint32_t step, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
+              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums) {
+    const uint32_t status = st->status, defer = st->defer;
+    const uint32_t K = st->bk, z0 = st->bz0;
+    const bool noop = status || defer || K == 0;
+    if (blockIdx.x < na) {
+        if (noop) return;
+        const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t Zlast = z0 + K - 1u;
+        if (blockIdx.x * 256u > Zlast) return;  // (the host sized the grid for the most a step can reach)
+        const bool live = t <= Zlast;  // (dead lanes stay for the wave reductions below)
+        const uint32_t nrep = 1u << (vcap >> 24);
+        const uint32_t vc = vcap & 0xFFFFFFu;
+        const uint32_t M = st->count;
+        (void)M;
+        uint2 rm = make_uint2(0u, 0u);
+        uint32_t prevflag = 0;
+        if (live) {
+            prevflag = (dbits[t >> 5] >> (t & 31)) & 1u;  // (flagged by an earlier step of this level, not re-scanned yet)
+            rm = reinterpret_cast<const uint2 *>(rowmax)[t];
+        }
+        bool flagged = false;
+        if (K == 1) {
+            // ---- one pair: all nrep replicas, (t,a) loaded up front (no returning atomic) ----------------
+            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0, adj = st->badj[0];
+            uint32_t x[16][2];
+            auto load_batch = [&](uint32_t r0) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t r = r0 + k;
+                    x[k][0] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + t] : 0u;
+                    x[k][1] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
+                }
+            };
+            load_batch(0);
+            const uint32_t old_ta = live ? mat[(size_t)t * stride + a] : 0u;
+            uint32_t sl = 0, sr = 0;
+            for (uint32_t r0 = 0;;) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (x[k][0]) delta[delta_rep_off(r0 + k, vc) + t] = 0;
+                    if (x[k][1]) delta[delta_rep_off(r0 + k, vc) + vc + t] = 0;
+                    sl += x[k][0];
+                    sr += x[k][1];
+                }
+                r0 += 16;
+                if (r0 >= nrep) break;
+                load_batch(r0);
+            }
+            const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
+            if (sl) {
+                atomicSub(&mat[(size_t)t * stride + a], sl);
+                atomicAdd(&mat[(size_t)t * stride + Z], sl);
+                flagged |= old_ta == rm.x;  // row t's maximum moves only if (t,a) attained it ((t,Z) = sl <= what (t,a) lost)
+            }
+            if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
+            if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+            if (live && t == b) mat[(size_t)a * stride + b] = 0;  // no (a,b) survives the merge (F2)
+            flagged |= live && ((t == a) | (t == b) | (t == Z));
+        } else {
+            // ---- a batch: CH_REP replicas per pair, everything in flight at once ---------------------------
+            uint32_t x[CH_KMAX][CH_REP][2];
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) {
+#pragma unroll
+                for (int r = 0; r < CH_REP; r++) {
+                    const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                    x[p][r][0] = (live && (uint32_t)p < K) ? delta[o + t] : 0u;
+                    x[p][r][1] = (live && (uint32_t)p < K) ? delta[o + vc + t] : 0u;
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) {
+                if ((uint32_t)p >= K) break;  // (uniform)
+                const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + (uint32_t)p, adj = st->badj[p];
+                uint32_t sl = 0, sr = 0;
+#pragma unroll
+                for (int r = 0; r < CH_REP; r++) {
+                    const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                    if (x[p][r][0]) delta[o + t] = 0;
+                    if (x[p][r][1]) delta[o + vc + t] = 0;
+                    sl += x[p][r][0];
+                    sr += x[p][r][1];
+                }
+                const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
+                if (sl) {
+                    // (the value before: decides whether row t's maximum may have moved.  Rows of the batch's own
+                    // tokens are flagged anyway, every other row is touched by this thread alone)
+                    const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], sl);
+                    atomicAdd(&mat[(size_t)t * stride + Z], sl);
+                    flagged |= old == rm.x;
+                }
+                if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
+                if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+                if (live && t == b) mat[(size_t)a * stride + b] = 0;
+                flagged |= live && ((t == a) | (t == b) | (t == Z));
+            }
+        }
+        if (flagged && !prevflag) atomicOr(&dbits[t >> 5], 1u << (t & 31));
+        // ---- what the next FULL selection needs: the largest maximum of my wave's 64 rows (flagged rows left
+        // out: they are re-scanned), the first row that attains it, that row's arg, how many rows attain it
+        const uint32_t vs = (!live || flagged || prevflag) ? 0u : rm.x;
+        const uint32_t gw = blockIdx.x * 4u + wave_id(), base = gw * 64u;
+        const int lane = lane_id();
+        const uint32_t m = wave_umax_dpp(vs);
+        const unsigned long long bal = __ballot(m != 0 && vs == m);
+        const int fl = bal ? __ffsll((long long)bal) - 1 : 0;
+        const uint32_t arg = (uint32_t)__shfl((int)rm.y, fl);
+        if (lane == 0) sums[gw] = make_uint4(m, base + (uint32_t)fl, arg, (uint32_t)__popcll(bal));
+        return;
+    }
+    if (blockIdx.x == na && threadIdx.x < 64) {
+        // ids removed by the merge pass: 32 counters per pair of the batch, one per 256-byte line (lane l: counters
+        // 4l .. 4l + 3, all of pair l / 8)
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
+            v += x;
+        }
+        v += (uint32_t)__shfl_xor((int)v, 1);
+        v += (uint32_t)__shfl_xor((int)v, 2);
+        v += (uint32_t)__shfl_xor((int)v, 4);  // lanes 8p .. 8p + 7 hold the removals of pair p
+        uint32_t rem[CH_KMAX];
+#pragma unroll
+        for (int p = 0; p < CH_KMAX; p++) rem[p] = (uint32_t)__shfl((int)v, 8 * p);
+        if (K == 1) {  // (a pair merged alone spreads over all the counters)
+            uint32_t tot = 0;
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) tot += rem[p];
+            rem[0] = tot;
+        }
+        if (threadIdx.x == 0) {
+            const unsigned long long n = st->n[par];
+            unsigned long long nn = n;
+            const uint32_t iter = st->iter;
+            const uint32_t mode_used = st->sel_mode;  // (what this step's k_chain_sel ran as)
+            uint32_t k_done = 0;
+            if (!noop) {
+                for (uint32_t p = 0; p < K; p++) {
+                    nn -= rem[p];
+                    IterRec *r = rec + iter + p;
+                    r->a = st->ba[p];
+                    r->b = st->bb[p];
+                    r->count = st->count;
+                    r->status = ST_OK;
+                    r->new_len = nn;
+                }
+                __threadfence_system();
+                for (uint32_t p = 0; p < K; p++) rec[iter + p].seq = (unsigned long long)(iter + p) + 1;
+                k_done = K;
+                st->iter = iter + K;
+                // the list minus the batch: anything left -> the next step takes its pairs off it
+                st->sel_mode = (st->tl_n > K) ? CH_LIST : CH_FULL;
+            } else if (status == 0 && !defer) {
+                st->sel_mode = CH_FULL;  // (an emptied list, or training is over: select when asked again)
+            }
+            if (status == 0) st->n[par ^ 1] = nn;  // (a step that merged nothing carries the length forward)
+            st->removed = 0;
+            StepRec *sr = srec + (step % STEP_RING);
+            sr->first_iter = iter;
+            sr->k = k_done;
+            sr->status = (status == 0 && defer) ? ST_DEFER : status;
+            sr->pad = mode_used;
+            sr->new_len = nn;
+            __threadfence_system();
+            sr->seq = (unsigned long long)step + 1;
+        }
+    }
+    if (noop) return;
+    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
+    const uint32_t stp = (gridDim.x - na) * blockDim.x;
+    for (uint32_t w = (blockIdx.x - na) * blockDim.x + threadIdx.x; w < nwords; w += stp) {
+        uint32_t m = smask[w];
+        if (!m) continue;
+        smask[w] = 0;
+        while (m) {
+            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
+            m &= m - 1u;
+            const StageRec r = stage[t];
+            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
+            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
+            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The batch: the longest prefix of the list (n entries in LDS) whose pairs have a != b and share no token.
+// Thread 0 of the deciding workgroup.  An empty batch with a non-empty list means a == b at its head: the
+// general path's merge.
+__device__ __forceinline__ void chain_form_batch(DevState *st, const int32_t *s_list, uint32_t n, uint32_t M,
+                                                 uint32_t iter, uint32_t nm) {
+    const uint32_t kmax = min((uint32_t)(M > CH_BATCH_COUNT ? 1 : CH_KMAX), nm - iter);
+    int32_t ta[CH_KMAX], tb[CH_KMAX];
+    uint32_t k = 0;
+    for (uint32_t e = 0; e < n && k < kmax; e++) {
+        const int32_t a = s_list[2 * e], b = s_list[2 * e + 1];
+        bool clash = a == b;
+        for (uint32_t i = 0; i < k; i++) clash |= (a == ta[i]) | (a == tb[i]) | (b == ta[i]) | (b == tb[i]);
+        if (clash) break;
+        ta[k] = a;
+        tb[k] = b;
+        k++;
+    }
+    st->adj = 0;
+    st->count = M;
+    st->ntied = n;
+    st->firstpos = NOPOS;
+    st->sel_tie = 0;
+    st->a = s_list[0];
+    st->b = s_list[1];
+    st->fin_a = s_list[0];
+    st->fin_b = s_list[1];
+    st->bk = k;
+    st->bz0 = 256u + iter;
+    st->tl_skip = k;
+    if (k == 0) {
+        st->found = 0;
+        st->defer = 1;  // a == b: the host re-runs this merge through the general path
+        return;
+    }
+    st->found = 1;
+    for (uint32_t i = 0; i < k; i++) {
+        st->ba[i] = ta[i];
+        st->bb[i] = tb[i];
+        st->badj[i] = 0;
+    }
+}
+
+// K2 of a chain step.  RECORDS: the last launch that touched the table was a k_apply_chain (its per-wave
+// records are current); otherwise the whole row-maxima array is read (the first chain step after a general
+// iteration).
+template <bool RECORDS>
+__global__ void __launch_bounds__(1024)
+k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
+            CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+            const uint4 *__restrict__ sums) {
+    __shared__ unsigned long long s_red[32];
+    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ int32_t s_list[2 * TIE_CAP];
+    __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
+    __shared__ uint32_t s_blk[LEAN_BLK_CAP], s_rows[ARGMAX_ROWS];
+    __shared__ uint32_t s_bits[RECORDS ? 1 : 2048];
+    __shared__ uint32_t s_wm[16];
+    __shared__ uint32_t s_fail, s_M, s_nt, s_nrows, s_nblk;
+    __shared__ unsigned long long s_pos[TIE_CAP];
+    __shared__ uint32_t s_order[TIE_CAP], s_keep[TIE_CAP];
+    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
+    const uint32_t iter = st->iter, nm = st->num_merges, mode = st->sel_mode;
+    const uint32_t vcur = 256u + iter;
+    const uint32_t tid = threadIdx.x;
+    if (status || defer) return;
+    if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
+        if (blockIdx.x == 0 && tid == 0) st->bk = 0;
+        return;
+    }
+    // ================= LIST mode: one workgroup, table look-ups only =================================
+    if (mode == CH_LIST) {
+        if (blockIdx.x != 0) return;
+        const uint32_t n_old = st->tl_n, skip = st->tl_skip, M = st->tl_M;
+        const uint32_t Kp = st->bk, zp = st->bz0;  // the batch the last step merged: the first `skip` entries
+        const uint32_t n_in = n_old - skip;
+        // every listed pair the batch touched: up to four places its occurrences can have gone to
+        int32_t nx = 0, ny = 0;
+        uint32_t keep = 0;
+        if (tid < n_in) {
+            const int32_t x = st->chain[2 * (skip + tid)], y = st->chain[2 * (skip + tid) + 1];
+            int32_t zx = -1, zy = -1;
+            for (uint32_t p = 0; p < Kp; p++) {
+                if (st->bb[p] == x) zx = (int32_t)(zp + p);
+                if (st->ba[p] == y) zy = (int32_t)(zp + p);
+            }
+            nx = x;
+            ny = y;
+            if (zx < 0 && zy < 0) {
+                keep = 1;  // shares no token that matters: untouched
+            } else {
+                const uint32_t c00 = mat[(size_t)x * stride + y];
+                const uint32_t c10 = zx >= 0 ? mat[(size_t)zx * stride + y] : 0u;
+                const uint32_t c01 = zy >= 0 ? mat[(size_t)x * stride + zy] : 0u;
+                const uint32_t c11 = (zx >= 0 && zy >= 0) ? mat[(size_t)zx * stride + zy] : 0u;
+                if (c00 == M) keep = 1;
+                else if (c10 == M) { keep = 1; nx = zx; }
+                else if (c01 == M) { keep = 1; ny = zy; }
+                else if (c11 == M) { keep = 1; nx = zx; ny = zy; }
+            }
+            s_keep[tid] = keep;
+        }
+        __syncthreads();
+        if (tid < n_in && keep) {
+            uint32_t r = 0;
+            for (uint32_t q = 0; q < tid; q++) r += s_keep[q];
+            s_list[2 * r] = nx;
+            s_list[2 * r + 1] = ny;
+        }
+        if (tid == 0) {
+            uint32_t n = 0;
+            for (uint32_t q = 0; q < n_in; q++) n += s_keep[q];
+            s_nt = n;
+        }
+        __syncthreads();
+        const uint32_t n = s_nt;
+        if (tid < 2 * n) st->chain[tid] = s_list[tid];
+        if (tid == 0) {
+            st->tl_n = n;
+            st->tl_skip = 0;
+            if (n == 0) st->bk = 0;  // the maximum dropped: this step merges nothing, the next one selects
+            else chain_form_batch(st, s_list, n, M, iter, nm);
+        }
+        return;
+    }
+    // ================= FULL mode ======================================================================
+    const DirtyView D{s_words, s_pref};
+    if (blockIdx.x != 0) {
+        const uint32_t nd = dirty_view_build(dbits, D);
+        if (nd == 0) return;
+        lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
+                       true, s_red, 3);
+        return;
+    }
+    // ---- the deciding workgroup ---------------------------------------------------------------
+    const int lane = lane_id(), wv = wave_id();
+    uint4 su = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t rm[SEL_RPT];
+    const uint32_t nwv = ((vcur + 255u) / 256u) * 4u;  // one record per wave of the last table update's token workgroups
+    if (RECORDS) {
+        if (tid < nwv) su = sums[tid];
+    } else {
+        select_load(rowmax, vcur, rm);
+        for (uint32_t i = tid; i < 2048; i += 1024) s_bits[i] = 0;
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_nt = 0;
+        s_nrows = 0;
+        s_nblk = 0;
+    }
+    const uint32_t nd = dirty_view_build(dbits, D);
+    if (tid == 0) st->sel_ran = 1;  // (this launch re-scans every flagged row)
+    if (nd > CH_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
+        if (tid == 0) {
+            st->found = 0;
+            st->bk = 0;
+            st->defer = 2;
+        }
+        return;
+    }
+    for (uint32_t i = tid; i < nd; i += 1024) {
+        const uint32_t x = dirty_view_row(D, i);
+        uint32_t m = 0, arg = 0;
+        const bool ok = granule_get(res + 2 * (size_t)i, tag, m) && granule_get(res + 2 * (size_t)i + 1, tag, arg);
+        if (!ok) s_fail = 1;
+        s_exrow[i] = x;
+        s_exm[i] = m;
+        s_exarg[i] = arg;
+    }
+    __syncthreads();
+    if (s_fail) {  // a row never arrived: never decide on a stale maximum
+        if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
+        return;
+    }
+    uint32_t M = 0, nt = 0;
+    if (RECORDS) {
+        auto flagged = [&](uint32_t x) -> bool { return (s_words[x >> 5] >> (x & 31)) & 1u; };
+        {
+            uint32_t m = su.x;  // (0 beyond nwv)
+            for (uint32_t i = tid; i < nd; i += 1024) m = max(m, s_exm[i]);
+            m = wave_umax_dpp(m);
+            if (lane == 0) s_wm[wv] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t mm = 0;
+            for (int i = 0; i < 16; i++) mm = max(mm, s_wm[i]);
+            s_M = mm;
+        }
+        __syncthreads();
+        M = s_M;
+        if (M != 0) {
+            auto row_at_max = [&](uint32_t x, uint32_t y) {
+                if (y != ROWARG_MULTI) {
+                    const uint32_t s = atomicAdd(&s_nt, 1u);
+                    if (s < TIE_CAP) {
+                        s_tied[2 * s] = (int32_t)x;
+                        s_tied[2 * s + 1] = (int32_t)y;
+                    }
+                } else {
+                    const uint32_t s = atomicAdd(&s_nrows, 1u);
+                    if (s < ARGMAX_ROWS) s_rows[s] = x;
+                }
+            };
+            if (su.x == M) {
+                if (su.w == 1) {
+                    row_at_max(su.y, su.z);
+                } else {  // several rows of this group of 64 attain it: look into the group
+                    const uint32_t s = atomicAdd(&s_nblk, 1u);
+                    if (s < LEAN_BLK_CAP) s_blk[s] = tid;
+                }
+            }
+            for (uint32_t i = tid; i < nd; i += 1024)
+                if (s_exm[i] == M) row_at_max(s_exrow[i], s_exarg[i]);
+            __syncthreads();
+            const uint32_t nblk = s_nblk;
+            if (nblk <= LEAN_BLK_CAP) {
+                const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
+                for (uint32_t i = wv; i < nblk; i += 16) {
+                    const uint32_t x = s_blk[i] * 64u + (uint32_t)lane;
+                    if (x < vcur && !flagged(x)) {  // (the flagged rows were left out of the record: they came in above)
+                        const uint2 v = rowma[x];
+                        if (v.x == M) row_at_max(x, v.y);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t nrows = s_nrows;
+            if (nblk <= LEAN_BLK_CAP && nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
+                for (uint32_t r = 0; r < nrows; r++) {
+                    const uint32_t x = s_rows[r];
+                    const uint32_t *row = mat + (size_t)x * stride;
+                    for (uint32_t y = tid; y < vcur; y += 1024) {
+                        if (row[y] == M) {
+                            const uint32_t s = atomicAdd(&s_nt, 1u);
+                            if (s < TIE_CAP) {
+                                s_tied[2 * s] = (int32_t)x;
+                                s_tied[2 * s + 1] = (int32_t)y;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            nt = (nblk > LEAN_BLK_CAP || nrows > ARGMAX_ROWS) ? (TIE_CAP + 1) : min(s_nt, (uint32_t)TIE_CAP + 1);
+        }
+    } else {
+        // s_words (the flag words) is the bitmap of rows whose entry in the row-maxima array is stale
+        select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{s_words, nd, s_exrow, s_exm, s_exarg});
+    }
+    if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
+        if (tid == 0) {
+            st->status = ST_EMPTY;
+            st->count = 0;
+            st->found = 0;
+            st->bk = 0;
+            st->sel_tie = 0;
+        }
+        return;
+    }
+    // ---- the list: every tied pair, in order of first occurrence ---------------------------------------
+    bool ok = nt <= TIE_CAP && (nt == 1 || gap == 0);
+    if (ok && nt > 1) {
+        (void)tie_by_index(ref, C, s_tied, nt, s_pos);
+        __syncthreads();
+        if (tid < nt && s_pos[tid] == NOPOS) s_fail = 1;  // (a tied pair the index does not lead to: not ours to order)
+        __syncthreads();
+        ok = s_fail == 0;
+        if (ok && tid < nt) {
+            const unsigned long long me = s_pos[tid];
+            uint32_t rank = 0;
+            for (uint32_t q = 0; q < nt; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
+            s_order[rank] = tid;
+        }
+    } else if (tid == 0) {
+        s_order[0] = 0;
+    }
+    __syncthreads();
+    if (!ok) {  // too many tied pairs, or short slots about: the general path decides
+        if (tid == 0) {
+            st->count = M;
+            st->ntied = nt;
+            st->found = 0;
+            st->bk = 0;
+            st->defer = 2;
+        }
+        return;
+    }
+    if (tid < nt) {
+        s_list[2 * tid] = s_tied[2 * s_order[tid]];
+        s_list[2 * tid + 1] = s_tied[2 * s_order[tid] + 1];
+    }
+    __syncthreads();
+    if (tid < 2 * nt) st->chain[tid] = s_list[tid];
+    if (tid == 0) {
+        st->tl_n = nt;
+        st->tl_M = M;
+        chain_form_batch(st, s_list, nt, M, iter, nm);
+    }
+}
+
+// host: entering chain steps after general iterations (the device counts the merges from here on)
+__global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
+    st->iter = iter;
+    st->num_merges = num_merges;
+    st->sel_mode = CH_FULL;
+    st->tl_n = st->tl_skip = 0;
+    st->bk = 0;
+    st->scan_a = st->scan_b = st->scan_z = NOROW;  // (rows to re-scan are named by the flag words alone)
+    st->chain_n = 0;
+}
+// host: a deferred chain step is about to be re-run through the general path
+__global__ void k_clear_defer_chain(DevState *st) {
+    st->defer = 0;
+    st->chain_n = 0;
+    st->sel_mode = CH_FULL;
+    st->tl_n = st->tl_skip = 0;
+    st->bk = 0;
+}
+
+}  // namespace bpe

@@ -88,6 +88,11 @@ __global__ void k_init_state(DevState *st, unsigned long long n) {
     st->scan_a = st->scan_b = st->scan_z = 0xFFFFFFFFu;
     st->chain_n = st->chain_pos = st->chain_cut = st->chain_taken = 0;
     st->sel_ran = 0;
+    st->iter = 0;
+    st->num_merges = 0;
+    st->sel_mode = CH_FULL;
+    st->tl_n = st->tl_M = st->tl_skip = 0;
+    st->bk = st->bz0 = 0;
 }
 
 }  // namespace bpe

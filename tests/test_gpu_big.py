@@ -87,7 +87,8 @@ def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golde
 # update's per-wave records)
 # (lean 4: every lean iteration selects, no chained merges; lean 5: a == b passes over every slot + index rebuild;
 # lean 6: no general-path stretches after clustered deferrals -- every tie the lean selection cannot settle is one)
-FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5), (1, 6)]
+# lean 7: chain steps (k_chain.hip) forced onto every merge; lean 8: the default engine without chain steps
+FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (2, 7), (1, 8)]
 
 
 @pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
@@ -105,11 +106,12 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
         offs = native.split_offsets(data, 4)
         assert hashlib.sha256(np.ascontiguousarray(offs, dtype=np.uint64).tobytes()).hexdigest() == g["offsets_sha256"]
     engine.set_option("sparse", sparse)
-    engine.set_option("lean", 1 if lean >= 3 else lean)
+    engine.set_option("lean", 2 if lean == 7 else (1 if lean >= 3 else lean))
+    engine.set_option("chain", 1 if lean in (1, 7) else 0)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
     engine.set_option("aa_sparse", 0 if lean == 5 else 1)
-    engine.set_option("lean_backoff", 0 if lean == 6 else 1)
+    engine.set_option("lean_backoff", 0 if lean in (6, 7) else 1)
     try:
         engine.load_bytes(data, offs)
         _check_digests(engine.train(g["merges"]), g)
@@ -121,6 +123,7 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
             assert st["lean"] > 1000 and st["deferred"] <= 400, st
     finally:
         engine.set_option("lean_backoff", 1)
+        engine.set_option("chain", 1)
         engine.set_option("sparse", 1)
         engine.set_option("lean", 1)
         engine.set_option("lean_sum", 1)

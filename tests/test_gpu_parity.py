@@ -124,21 +124,26 @@ def test_train_golden_cases(golden, engine, native):
 # but a == b passes visit every slot and mark what they rewrite for an index rebuild (option aa_sparse = 0)
 VARIANTS = [(0, 0, 0, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 1), (1, 1, 0, 1, 1), (0, 1, 0, 1, 1), (1, 0, 2, 1, 1),
             (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2),
-            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4), (1, 0, 2, 2, 5)]
+            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4), (1, 0, 2, 2, 5), (1, 0, 2, 1, 7), (1, 0, 2, 2, 7), (1, 0, 2, 1, 8)]
 
 
 def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
+    """lean: 0 never | 1 the default engine (chain steps, k_chain.hip, wherever lean iterations would run with the
+    index live) | 2 lean iterations forced onto every merge, no chain steps | 3, 4, 5 variants of 2 (selection from
+    the whole row-maxima array; no chained merges; a == b passes over every slot) | 7 = 2 with chain steps |
+    8 = 1 without chain steps (round 3's default engine)"""
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
     engine.set_option("slots", slots)
     engine.set_option("sparse", sparse)
-    engine.set_option("lean", 2 if lean >= 3 else lean)
+    engine.set_option("lean", 1 if lean in (1, 8) else (2 if lean >= 2 else 0))
+    engine.set_option("chain", 1 if lean in (1, 7) else 0)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
     engine.set_option("aa_sparse", 0 if lean == 5 else 1)
     # lean >= 2 forces the lean iterations onto every merge (coverage of their kernels and of the hand-back):
     # no general-path stretches after clustered deferrals there
-    engine.set_option("lean_backoff", 0 if lean >= 2 else 1)
+    engine.set_option("lean_backoff", 0 if lean in (2, 3, 4, 5, 7) else 1)
 
 
 def reset_variant(engine):
@@ -190,17 +195,21 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
         res = engine.train(nm)
         stats = engine.train_stats()
         if sparse == 2:
-            assert stats["sparse"] == nm
+            # every a != b pass a sparse one; a chain step (k_chain.hip) is ONE pass for all the merges of its batch
+            chain_merges = stats["chained"] + stats["selections"] if stats["steps"] else 0
+            assert stats["sparse"] == nm - chain_merges + stats["steps"]
         if slots == 2 and mode == 1:
             n_same = sum(a == b for a, b in exp[0])
             if lean == 0:
                 assert stats["lean"] == 0 and stats["deferred"] == 0
-            elif lean >= 2:
+            elif lean in (2, 3, 4, 5, 7):
                 # every merge is a lean iteration or was handed back to the general path: all a == b ones
                 # are, and (index live) those whose tie the lean selection could not settle by itself
                 assert stats["lean"] + stats["deferred"] == nm and stats["deferred"] >= n_same
-                if sparse != 2:
+                if sparse != 2 and lean != 7:
                     assert stats["deferred"] == n_same
+                if lean == 7:
+                    assert stats["steps"] > 0 and stats["selections"] <= stats["steps"]
             else:
                 assert stats["lean"] > 0
         assert res["pairs"] == exp[0]
