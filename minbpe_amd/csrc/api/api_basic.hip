@@ -150,6 +150,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lean_select = value != 0;
     } else if (!strcmp(name, "aa_sparse")) {
         c->aa_sparse = value != 0;
+    } else if (!strcmp(name, "chain_scan")) {
+        if (value < 1 || value > 255) return fail(c, BPE_E_ARG, "chain_scan must be 1..255");
+        c->chain_scan = value;
     } else if (!strcmp(name, "chain")) {
         c->chain = value != 0;
     } else if (!strcmp(name, "lean_chain")) {

@@ -90,6 +90,8 @@ struct bpe_ctx {
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     int aa_sparse = 1;                        // option "aa_sparse": a sparse iteration's a == b pass works through a candidate list and keeps the index current itself (no rebuild after it)
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
+    int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
+                                              // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
     int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
                                               // token-disjoint pairs merged in one pass) instead of lean iterations, wherever those would run with the index live
     StepRec *h_srec = nullptr;                // pinned ring of step records (STEP_RING entries)
@@ -1036,10 +1038,10 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     C.tie_window = 0;
     C.aa = 0;
     if (records)
-        hipLaunchKernelGGL(k_chain_sel<true>, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+        hipLaunchKernelGGL(k_chain_sel<true>, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
     else
-        hipLaunchKernelGGL(k_chain_sel<false>, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+        hipLaunchKernelGGL(k_chain_sel<false>, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
     LAUNCHCHK(c, "k_chain_sel");
     TRY(prof_end(c));

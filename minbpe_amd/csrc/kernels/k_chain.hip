@@ -59,10 +59,11 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
 }
 
 // One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip; sparse form, index live,
-// global delta replicas) for K token-disjoint pairs at once.  pa / pb: the pairs (LDS), z0: pair p becomes z0 + p.
+// global delta replicas) for K >= 2 token-disjoint pairs at once.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
+// pb1[0] a word that matches nothing, z0: pair p becomes z0 + p.
 __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, const uint32_t t, const AbArgs &A,
-                                                 const uint32_t *pa, const uint32_t *pb, const uint32_t K,
-                                                 const uint32_t z0) {
+                                                 const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
+                                                 const uint32_t K, const uint32_t z0) {
     const int lane = lane_id();
     const uint32_t Tl = min(A.T, A.st->tlive);
     // ---- (1) every load that does not depend on another one -------------------------------
@@ -128,24 +129,38 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
         rb[j] = 0;
         jc[j] = 0;
     }
+    // Two stages, so that the work per word does not grow with K twice over (four waves share a SIMD: with
+    // every word compared against every pair the pass was bound by instruction issue, not by the slot's
+    // latency): which pair's FIRST token is this word (K compares), then ONE compare of the next word with that
+    // pair's second token, fetched from LDS by pair number (pb1[0] matches nothing: no pair).
     uint32_t s = 0;  // carry: my first word is the second word of a site that starts at the previous slot's last word
+    uint32_t ia[MJ];  // a nibble per word: the pair whose first token it is, + 1 (tokens are distinct: at most one)
+#pragma unroll
+    for (int j = 0; j < MJ; j++) ia[j] = 0;
+    uint32_t ip = 0;
     for (uint32_t p = 0; p < K; p++) {
-        const uint32_t a = pa[p], b = pb[p];
+        const uint32_t a = pa[p];
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
-            // (the word after my four: recomputed per pair -- two cross-lane moves against a register held across the loop)
-            const uint32_t up = (j < MJ - 1) ? lane_first(x[(j + 1) % MJ][0]) : tail[0];
-            const uint32_t nxw = lane_next(x[j][0], up);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t nxt = (k < 3) ? x[j][k + 1] : nxw;
-                const uint32_t m = (uint32_t)(((x[j][k] & IDMASK) == a) & ((nxt & NWMASK) == b));
-                rb[j] |= m << k;
-                jc[j] |= (m * (p + 1u)) << (4 * k);
-            }
+            for (int k = 0; k < 4; k++) ia[j] |= ((x[j][k] & IDMASK) == a) ? (p + 1u) << (4 * k) : 0u;
         }
-        s |= (uint32_t)((prev1 != INVALID_WORD) & ((prev1 & IDMASK) == a) & ((first & NWMASK) == b));
+        ip = ((prev1 & IDMASK) == a) ? p + 1u : ip;
     }
+#pragma unroll
+    for (int j = 0; j < MJ; j++) {
+        const uint32_t up = (j < MJ - 1) ? lane_first(x[(j + 1) % MJ][0]) : tail[0];
+        const uint32_t nxw = lane_next(x[j][0], up);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t nxt = (k < 3) ? x[j][k + 1] : nxw;
+            const uint32_t i = (ia[j] >> (4 * k)) & 15u;
+            const uint32_t m = (uint32_t)((nxt & NWMASK) == pb1[i]);
+            rb[j] |= m << k;
+            jc[j] |= (m ? i : 0u) << (4 * k);
+        }
+    }
+    s = (uint32_t)((prev1 != INVALID_WORD) & ((first & NWMASK) == pb1[ip]));
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const int nb = (int)len - (j * 256 + lane * 4);
@@ -226,21 +241,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
         if (total < 3 && t + 1 < Tl) A.st->gap = 1;
     }
     if (!sites) return;  // carry only: the site belongs to the previous slot
-    // ---- ids removed, per pair: every site is counted by the slot that owns its first word ----
-    for (uint32_t p = 0; p < K; p++) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < MJ; j++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) c += (uint32_t)(((mb[j] >> k) & 1u) & (((jc[j] >> (4 * k)) & 15u) == p + 1u));
-        }
-        if (!__any(c != 0)) continue;  // (uniform)
-        c = wave_sum_u32(c);
-        // (a pair merged alone can have 10^5 changed slots: all 256 counters, as a lean pass does)
-        if (lane == 0) atomicAdd(&A.removed[(K == 1 ? (t & 255u) : (p * 32u + (t & 31u))) * REMOVED_STRIDE], c);
-    }
     // ---- (7) pair-table delta of my sites, as the sequential merges would charge it ------------
-    const uint32_t nrep = 1u << (A.vcap >> 24);
     const uint32_t vc = A.vcap & 0xFFFFFFu;
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
@@ -279,7 +280,10 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
             const int q = j * 256 + lane * 4 + k;
             const uint32_t p = ((jc[j] >> (4 * k)) & 15u) - 1u;
             const uint32_t Z = z0 + p;
-            const uint32_t rho = (K == 1) ? (t & (nrep - 1u)) : (p * (uint32_t)CH_RSTRIDE + (t & (uint32_t)(CH_REP - 1)));
+            // ids removed, per pair: every site is counted by the slot that owns its first word (a batch's pairs
+            // have at most CH_BATCH_COUNT sites each: one atomic per site, 32 counters per pair)
+            atomicAdd(&A.removed[(p * 32u + (t & 31u)) * REMOVED_STRIDE], 1u);
+            const uint32_t rho = p * (uint32_t)CH_RSTRIDE + (t & (uint32_t)(CH_REP - 1));
             uint32_t *dl = A.delta + delta_rep_off(rho, vc);  // SL of pair p
             uint32_t *dr = dl + vc;                             // SR of pair p
             const uint32_t wa = W[k + 2];
@@ -318,7 +322,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     __shared__ __attribute__((aligned(16))) uint32_t s_out[LEAN_MT / 64][TILE2];
     __shared__ uint32_t s_list[LEAN_SUB * 32];
     __shared__ uint32_t s_tot[2];
-    __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX];
+    __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
     DevState *st = A.st;
     // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
     const uint32_t ran = st->sel_ran;
@@ -333,14 +337,24 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     if (threadIdx.x < CH_KMAX) {
         s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
         s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        s_pb1[threadIdx.x + 1] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        if (threadIdx.x == 0) s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
     }
     __syncthreads();
     const uint32_t Tl = min(A.T, st->tlive);
     constexpr uint32_t NWV = LEAN_MT / 64;
+    // a batch of one: the single-pair rewrite (merge_ab_wave, k_slots2.hip) -- no per-pair loops, format B's
+    // adj in st->adj, all 256 removal counters
+    AbArgs A1 = A;
+    A1.newid = z0;
+    const uint32_t a0 = s_pa[0], b0 = s_pb[0];
+    auto do_slot = [&](uint32_t t) {
+        if (K == 1) merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
+        else merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, s_pb1, K, z0);
+    };
     if (!use_index || st->gap != 0) {  // short slots about: visit everything
         const uint32_t nw = gridDim.x * NWV;
-        for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw)
-            merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, K, z0);
+        for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw) do_slot(t);
         return;
     }
     const uint32_t nwords = (Tl + 31) / 32;
@@ -373,8 +387,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
             }
         }
         __syncthreads();
-        for (uint32_t i = wave_id(); i < n; i += NWV)
-            merge_chain_wave(s_out[wave_id()], s_list[i], A, s_pa, s_pb, K, z0);
+        for (uint32_t i = wave_id(); i < n; i += NWV) do_slot(s_list[i]);
         __syncthreads();  // (the list is rewritten by the next round)
     }
 }
@@ -410,7 +423,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
         bool flagged = false;
         if (K == 1) {
             // ---- one pair: all nrep replicas, (t,a) loaded up front (no returning atomic) ----------------
-            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0, adj = st->badj[0];
+            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0, adj = st->adj;  // (merge_ab_wave's adj)
             uint32_t x[16][2];
             auto load_batch = [&](uint32_t r0) {
 #pragma unroll
@@ -647,6 +660,10 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     }
     // ================= LIST mode: one workgroup, table look-ups only =================================
     if (mode == CH_LIST) {
+        // (Re-scanning the flagged rows here, off the critical path, so that the next FULL selection finds only one
+        // step's worth of them, was tried: +3 us on every LIST step for the 31 extra workgroups, -3 us on a FULL
+        // one -- whose time goes to locating the tied pairs, not to the rows -- and flags must then not be cleared
+        // by a step that merges nothing, or the records lose those rows.  Dropped.)
         if (blockIdx.x != 0) return;
         const uint32_t n_old = st->tl_n, skip = st->tl_skip, M = st->tl_M;
         const uint32_t Kp = st->bk, zp = st->bz0;  // the batch the last step merged: the first `skip` entries

@@ -17,13 +17,17 @@ namespace bpe {
 // Layout: bucket-major, idx[h * stride + g].  A query reads the three bucket rows of one pair --
 // contiguous, so that the single block that lists a pass's candidates (below) or breaks a tie
 // (k_select) streams a few KB instead of touching one cache line per group.
-// (16 Ki buckets for the ~1000 pairs of a 1024-id slot: about 16 % of a slot's bits set with three
-// hashes, false positives around 0.4 %)
-constexpr uint32_t IDX_H = 16384;
+// (32 Ki buckets for the ~1000 pairs of a 1024-id slot: about 9 % of a slot's bits set with three
+// hashes, false positives around 0.07 %.  With 16 Ki buckets they were 0.46 %: ~800 of the 195 k slots of a
+// late 1 GB stream per pair, more than the ~650 slots that do hold a late pair -- and a chain step's pass
+// (k_chain.hip) visits the candidates of all its pairs.)
+constexpr uint32_t IDX_H = 32768;
+constexpr int IDX_SHIFT = 17;  // 32 - log2(IDX_H)
+static_assert((1u << (32 - IDX_SHIFT)) == IDX_H, "hash width");
 __device__ __forceinline__ void pair_hash(uint32_t x, uint32_t y, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
-    h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> 18;
-    h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> 18;
-    h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> 18;
+    h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> IDX_SHIFT;
+    h2 = ((x * 0xC2B2AE3Du) + (y * 0x27D4EB2Fu) + 0x165667B1u) >> IDX_SHIFT;
+    h3 = (((x + 0x7F4A7C15u) * 0xD6E8FEB9u) ^ ((y + 0x51ED270Bu) * 0xA24BAED5u)) >> IDX_SHIFT;
 }
 __device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t stride, uint32_t owner, uint32_t x,
                                           uint32_t y) {

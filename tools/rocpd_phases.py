@@ -21,9 +21,9 @@ def short(name):
     return s
 
 
-SEL = ("k_select<", "k_rowsel_lean", "k_sel_lean")
+SEL = ("k_select<", "k_rowsel_lean", "k_sel_lean", "k_chain_sel")
 it = -1
-per = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))  # bin -> kernel -> [calls, us]
+per = defaultdict(lambda: defaultdict(lambda: [0, 0.0, []]))  # bin -> kernel -> [calls, us, durations]
 span = defaultdict(lambda: [None, None, 0])
 for name, s, e in rows:
     k = short(name)
@@ -36,6 +36,7 @@ for name, s, e in rows:
     c = per[b][k]
     c[0] += 1
     c[1] += (e - s) / 1e3
+    c[2].append((e - s) / 1e3)
     sp = span[b]
     sp[0] = s if sp[0] is None else sp[0]
     sp[1] = e
@@ -49,5 +50,7 @@ for b in per:
         prev_it = span[b][2]
     out[b] = {"iterations": n_it, "wall_us": round((span[b][1] - span[b][0]) / 1e3, 1),
               "us_per_iteration": round((span[b][1] - span[b][0]) / 1e3 / max(n_it, 1), 2),
-              "kernels": {k: {"calls": v[0], "total_us": round(v[1], 1), "avg_us": round(v[1] / v[0], 2)} for k, v in ks}}
+              "kernels": {k: {"calls": v[0], "total_us": round(v[1], 1), "avg_us": round(v[1] / v[0], 2),
+                                  "p10_p50_p90_us": [round(sorted(v[2])[int(q * (len(v[2]) - 1))], 2) for q in (0.1, 0.5, 0.9)]}
+                              for k, v in ks}}
 print(json.dumps(out, indent=1))
