@@ -90,6 +90,8 @@ struct bpe_ctx {
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     int aa_sparse = 1;                        // option "aa_sparse": a sparse iteration's a == b pass works through a candidate list and keeps the index current itself (no rebuild after it)
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
+    int chain_extend = 1;                     // option "chain_extend": a chain step's batch may reach below the maximum count (k_chain_sel)
+    unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
     int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
                                               // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
     int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
@@ -1037,12 +1039,14 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     C.tie_index = 1;
     C.tie_window = 0;
     C.aa = 0;
-    if (records)
-        hipLaunchKernelGGL(k_chain_sel<true>, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
-                           c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
-    else
-        hipLaunchKernelGGL(k_chain_sel<false>, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
-                           c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_lean_sum);
+    (void)records;
+    if (!c->d_chain_req) {
+        HIPCHK(c, hipMalloc((void **)&c->d_chain_req, 64 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_chain_req, 0, 64 * sizeof(unsigned long long), c->stream));
+    }
+    hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                       c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
+                       (uint32_t)(c->chain_extend && c->chain_scan >= CH_KMAX - 1));  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
     LAUNCHCHK(c, "k_chain_sel");
     TRY(prof_end(c));
     AbArgs A;

@@ -57,9 +57,9 @@ __host__ __device__ inline size_t delta_rep_off(uint32_t r, uint32_t stride) {
 // Chain steps (k_chain.hip): the tied pairs at the maximum are kept as a LIST in first-occurrence order, and the
 // longest prefix of it whose pairs have a != b and share no token -- at most CH_KMAX of them -- is merged in ONE pass.
 constexpr int CH_KMAX = 8;
-constexpr uint32_t CH_BATCH_COUNT = 1u << 14;  // a pair with more sites than this is merged alone (all delta replicas for it)
-constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per pair of a batch ...
-constexpr int CH_REP = 4;                      // ... of which a batch of two or more uses this many per pair
+constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per pair of a batch: all of them while its pairs have
+constexpr uint32_t CH_REP_COUNT = 4096;        // more sites than this (hot tokens queue ~11 ns per same-address atomic) ...
+constexpr int CH_REP = 4;                      // ... this many otherwise (the table update folds every replica it is told to)
 static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must fit the replica blocks");
 static_assert(CH_KMAX * 32 <= 256, "removal counters: 32 per pair of a batch");
 constexpr uint32_t CH_FULL = 0, CH_LIST = 1;   // DevState::sel_mode
@@ -156,6 +156,8 @@ struct DevState {
     uint32_t bk, bz0;             // this step's batch: pairs, the new id of the first one
     int32_t ba[CH_KMAX], bb[CH_KMAX];
     uint32_t badj[CH_KMAX];       // delta format B, per pair of the batch: sites whose right neighbour starts a site of the SAME pair
+    uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum: k_chain_sel)
+    uint32_t brep;                // delta replicas per pair of this batch (CH_REP or CH_RSTRIDE)
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -63,7 +63,7 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
 // pb1[0] a word that matches nothing, z0: pair p becomes z0 + p.
 __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, const uint32_t t, const AbArgs &A,
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
-                                                 const uint32_t K, const uint32_t z0) {
+                                                 const uint32_t K, const uint32_t z0, const uint32_t brep) {
     const int lane = lane_id();
     const uint32_t Tl = min(A.T, A.st->tlive);
     // ---- (1) every load that does not depend on another one -------------------------------
@@ -280,10 +280,10 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
             const int q = j * 256 + lane * 4 + k;
             const uint32_t p = ((jc[j] >> (4 * k)) & 15u) - 1u;
             const uint32_t Z = z0 + p;
-            // ids removed, per pair: every site is counted by the slot that owns its first word (a batch's pairs
-            // have at most CH_BATCH_COUNT sites each: one atomic per site, 32 counters per pair)
+            // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
+            // site, 32 counters per pair)
             atomicAdd(&A.removed[(p * 32u + (t & 31u)) * REMOVED_STRIDE], 1u);
-            const uint32_t rho = p * (uint32_t)CH_RSTRIDE + (t & (uint32_t)(CH_REP - 1));
+            const uint32_t rho = p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u));
             uint32_t *dl = A.delta + delta_rep_off(rho, vc);  // SL of pair p
             uint32_t *dr = dl + vc;                             // SR of pair p
             const uint32_t wa = W[k + 2];
@@ -333,7 +333,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     }
     const uint32_t K = st->bk;
     if (st->status || st->defer || K == 0) return;
-    const uint32_t z0 = st->bz0;
+    const uint32_t z0 = st->bz0, brep = st->brep;
     if (threadIdx.x < CH_KMAX) {
         s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
         s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
@@ -350,7 +350,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
         if (K == 1) merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
-        else merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, s_pb1, K, z0);
+        else merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, s_pb1, K, z0, brep);
     };
     if (!use_index || st->gap != 0) {  // short slots about: visit everything
         const uint32_t nw = gridDim.x * NWV;
@@ -459,15 +459,18 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             if (live && t == b) mat[(size_t)a * stride + b] = 0;  // no (a,b) survives the merge (F2)
             flagged |= live && ((t == a) | (t == b) | (t == Z));
         } else {
-            // ---- a batch: CH_REP replicas per pair, everything in flight at once ---------------------------
+            // ---- a batch: brep replicas per pair ------------------------------------------------------------
+            const uint32_t brep = st->brep;
             uint32_t x[CH_KMAX][CH_REP][2];
+            if (brep == (uint32_t)CH_REP) {  // (everything in flight at once)
 #pragma unroll
-            for (int p = 0; p < CH_KMAX; p++) {
+                for (int p = 0; p < CH_KMAX; p++) {
 #pragma unroll
-                for (int r = 0; r < CH_REP; r++) {
-                    const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                    x[p][r][0] = (live && (uint32_t)p < K) ? delta[o + t] : 0u;
-                    x[p][r][1] = (live && (uint32_t)p < K) ? delta[o + vc + t] : 0u;
+                    for (int r = 0; r < CH_REP; r++) {
+                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                        x[p][r][0] = (live && (uint32_t)p < K) ? delta[o + t] : 0u;
+                        x[p][r][1] = (live && (uint32_t)p < K) ? delta[o + vc + t] : 0u;
+                    }
                 }
             }
 #pragma unroll
@@ -475,13 +478,31 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                 if ((uint32_t)p >= K) break;  // (uniform)
                 const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + (uint32_t)p, adj = st->badj[p];
                 uint32_t sl = 0, sr = 0;
+                if (brep == (uint32_t)CH_REP) {
 #pragma unroll
-                for (int r = 0; r < CH_REP; r++) {
-                    const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                    if (x[p][r][0]) delta[o + t] = 0;
-                    if (x[p][r][1]) delta[o + vc + t] = 0;
-                    sl += x[p][r][0];
-                    sr += x[p][r][1];
+                    for (int r = 0; r < CH_REP; r++) {
+                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                        if (x[p][r][0]) delta[o + t] = 0;
+                        if (x[p][r][1]) delta[o + vc + t] = 0;
+                        sl += x[p][r][0];
+                        sr += x[p][r][1];
+                    }
+                } else {  // (pairs with thousands of sites: all CH_RSTRIDE replicas, one pair at a time)
+                    uint32_t y[CH_RSTRIDE][2];
+#pragma unroll
+                    for (int r = 0; r < CH_RSTRIDE; r++) {
+                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                        y[r][0] = live ? delta[o + t] : 0u;
+                        y[r][1] = live ? delta[o + vc + t] : 0u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < CH_RSTRIDE; r++) {
+                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
+                        if (y[r][0]) delta[o + t] = 0;
+                        if (y[r][1]) delta[o + vc + t] = 0;
+                        sl += y[r][0];
+                        sr += y[r][1];
+                    }
                 }
                 const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
                 if (sl) {
@@ -544,7 +565,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                     IterRec *r = rec + iter + p;
                     r->a = st->ba[p];
                     r->b = st->bb[p];
-                    r->count = st->count;
+                    r->count = st->bcnt[p];
                     r->status = ST_OK;
                     r->new_len = nn;
                 }
@@ -593,7 +614,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 // general path's merge.
 __device__ __forceinline__ void chain_form_batch(DevState *st, const int32_t *s_list, uint32_t n, uint32_t M,
                                                  uint32_t iter, uint32_t nm) {
-    const uint32_t kmax = min((uint32_t)(M > CH_BATCH_COUNT ? 1 : CH_KMAX), nm - iter);
+    const uint32_t kmax = min((uint32_t)CH_KMAX, nm - iter);
     int32_t ta[CH_KMAX], tb[CH_KMAX];
     uint32_t k = 0;
     for (uint32_t e = 0; e < n && k < kmax; e++) {
@@ -627,28 +648,72 @@ __device__ __forceinline__ void chain_form_batch(DevState *st, const int32_t *s_
         st->ba[i] = ta[i];
         st->bb[i] = tb[i];
         st->badj[i] = 0;
+        st->bcnt[i] = M;
     }
+    st->brep = M > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
 }
 
-// K2 of a chain step.  RECORDS: the last launch that touched the table was a k_apply_chain (its per-wave
-// records are current); otherwise the whole row-maxima array is read (the first chain step after a general
-// iteration).
-template <bool RECORDS>
+// Largest entry of a table row except column excl, by a 1024-thread workgroup (thread 0 gets it).
+__device__ __forceinline__ uint32_t row_scan_excl(const uint32_t *__restrict__ row, uint32_t ncols, uint32_t excl,
+                                                  uint32_t *s_r16) {
+    uint32_t m = 0;
+    const uint32_t n4 = (ncols + 3) & ~3u;
+    constexpr int U = 8;
+    for (uint32_t base = 0; base < n4; base += U * 4096) {
+        uint4 q[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
+            q[u] = (y < n4) ? *reinterpret_cast<const uint4 *>(row + y) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
+            const uint32_t v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (y + k != excl && y + k < ncols) m = max(m, v[k]);
+        }
+    }
+    m = wave_umax_dpp(m);
+    __syncthreads();
+    if (lane_id() == 0) s_r16[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < 16; w++) m = max(m, s_r16[w]);
+    return m;
+}
+
+// K2 of a chain step.
+// LIST mode: one workgroup, table look-ups only (see the head of this file).
+// FULL mode: workgroup 0 reads the whole row-maxima array (32 rows per thread, in registers) while workgroups 1..
+// re-scan the flagged rows and hand their maxima over; the pairs at the maximum M, located through the index and
+// sorted, are the list; the batch is its longest token-disjoint prefix.  If that prefix is the WHOLE list the batch
+// goes on BELOW the maximum: the argument for ties holds for any prefix of the ranking by (count, first
+// occurrence) -- a created pair inherits at most the count and the place of a pair that ranks after the prefix.
+// The device has only every row's maximum, so it takes, level by level, the largest row maximum below the last
+// one if exactly one row attains it with one column (a != b, no shared token) -- and then makes sure that no
+// entry HIDDEN behind the maximum of a row it took from ranks among the taken pairs: workgroups 1..k-1 scan those
+// rows for their second largest entry, and the batch is cut before the first pair whose count does not exceed
+// them all (tests/test_list_model.py restates exactly this against the reference semantics).
+// req: the request / answer words of that exchange ([0] = tag | n, [1 + j] = tag | row << 16 | column,
+// [16 + j] = tag | second maximum), all self-validating (the launch tag never repeats).
 __global__ void __launch_bounds__(1024)
 k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
             CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-            const uint4 *__restrict__ sums) {
+            unsigned long long *__restrict__ req, uint32_t extend) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ int32_t s_list[2 * TIE_CAP];
     __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
-    __shared__ uint32_t s_blk[LEAN_BLK_CAP], s_rows[ARGMAX_ROWS];
-    __shared__ uint32_t s_bits[RECORDS ? 1 : 2048];
-    __shared__ uint32_t s_wm[16];
-    __shared__ uint32_t s_fail, s_M, s_nt, s_nrows, s_nblk;
+    __shared__ uint32_t s_bits[2048];
+    __shared__ uint32_t s_r16[16], s_c16[16];
+    __shared__ uint32_t s_fail, s_nt, s_k, s_m2, s_hit, s_hitarg, s_stop;
     __shared__ unsigned long long s_pos[TIE_CAP];
     __shared__ uint32_t s_order[TIE_CAP], s_keep[TIE_CAP];
+    __shared__ int32_t s_ba[CH_KMAX], s_bb[CH_KMAX];
+    __shared__ uint32_t s_bc[CH_KMAX], s_sec[CH_KMAX];
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
     const uint32_t iter = st->iter, nm = st->num_merges, mode = st->sel_mode;
     const uint32_t vcur = 256u + iter;
@@ -663,7 +728,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         // (Re-scanning the flagged rows here, off the critical path, so that the next FULL selection finds only one
         // step's worth of them, was tried: +3 us on every LIST step for the 31 extra workgroups, -3 us on a FULL
         // one -- whose time goes to locating the tied pairs, not to the rows -- and flags must then not be cleared
-        // by a step that merges nothing, or the records lose those rows.  Dropped.)
+        // by a step that merges nothing.  Dropped.)
         if (blockIdx.x != 0) return;
         const uint32_t n_old = st->tl_n, skip = st->tl_skip, M = st->tl_M;
         const uint32_t Kp = st->bk, zp = st->bz0;  // the batch the last step merged: the first `skip` entries
@@ -721,27 +786,36 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     const DirtyView D{s_words, s_pref};
     if (blockIdx.x != 0) {
         const uint32_t nd = dirty_view_build(dbits, D);
-        if (nd == 0) return;
-        lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
-                       true, s_red, 3);
+        if (nd) lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
+                               true, s_red, 3);
+        // workgroups 1 .. CH_KMAX - 1 stay for the deciding workgroup's question: the second largest entry of a row
+        if (!extend || blockIdx.x >= CH_KMAX) return;
+        uint32_t n = 0, rc = 0;
+        if (tid == 0) {
+            if (!granule_get(req, tag, n)) n = 0;  // (never asked: the deciding workgroup reports its own failures)
+            if (blockIdx.x <= n && !granule_get(req + blockIdx.x, tag, rc)) n = 0;
+            s_k = n;
+            s_m2 = rc;
+        }
+        __syncthreads();
+        if (blockIdx.x > s_k) return;
+        const uint32_t x = s_m2 >> 16, y = s_m2 & 0xFFFFu;
+        const uint32_t sec = row_scan_excl(mat + (size_t)x * stride, vcur, y, s_r16);
+        if (tid == 0) granule_put(req + 16 + blockIdx.x, tag, sec);
         return;
     }
     // ---- the deciding workgroup ---------------------------------------------------------------
-    const int lane = lane_id(), wv = wave_id();
-    uint4 su = make_uint4(0u, 0u, 0u, 0u);
+    // (whatever happens below, the waiting workgroups get an answer: n = 0 unless rows are to be scanned)
+    auto dismiss = [&]() {
+        if (extend && tid == 0) granule_put(req, tag, 0u);
+    };
     uint32_t rm[SEL_RPT];
-    const uint32_t nwv = ((vcur + 255u) / 256u) * 4u;  // one record per wave of the last table update's token workgroups
-    if (RECORDS) {
-        if (tid < nwv) su = sums[tid];
-    } else {
-        select_load(rowmax, vcur, rm);
-        for (uint32_t i = tid; i < 2048; i += 1024) s_bits[i] = 0;
-    }
+    select_load(rowmax, vcur, rm);
+    for (uint32_t i = tid; i < 2048; i += 1024) s_bits[i] = 0;
     if (tid == 0) {
         s_fail = 0;
         s_nt = 0;
-        s_nrows = 0;
-        s_nblk = 0;
+        s_stop = 0;
     }
     const uint32_t nd = dirty_view_build(dbits, D);
     if (tid == 0) st->sel_ran = 1;  // (this launch re-scans every flagged row)
@@ -751,6 +825,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             st->bk = 0;
             st->defer = 2;
         }
+        dismiss();
         return;
     }
     for (uint32_t i = tid; i < nd; i += 1024) {
@@ -765,84 +840,12 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     __syncthreads();
     if (s_fail) {  // a row never arrived: never decide on a stale maximum
         if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
+        dismiss();
         return;
     }
     uint32_t M = 0, nt = 0;
-    if (RECORDS) {
-        auto flagged = [&](uint32_t x) -> bool { return (s_words[x >> 5] >> (x & 31)) & 1u; };
-        {
-            uint32_t m = su.x;  // (0 beyond nwv)
-            for (uint32_t i = tid; i < nd; i += 1024) m = max(m, s_exm[i]);
-            m = wave_umax_dpp(m);
-            if (lane == 0) s_wm[wv] = m;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t mm = 0;
-            for (int i = 0; i < 16; i++) mm = max(mm, s_wm[i]);
-            s_M = mm;
-        }
-        __syncthreads();
-        M = s_M;
-        if (M != 0) {
-            auto row_at_max = [&](uint32_t x, uint32_t y) {
-                if (y != ROWARG_MULTI) {
-                    const uint32_t s = atomicAdd(&s_nt, 1u);
-                    if (s < TIE_CAP) {
-                        s_tied[2 * s] = (int32_t)x;
-                        s_tied[2 * s + 1] = (int32_t)y;
-                    }
-                } else {
-                    const uint32_t s = atomicAdd(&s_nrows, 1u);
-                    if (s < ARGMAX_ROWS) s_rows[s] = x;
-                }
-            };
-            if (su.x == M) {
-                if (su.w == 1) {
-                    row_at_max(su.y, su.z);
-                } else {  // several rows of this group of 64 attain it: look into the group
-                    const uint32_t s = atomicAdd(&s_nblk, 1u);
-                    if (s < LEAN_BLK_CAP) s_blk[s] = tid;
-                }
-            }
-            for (uint32_t i = tid; i < nd; i += 1024)
-                if (s_exm[i] == M) row_at_max(s_exrow[i], s_exarg[i]);
-            __syncthreads();
-            const uint32_t nblk = s_nblk;
-            if (nblk <= LEAN_BLK_CAP) {
-                const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
-                for (uint32_t i = wv; i < nblk; i += 16) {
-                    const uint32_t x = s_blk[i] * 64u + (uint32_t)lane;
-                    if (x < vcur && !flagged(x)) {  // (the flagged rows were left out of the record: they came in above)
-                        const uint2 v = rowma[x];
-                        if (v.x == M) row_at_max(x, v.y);
-                    }
-                }
-            }
-            __syncthreads();
-            const uint32_t nrows = s_nrows;
-            if (nblk <= LEAN_BLK_CAP && nrows <= ARGMAX_ROWS && s_nt <= TIE_CAP) {
-                for (uint32_t r = 0; r < nrows; r++) {
-                    const uint32_t x = s_rows[r];
-                    const uint32_t *row = mat + (size_t)x * stride;
-                    for (uint32_t y = tid; y < vcur; y += 1024) {
-                        if (row[y] == M) {
-                            const uint32_t s = atomicAdd(&s_nt, 1u);
-                            if (s < TIE_CAP) {
-                                s_tied[2 * s] = (int32_t)x;
-                                s_tied[2 * s + 1] = (int32_t)y;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            nt = (nblk > LEAN_BLK_CAP || nrows > ARGMAX_ROWS) ? (TIE_CAP + 1) : min(s_nt, (uint32_t)TIE_CAP + 1);
-        }
-    } else {
-        // s_words (the flag words) is the bitmap of rows whose entry in the row-maxima array is stale
-        select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{s_words, nd, s_exrow, s_exm, s_exarg});
-    }
+    // s_words (the flag words) is the bitmap of rows whose entry in the row-maxima array is stale
+    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{s_words, nd, s_exrow, s_exm, s_exarg});
     if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
         if (tid == 0) {
             st->status = ST_EMPTY;
@@ -851,6 +854,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             st->bk = 0;
             st->sel_tie = 0;
         }
+        dismiss();
         return;
     }
     // ---- the list: every tied pair, in order of first occurrence ---------------------------------------
@@ -879,6 +883,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             st->bk = 0;
             st->defer = 2;
         }
+        dismiss();
         return;
     }
     if (tid < nt) {
@@ -891,6 +896,121 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         st->tl_n = nt;
         st->tl_M = M;
         chain_form_batch(st, s_list, nt, M, iter, nm);
+        const uint32_t k = st->bk;
+        s_k = k;
+        for (uint32_t i = 0; i < k; i++) {
+            s_ba[i] = st->ba[i];
+            s_bb[i] = st->bb[i];
+            s_bc[i] = M;
+        }
+    }
+    __syncthreads();
+    const uint32_t k1 = s_k;
+    const uint32_t kmax = min((uint32_t)CH_KMAX, nm - iter);
+    if (!extend || k1 == 0 || k1 != nt || k1 >= kmax) {  // the list goes on (or a == b heads it): nothing below M yet
+        dismiss();
+        return;
+    }
+    // ---- below the maximum: one row maximum per level, while it is unambiguous ---------------------------
+    const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
+    uint32_t cur = M;
+    for (uint32_t round = k1; round < kmax; round++) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < SEL_RPT; i++) m = (rm[i] < cur) ? max(m, rm[i]) : m;
+        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
+            const uint32_t v = ((s_words[x >> 5] >> (x & 31)) & 1u) ? 0u : rowma[x].x;
+            m = (v < cur) ? max(m, v) : m;
+        }
+        for (uint32_t i = tid; i < nd; i += 1024) m = (s_exm[i] < cur) ? max(m, s_exm[i]) : m;
+        m = wave_umax_dpp(m);
+        if (lane_id() == 0) s_r16[wave_id()] = m;
+        if (tid == 0) s_hit = 0;
+        __syncthreads();
+        uint32_t m2 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) m2 = max(m2, s_r16[w]);
+        if (m2 == 0) break;  // (uniform)
+        // the rows that attain it: exactly one, or the level is not ours to order
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < SEL_RPT; i++) {
+            if (rm[i] == m2) {
+                c++;
+                s_m2 = tid + 1024u * (uint32_t)i;  // (read only if the count turns out to be one)
+                s_hitarg = 0xFFFFFFFEu;            // (row-maxima array: the column is fetched below)
+            }
+        }
+        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
+            if (!((s_words[x >> 5] >> (x & 31)) & 1u) && rowma[x].x == m2) {
+                c++;
+                s_m2 = x;
+                s_hitarg = 0xFFFFFFFEu;
+            }
+        }
+        for (uint32_t i = tid; i < nd; i += 1024) {
+            if (s_exm[i] == m2) {
+                c++;
+                s_m2 = s_exrow[i];
+                s_hitarg = s_exarg[i];
+            }
+        }
+        if (c) atomicAdd(&s_hit, c);
+        __syncthreads();
+        if (s_hit != 1) break;  // (uniform)
+        if (tid == 0) {
+            const uint32_t x = s_m2;
+            uint32_t y = s_hitarg;
+            if (y == 0xFFFFFFFEu) y = rowma[x].y;
+            bool clash = (y == ROWARG_MULTI) || (x == y);
+            for (uint32_t i = 0; i < round && !clash; i++)
+                clash = ((int32_t)x == s_ba[i]) | ((int32_t)x == s_bb[i]) | ((int32_t)y == s_ba[i]) | ((int32_t)y == s_bb[i]);
+            if (clash) {
+                s_stop = 1;
+            } else {
+                s_ba[round] = (int32_t)x;
+                s_bb[round] = (int32_t)y;
+                s_bc[round] = m2;
+                s_k = round + 1;
+            }
+        }
+        __syncthreads();
+        if (s_stop) break;
+        cur = m2;
+    }
+    __syncthreads();
+    const uint32_t k2 = s_k;
+    if (k2 == k1) {
+        dismiss();
+        return;
+    }
+    // ---- entries hidden behind the maxima of the rows taken from: second maxima, by workgroups 1 .. k2 - 1 ------
+    if (tid < k2 - 1) granule_put(req + 1 + tid, tag, ((uint32_t)s_ba[tid] << 16) | (uint32_t)s_bb[tid]);
+    if (tid == 0) granule_put(req, tag, k2 - 1);
+    if (tid < k2 - 1) {
+        uint32_t sec = 0;
+        if (!granule_get(req + 17 + tid, tag, sec)) s_fail = 1;
+        s_sec[tid] = sec;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = k1;
+        if (!s_fail) {
+            uint32_t S = 0;
+            for (uint32_t t = 0; t + 1 < k1; t++) S = max(S, s_sec[t]);
+            for (uint32_t t = k1; t < k2; t++) {
+                S = max(S, s_sec[t - 1]);
+                if (S < s_bc[t]) m = t + 1; else break;
+            }
+        }
+        for (uint32_t i = k1; i < m; i++) {
+            st->ba[i] = s_ba[i];
+            st->bb[i] = s_bb[i];
+            st->badj[i] = 0;
+            st->bcnt[i] = s_bc[i];
+        }
+        st->bk = m;
+        // (the list holds the k1 pairs at M only: the batch takes them all, so the next step selects again)
     }
 }
 

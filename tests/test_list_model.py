@@ -151,3 +151,90 @@ def test_list_and_batches_are_the_references_merges(name, k, n, seed):
         assert batched > 0, batched
     if name in ("words", "chunks"):  # rigid sequences: a created pair takes over a listed one
         assert replaced > 0, replaced
+
+
+# ---------------------------------------------------------------------------------------------------
+# Batches that reach BELOW the maximum (k_chain_sel, FULL mode).  The argument for ties carries over to any
+# prefix of the ranking by (count descending, first occurrence): if the first k pairs of that ranking have
+# a != b and share no token, the reference merges them in that order -- a pair created on the way inherits at most
+# the count AND the place of a pair that ranks after all k.  The device does not have the ranking, only every
+# row's maximum and the column that attains it; what it does, restated here:
+#   level 0   all pairs at the maximum M, in order of first occurrence; the batch is their longest token-disjoint
+#             prefix.  Only if that prefix is ALL of them does the batch go on:
+#   level t   the largest row maximum below the last level, if exactly one row attains it, with one column,
+#             a != b, no token shared with the batch so far; otherwise stop.
+#   check     an entry hidden behind the maximum of a row the batch took from (its second largest entry) must
+#             rank after everything taken: the batch is cut before the first pair whose count does not exceed
+#             the second maxima of all rows taken before it.
+
+def device_batch(chunks, left):
+    table = table_of(chunks)
+    pairs, counts = stats_in_order(chunks)
+    rows = {}
+    for (a, b), c in table.items():
+        rows.setdefault(a, []).append((c, b))
+    rowmax = {a: max(v) [0] for a, v in rows.items()}
+    M = max(rowmax.values())
+    tl = [p for p, c in zip(pairs, counts) if c == M]
+    batch = batch_of(tl, left)
+    cnts = [M] * len(batch)
+    if batch and len(batch) == len(tl):
+        used = set(t for p in batch for t in p)
+        cur = M
+        while len(batch) < min(KMAX, left):
+            lower = [m for m in rowmax.values() if m < cur]
+            if not lower:
+                break
+            m2 = max(lower)
+            at = [a for a, m in rowmax.items() if m == m2]
+            if len(at) != 1:
+                break
+            x = at[0]
+            cols = [b for c, b in rows[x] if c == m2]
+            if len(cols) != 1 or cols[0] == x or x in used or cols[0] in used:
+                break
+            batch.append((x, cols[0]))
+            cnts.append(m2)
+            used.update((x, cols[0]))
+            cur = m2
+        # second largest entry of every row taken from, except the last
+        def second(a, b):
+            rest = [c for c, y in rows[a] if y != b]
+            return max(rest) if rest else 0
+        S, m = 0, 1
+        for t in range(1, len(batch)):
+            S = max(S, second(*batch[t - 1]))
+            if S < cnts[t]:
+                m = t + 1
+            else:
+                break
+        batch, cnts = batch[:m], cnts[:m]
+    return batch, cnts, tl, M
+
+
+@pytest.mark.parametrize("name,k,n", STREAMS)
+@pytest.mark.parametrize("seed", [4, 5])
+def test_batches_below_the_maximum_are_the_references_merges(name, k, n, seed):
+    chunks = make_stream(name, k, n, 77 * seed + n)
+    total, next_id, done, multi_level = 200, 256, 0, 0
+    while done < total:
+        pairs, counts = stats_in_order(chunks)
+        if not len(counts) or counts.max() < 2:
+            break
+        batch, cnts, tl, M = device_batch(chunks, total - done)
+        if not batch:  # a == b at the head of the list: the general path's merge
+            chunks = [merge(c, tl[0], next_id) for c in chunks]
+            next_id += 1
+            done += 1
+            continue
+        multi_level += len(set(cnts)) > 1
+        for pair, cnt in zip(batch, cnts):
+            ref_pairs, ref_counts = stats_in_order(chunks)
+            j = int(np.argmax(ref_counts))
+            assert ref_pairs[j] == pair and int(ref_counts[j]) == cnt, (name, seed, done, pair, cnt, ref_pairs[j])
+            chunks = [merge(c, pair, next_id) for c in chunks]
+            next_id += 1
+            done += 1
+    assert done > 40
+    if name in ("k12", "words", "chunks"):
+        assert multi_level > 0
