@@ -150,6 +150,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lean_select = value != 0;
     } else if (!strcmp(name, "aa_sparse")) {
         c->aa_sparse = value != 0;
+    } else if (!strcmp(name, "chain_dense")) {
+        c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
     } else if (!strcmp(name, "chain_scan")) {

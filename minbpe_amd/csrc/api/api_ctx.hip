@@ -90,6 +90,8 @@ struct bpe_ctx {
     int lean_select = 1;                      // option "lean_select": 1 = k_rowsel_lean (row maxima + selection in one launch) while the index is live
     int aa_sparse = 1;                        // option "aa_sparse": a sparse iteration's a == b pass works through a candidate list and keeps the index current itself (no rebuild after it)
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
+    int chain_dense = 1;                      // option "chain_dense": chain steps from the second merge on -- dense passes, LDS delta tables, up to CH_KDENSE
+                                              // pairs per sweep -- while every id is below LDSD_CAP and the index does not exist yet
     int chain_extend = 1;                     // option "chain_extend": a chain step's batch may reach below the maximum count (k_chain_sel)
     unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
     int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
@@ -1025,7 +1027,7 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
 // A chain step (k_chain.hip): selection or list look-ups, one merge pass for the whole batch, table update.
 // zhi: the largest token id the step can make (the device counts the merges; the host only knows a bound).
 // records: the last launch that touched the pair table was a k_apply_chain.
-int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, bool records) {
+int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, bool records, bool dense = false) {
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, zhi);
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
@@ -1039,6 +1041,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     C.tie_index = 1;
     C.tie_window = 0;
     C.aa = 0;
+    if (!c->idx_live) C.T = 0;  // (no index: a tie finds none of its pairs through it, and the step defers)
     (void)records;
     if (!c->d_chain_req) {
         HIPCHK(c, hipMalloc((void **)&c->d_chain_req, 64 * sizeof(unsigned long long)));
@@ -1046,14 +1049,15 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     }
     hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
-                       (uint32_t)(c->chain_extend && c->chain_scan >= CH_KMAX - 1));  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
+                       (uint32_t)(c->chain_extend && c->chain_scan >= CH_KMAX - 1),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
+                       (uint32_t)(dense ? CH_KDENSE : CH_KMAX));
     LAUNCHCHK(c, "k_chain_sel");
     TRY(prof_end(c));
     AbArgs A;
     A.b0 = c->d_ids[0];
     A.b1 = c->d_ids[1];
     A.hdr_in = c->d_hdr2[c->mq];
-    A.hdr_out = nullptr;
+    A.hdr_out = dense ? c->d_hdr2[c->mq ^ 1] : nullptr;
     A.stage = c->d_stage;
     A.smask = c->d_smask;
     A.T = T;
@@ -1061,15 +1065,24 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     A.newid = 0;  // (the device knows: st->bz0)
     A.delta = c->d_delta;
     A.vcap = dl;
-    A.idx = c->d_idx;
+    A.idx = c->idx_live ? c->d_idx : nullptr;
     A.istride = (uint32_t)c->idx_cap_words;
     A.cand = nullptr;
     A.removed = c->d_removed;
     A.dirty_n = c->d_dirty_n;
     const uint32_t nwords = (T + 31) / 32;
-    const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
-    hipLaunchKernelGGL(k_merge_chain, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
+    if (dense) {
+        // every slot, one 1024-thread workgroup per CU at most (sixteen slots in flight each)
+        const unsigned g = std::max(1u, std::min((T + 15) / 16, (unsigned)c->num_cus));
+        hipLaunchKernelGGL(k_merge_chain_dense, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_dbits);
+        // (the batch of one has its own kernel -- five 256-thread workgroups per CU, 96 VGPRs: the other one returns at once)
+        const unsigned g1 = std::max(1u, std::min((T + MT / 64 - 1) / (MT / 64), 5u * (unsigned)c->num_cus));
+        hipLaunchKernelGGL(k_merge_chain_dense1, dim3(g1), dim3(MT), 0, c->stream, A);
+    } else {
+        const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
+        hipLaunchKernelGGL(k_merge_chain, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
+    }
     LAUNCHCHK(c, "k_merge_chain");
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
@@ -1080,7 +1093,8 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
                        c->d_removed, c->d_smask, nwords, c->d_lean_sum);
     LAUNCHCHK(c, "k_apply_chain");
     TRY(prof_end(c));
-    c->par ^= 1;  // (staged headers: the header arrays do not flip)
+    c->par ^= 1;
+    if (dense) c->mq ^= 1;  // (a sparse step stages its headers: the header arrays do not flip)
     c->stats_valid = false;
     c->stream_is_bytes = false;
     c->rows_pending = true;

@@ -86,8 +86,11 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     // and -- a deferral costs a stream synchronisation, up to `depth` no-op units and the re-run (~200 us against
     // 25 us for a lean iteration and 44 us for a general one) -- the stretch after it when deferrals come
     // thick (streams whose late counts are 2 or 3: hundreds of tied pairs per selection, each of them a
-    // deferral).  The stretch doubles while they keep coming, up to 1024 iterations, and halves otherwise.
-    int general_until = -1, defer_hold = 0, last_deferred_at = -(1 << 30);
+    // deferral).  "Thick" = a tie the lean selection could not settle fewer than 16 lean merges after the last
+    // such one, twice running: the stretch is then 32 iterations and doubles while that goes on, up to 1024;
+    // a deferral that comes later ends it.  Pairs with a == b (the general path's merge by design) do not count.
+    int general_until = -1, defer_hold = 0, defer_strikes = 0;
+    uint64_t lean_at_last_defer = 0;
     bool lean_on = false;     // latched: the general path's kernels do not know a deferred iteration
     bool in_chain = false;    // the device counts the merges (k_set_iter ran, no GENERAL / LEAN unit enqueued since)
     bool records_ok = false;  // the last unit enqueued was a chain step: its table update's per-wave records are current
@@ -162,7 +165,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     // and chain steps only, all no-ops behind the deferred one); they did carry the stream length forward,
     // so the ping-pong parity (and any re-packing enqueued among them) stands as the host has it.  Take
     // their passes out of the statistics; merge `done` goes through the general path next.
-    auto handle_deferral = [&]() -> int {
+    auto handle_deferral = [&](bool a_eq_b = false) -> int {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const Unit &u : q) {
             if (u.kind == U_LEAN) {
@@ -186,14 +189,15 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
         LAUNCHCHK(c, "k_clear_defer");
         c->n_deferred++;
-        // back-off: a deferral within 32 lean iterations of the last one lengthens the general stretch
-        // (nothing is in flight here, so the switch is safe; the general path then runs until a lean
-        // iteration is enqueued again, which is the ordinary general -> lean hand-over)
-        if (c->lean_backoff) {
-            if (done - last_deferred_at <= defer_hold + 32) defer_hold = std::min(std::max(2 * defer_hold, 32), 1024);
-            else defer_hold /= 2;
+        // back-off (see general_until above); nothing is in flight here, so the switch to the general path is safe,
+        // and it runs until a lean iteration is enqueued again: the ordinary general -> lean hand-over
+        if (c->lean_backoff && !a_eq_b) {
+            defer_strikes = (c->n_lean - lean_at_last_defer < 16) ? defer_strikes + 1 : 0;
+            lean_at_last_defer = c->n_lean;
+            defer_hold = defer_strikes >= 2 ? std::min(32 << std::min(defer_strikes - 2, 5), 1024) : 0;
+        } else if (a_eq_b) {
+            defer_hold = 0;  // (one general iteration)
         }
-        last_deferred_at = done;
         general_until = done + 1 + defer_hold;
         if (defer_hold) lean_on = false;
         in_chain = false;
@@ -250,10 +254,16 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 }
                 if (c->slotted && c->slot2) TRY(plan_pass2(c, &sparse));
                 const bool lean = lean_wanted(sparse);
-                const bool chain = lean && c->chain && c->lean_select && c->idx_live && c->tie_index && !full_rowmax;
+                // dense chain steps: the early merges (no index yet, every id below LDSD_CAP), several pairs per sweep
+                const int hi_dense = std::min(num_merges, done + (int)q.size() * CH_KDENSE + CH_KDENSE);
+                const bool chain_dense = !lean && delta && c->chain && c->chain_dense && c->lean && c->lds_delta && c->slotted &&
+                                         c->slot2 && !c->idx_live && !sparse && !full_rowmax && i >= general_until &&
+                                         256 + hi_dense + 1 <= LDSD_CAP;
+                const bool chain = chain_dense ||
+                                   (lean && c->chain && c->lean_select && c->idx_live && c->tie_index && !full_rowmax);
                 Unit u{U_GENERAL, i, 0u, 0, 0, 0, -1};
                 if (chain) {
-                    lean_on = true;
+                    if (!chain_dense) lean_on = true;
                     if (!in_chain) {  // general iterations so far: the device counts from here
                         TRY(flush_lean_rows(c, c->vcur));  // (rows a lean table update left, if lean iterations ran before)
                         hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
@@ -262,12 +272,13 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                         records_ok = false;
                     }
                     // the most this step can reach: every chain step in flight doing CH_KMAX merges
-                    const int hi = std::min(num_merges, done + (int)q.size() * CH_KMAX + CH_KMAX);
-                    TRY(launch_chain_step(c, steps, 255u + (uint32_t)hi, sparse, records_ok));
+                    const int hi = chain_dense ? hi_dense : std::min(num_merges, done + (int)q.size() * CH_KMAX + CH_KMAX);
+                    TRY(launch_chain_step(c, steps, 255u + (uint32_t)hi, sparse, records_ok, chain_dense));
                     u.kind = U_CHAIN;
                     u.iter = -1;
                     u.step = steps++;
                     u.pass_kind = sparse ? 1 : 2;
+                    u.hdr_flip = chain_dense ? 1 : 0;
                     records_ok = true;
                     n_chain_inflight++;
                     enqueued = true;
@@ -323,7 +334,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 if (sr.status == ST_DEFER) {
                     if ((int)sr.first_iter != done)
                         return fail(c, BPE_E_INTERNAL, "chain step %u deferred merge %u, the host expected %d", u.step, sr.first_iter, done);
-                    TRY(handle_deferral());
+                    TRY(handle_deferral((sr.pad >> 8) == 1));
                 } else if (sr.status == ST_EMPTY) {
                     stop = true;
                     rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", done);
@@ -339,8 +350,8 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                     }
                     if (sr.k) {
                         c->n_lean += sr.k;
-                        if (sr.pad == CH_FULL) c->n_full++;
-                        c->n_chained += sr.pad == CH_FULL ? sr.k - 1 : sr.k;
+                        if ((sr.pad & 0xFF) == CH_FULL) c->n_full++;
+                        c->n_chained += (sr.pad & 0xFF) == CH_FULL ? sr.k - 1 : sr.k;
                         if (u.ev >= 0) ev_spans.push_back({u.ev, (int)sr.first_iter, (int)sr.k});
                     }
                     q.pop_front();
@@ -350,7 +361,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 TRY(wait_iter(u.iter));
                 TRY(take_record(u.iter, u.aa_indexed != 0));
                 if (deferred >= 0) {
-                    TRY(handle_deferral());
+                    TRY(handle_deferral(c->h_rec[u.iter].a == c->h_rec[u.iter].b));
                 } else if (!stop) {
                     if (u.ev >= 0) ev_spans.push_back({u.ev, u.iter, 1});
                     q.pop_front();

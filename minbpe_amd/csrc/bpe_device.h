@@ -169,7 +169,7 @@ constexpr uint32_t STEP_RING = 4096;  // step records form a ring (far more than
 // one per chain step, written by the device into pinned host memory (the IterRecs of its merges are final before it)
 struct StepRec {
     uint32_t first_iter, k;      // the merges this step did: first_iter .. first_iter + k - 1 (k == 0: none)
-    uint32_t status, pad;        // ST_* (ST_DEFER: the general path must do merge first_iter); pad = the step's mode (CH_FULL / CH_LIST)
+    uint32_t status, pad;        // ST_* (ST_DEFER: the general path must do merge first_iter); pad = the step's mode (CH_FULL / CH_LIST) | DevState::defer << 8
     unsigned long long new_len;
     unsigned long long seq;      // step + 1 once every field above is final
 };

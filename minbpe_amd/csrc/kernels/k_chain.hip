@@ -58,10 +58,15 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
     return (w0 == INVALID_WORD) ? -1 : hit;
 }
 
-// One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip; sparse form, index live,
-// global delta replicas) for K >= 2 token-disjoint pairs at once.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
+// One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip) for K >= 2 token-disjoint pairs at
+// once.  DENSE == false: the sparse form (staged headers, global delta replicas, index live).  DENSE == true: the
+// early passes, where every slot is visited and a pair has millions of sites: headers go to the other header array,
+// the delta into the workgroup's LDS tables sd (per pair p, at sd + p * CH_SD: SL[LDSD_CAP] | SR[LDSD_CAP] | adj |
+// ids removed; every id is below LDSD_CAP), flushed by the kernel when its slots are done.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
 // pb1[0] a word that matches nothing, z0: pair p becomes z0 + p.
-__device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, const uint32_t t, const AbArgs &A,
+constexpr uint32_t CH_SD = 2 * LDSD_CAP + 2;  // words of one pair's LDS delta tables
+template <bool DENSE>
+__device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t, const AbArgs &A,
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
                                                  const uint32_t K, const uint32_t z0, const uint32_t brep) {
     const int lane = lane_id();
@@ -79,7 +84,13 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
     }
     const uint32_t meta = bcast(hv.w, 2);
     const uint32_t len = meta & 0x7FFFFFFFu, buf = meta >> 31;
-    if (len == 0) return;
+    auto keep_header = [&]() {  // dense: the slot stays as it is (lanes 2 and 3 hold its header)
+        if (DENSE && (lane == 2 || lane == 3)) reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + (lane - 2)] = hv;
+    };
+    if (len == 0) {
+        keep_header();
+        return;
+    }
     if (buf) {  // (uniform) the slot lives in the other buffer: load again
         src = A.b1 + (size_t)t * TILE2;
 #pragma unroll
@@ -170,7 +181,10 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
 #pragma unroll
     for (int j = 0; j < MJ; j++) anyr |= rb[j] & valid[j];
     const bool sites = __any(anyr != 0) != 0;
-    if (!sites && !s) return;  // nothing in this slot changes and it owes no table update
+    if (!sites && !s) {  // nothing in this slot changes and it owes no table update
+        keep_header();
+        return;
+    }
     // ---- (5) kept flags, output offsets -------------------------------------------------------
     uint32_t mb[MJ], kb[MJ], ex[MJ], cnt[MJ];
 #pragma unroll
@@ -233,83 +247,103 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, con
         h[4] = total > 1 ? out[total - 2] : INVALID_WORD;
         h[5] = total > 0 ? out[total - 1] : INVALID_WORD;
         h[6] = h[7] = 0;
-        StageRec *r = A.stage + t;
-        r->t = t;
+        if (DENSE) {
+            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
+            reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = make_uint4(h[4], h[5], 0u, 0u);
+        } else {
+            StageRec *r = A.stage + t;
+            r->t = t;
 #pragma unroll
-        for (int i = 0; i < 8; i++) r->h[i] = h[i];
-        atomicOr(&A.smask[t >> 5], 1u << (t & 31));
+            for (int i = 0; i < 8; i++) r->h[i] = h[i];
+            atomicOr(&A.smask[t >> 5], 1u << (t & 31));
+        }
         if (total < 3 && t + 1 < Tl) A.st->gap = 1;
     }
     if (!sites) return;  // carry only: the site belongs to the previous slot
     // ---- (7) pair-table delta of my sites, as the sequential merges would charge it ------------
+    // Which pair (if any) the two words before a site, and the two after it, are a site of: the codes of the
+    // positions two to the left and two to the right -- computed above for every position, so a site only looks
+    // at its neighbours' nibbles (no search through the batch per site: the early passes have a site in nearly
+    // every group of words, and were bound by instruction issue while every site compared its neighbours with
+    // every pair).  Positions -2 and -1 (the previous slot's last words) and 1024, 1025 come from the context words.
     const uint32_t vc = A.vcap & 0xFFFFFFu;
+    const uint32_t cm2 = (uint32_t)(chain_match(pa, pb, K, prev2, prev1) + 1);  // (uniform)
+    const uint32_t cm1 = s ? ip : 0u;
+    const uint32_t ct0 = (uint32_t)(chain_match(pa, pb, K, tail[0], tail[1]) + 1);
+    const uint32_t ct1 = (uint32_t)(chain_match(pa, pb, K, tail[1], tail[2]) + 1);
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         if (!__any(mb[j] != 0)) continue;  // (uniform) no site in this stripe
-        uint32_t upm2, upm1, dn0, dn1, dn2;
-        if (j > 0) {
-            upm2 = lane_last(x[(j + MJ - 1) % MJ][2]);
-            upm1 = lane_last(x[(j + MJ - 1) % MJ][3]);
-        } else {
-            upm2 = prev2;
-            upm1 = prev1;
-        }
-        if (j < MJ - 1) {
-            dn0 = lane_first(x[(j + 1) % MJ][0]);
-            dn1 = lane_first(x[(j + 1) % MJ][1]);
-            dn2 = lane_first(x[(j + 1) % MJ][2]);
-        } else {
-            dn0 = tail[0];
-            dn1 = tail[1];
-            dn2 = tail[2];
-        }
-        uint32_t W[9];
-        W[0] = (uint32_t)dpp_mov<0x138>((int)upm2, (int)x[j][2]);  // (lane 0 keeps upm2 / upm1)
-        W[1] = (uint32_t)dpp_mov<0x138>((int)upm1, (int)x[j][3]);
-        W[2] = x[j][0];
-        W[3] = x[j][1];
-        W[4] = x[j][2];
-        W[5] = x[j][3];
-        W[6] = lane_next(x[j][0], dn0);
-        W[7] = lane_next(x[j][1], dn1);
-        W[8] = lane_next(x[j][2], dn2);
+        uint32_t upm1, dn0;
+        if (j > 0) upm1 = lane_last(x[(j + MJ - 1) % MJ][3]);
+        else upm1 = prev1;
+        if (j < MJ - 1) dn0 = lane_first(x[(j + 1) % MJ][0]);
+        else dn0 = tail[0];
+        // the words at positions q0 - 1 .. q0 + 5 (q0 = my first position)
+        uint32_t W[7];
+        W[0] = (uint32_t)dpp_mov<0x138>((int)upm1, (int)x[j][3]);  // (lane 0 keeps upm1)
+        W[1] = x[j][0];
+        W[2] = x[j][1];
+        W[3] = x[j][2];
+        W[4] = x[j][3];
+        W[5] = lane_next(x[j][0], dn0);
+        W[6] = lane_next(x[j][1], (j < MJ - 1) ? lane_first(x[(j + 1) % MJ][1]) : tail[1]);
+        // the codes of positions q0 - 2 .. q0 + 5, a nibble each
+        const uint32_t lo_fill = (j > 0) ? ((lane_last(jc[(j + MJ - 1) % MJ]) >> 8) & 0xFFu) : (cm2 | (cm1 << 4));
+        const uint32_t hi_fill = (j < MJ - 1) ? (lane_first(jc[(j + 1) % MJ]) & 0xFFu) : (ct0 | (ct1 << 4));
+        const uint32_t lo = (uint32_t)dpp_mov<0x138>((int)lo_fill, (int)((jc[j] >> 8) & 0xFFu));
+        const uint32_t hi = lane_next(jc[j] & 0xFFu, hi_fill);
+        const uint32_t win = lo | (jc[j] << 8) | (hi << 24);
         if (mb[j] == 0) continue;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (!((mb[j] >> k) & 1u)) continue;
             const int q = j * 256 + lane * 4 + k;
-            const uint32_t p = ((jc[j] >> (4 * k)) & 15u) - 1u;
+            const uint32_t p = ((win >> (4 * (k + 2))) & 15u) - 1u;
+            const int li = (int)((win >> (4 * k)) & 15u) - 1, ri = (int)((win >> (4 * (k + 4))) & 15u) - 1;
             const uint32_t Z = z0 + p;
-            // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
-            // site, 32 counters per pair)
-            atomicAdd(&A.removed[(p * 32u + (t & 31u)) * REMOVED_STRIDE], 1u);
-            const uint32_t rho = p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u));
-            uint32_t *dl = A.delta + delta_rep_off(rho, vc);  // SL of pair p
-            uint32_t *dr = dl + vc;                             // SR of pair p
-            const uint32_t wa = W[k + 2];
+            uint32_t *dl, *dr;  // SL, SR of pair p
+            if (DENSE) {
+                dl = sd + p * CH_SD;
+                dr = dl + LDSD_CAP;
+                atomicAdd(&dl[2 * LDSD_CAP + 1], 1u);
+            } else {
+                // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
+                // site, 32 counters per pair)
+                atomicAdd(&A.removed[(p * 32u + (t & 31u)) * REMOVED_STRIDE], 1u);
+                dl = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u)), vc);
+                dr = dl + vc;
+            }
+            const uint32_t wa = W[k + 1];
             const uint32_t wt = word_weight(wa);
-            const uint32_t Lw = W[k + 1], LL = W[k];
+            const uint32_t Lw = W[k];
             if (!(wa & FLAG) && Lw != INVALID_WORD) {
                 // the left neighbour ends a site of pair li: when pair p is merged it already reads Z_li
                 // (li < p) or still b_li (li > p); li == p is the same pair twice in a row -- format B's adj,
                 // charged by the left site
-                const int li = chain_match(pa, pb, K, LL, Lw);
                 if (li != (int)p) {
                     const uint32_t Lseq = (li >= 0 && (uint32_t)li < p) ? z0 + (uint32_t)li : (Lw & IDMASK);
-                    const uint32_t Lfin = li >= 0 ? z0 + (uint32_t)li : (Lw & IDMASK);
                     atomicAdd(&dl[Lseq], wt);
-                    index_add(A.idx, A.istride, t, Lfin, Z);
-                    if (q == 0) index_add(A.idx, A.istride, tprev, Lfin, Z);
+                    if (!DENSE || A.idx) {
+                        const uint32_t Lfin = li >= 0 ? z0 + (uint32_t)li : (Lw & IDMASK);
+                        index_add(A.idx, A.istride, t, Lfin, Z);
+                        if (q == 0) index_add(A.idx, A.istride, tprev, Lfin, Z);
+                    }
                 }
             }
-            const uint32_t R = W[k + 4], RR = W[k + 5];
+            const uint32_t R = W[k + 3];
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
-                const int ri = chain_match(pa, pb, K, R, RR);
-                if (ri == (int)p) atomicAdd(&A.st->badj[p], wt);
-                else atomicAdd(&dr[(ri >= 0 && (uint32_t)ri < p) ? z0 + (uint32_t)ri : (R & IDMASK)], wt);
-                const uint32_t y = ri >= 0 ? z0 + (uint32_t)ri : (R & IDMASK);
-                index_add(A.idx, A.istride, t, Z, y);
-                if (q + 2 >= (int)len) index_add(A.idx, A.istride, tnext, Z, y);
+                if (ri == (int)p) {
+                    if (DENSE) atomicAdd(&dl[2 * LDSD_CAP], wt);
+                    else atomicAdd(&A.st->badj[p], wt);
+                } else {
+                    atomicAdd(&dr[(ri >= 0 && (uint32_t)ri < p) ? z0 + (uint32_t)ri : (R & IDMASK)], wt);
+                }
+                if (!DENSE || A.idx) {
+                    const uint32_t y = ri >= 0 ? z0 + (uint32_t)ri : (R & IDMASK);
+                    index_add(A.idx, A.istride, t, Z, y);
+                    if (q + 2 >= (int)len) index_add(A.idx, A.istride, tnext, Z, y);
+                }
             }
         }
     }
@@ -350,7 +384,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
         if (K == 1) merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
-        else merge_chain_wave(s_out[wave_id()], t, A, s_pa, s_pb, s_pb1, K, z0, brep);
+        else merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep);
     };
     if (!use_index || st->gap != 0) {  // short slots about: visit everything
         const uint32_t nw = gridDim.x * NWV;
@@ -390,6 +424,86 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
         for (uint32_t i = wave_id(); i < n; i += NWV) do_slot(s_list[i]);
         __syncthreads();  // (the list is rewritten by the next round)
     }
+}
+
+// ---------------------------------------------------------------------------
+// merge pass of a DENSE chain step: the early merges, whose pairs sit in nearly every slot (the inverted index does
+// not exist yet, and a pair has 10^5 .. 10^7 sites: the delta goes through LDS tables, as in k_merge_ab_dense_early).
+// A batch of K pairs costs ONE sweep over the stream instead of K.  One 1024-thread workgroup per CU, wave w of the
+// grid takes slots w, w + waves, ...; every slot's header is written to the other header array (the host flips the
+// arrays after every dense step -- a step that merges nothing copies the headers across, so that the flip stands).
+constexpr int CH_KDENSE = 4;  // most pairs of a dense step's batch: their LDS tables must fit next to the staging
+static_assert((LEAN_MT / 64) * TILE2 * 4 + CH_KDENSE * (int)CH_SD * 4 + 256 <= 160 * 1024, "dense chain pass: LDS");
+__global__ void __launch_bounds__(LEAN_MT)
+k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[LEAN_MT / 64][TILE2];
+    __shared__ uint32_t s_sd[CH_KDENSE * CH_SD];
+    __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
+    DevState *st = A.st;
+    const uint32_t ran = st->sel_ran;
+    if (blockIdx.x == 0 && ran) {
+        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) st->sel_ran = 0;
+    }
+    const uint32_t K = st->bk;
+    if (!(st->status || st->defer) && K == 1) return;  // (k_merge_chain_dense1's pass)
+    if (st->status || st->defer || K == 0 || K > (uint32_t)CH_KDENSE) {
+        // nothing to merge: the headers cross over unchanged
+        const uint4 *hi = reinterpret_cast<const uint4 *>(A.hdr_in);
+        uint4 *ho = reinterpret_cast<uint4 *>(A.hdr_out);
+        for (size_t i = (size_t)blockIdx.x * LEAN_MT + threadIdx.x; i < 2 * (size_t)A.T; i += (size_t)gridDim.x * LEAN_MT) ho[i] = hi[i];
+        if (K > (uint32_t)CH_KDENSE && blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
+        return;
+    }
+    const uint32_t z0 = st->bz0;
+    if (threadIdx.x < CH_KMAX) {
+        s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
+        s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        s_pb1[threadIdx.x + 1] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        if (threadIdx.x == 0) s_pb1[0] = 0xFFFFFFFFu;
+    }
+    for (uint32_t i = threadIdx.x; i < K * CH_SD; i += LEAN_MT) s_sd[i] = 0;
+    __syncthreads();
+    constexpr uint32_t NWV = LEAN_MT / 64;
+    const uint32_t nw = gridDim.x * NWV;
+    for (uint32_t t = blockIdx.x * NWV + wave_id(); t < A.T; t += nw)
+        merge_chain_wave<true>(s_out[wave_id()], s_sd, t, A, s_pa, s_pb, s_pb1, K, z0, (uint32_t)CH_RSTRIDE);
+    __syncthreads();
+    // flush: the tables of pair p into one of its CH_RSTRIDE replica blocks
+    const uint32_t vc = A.vcap & 0xFFFFFFu;
+    const uint32_t lim = min(vc, (uint32_t)LDSD_CAP);
+    for (uint32_t p = 0; p < K; p++) {
+        const uint32_t *sd = s_sd + p * CH_SD;
+        uint32_t *g = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (blockIdx.x & (uint32_t)(CH_RSTRIDE - 1)), vc);
+        for (uint32_t i = threadIdx.x; i < lim; i += LEAN_MT) {
+            const uint32_t l = sd[i], r = sd[LDSD_CAP + i];
+            if (l) atomicAdd(&g[i], l);
+            if (r) atomicAdd(&g[vc + i], r);
+        }
+        if (threadIdx.x == 0) {
+            const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
+            if (adj) atomicAdd(&st->badj[p], adj);
+            if (rem) atomicAdd(&A.removed[(p * 32u + (blockIdx.x & 31u)) * REMOVED_STRIDE], rem);
+        }
+    }
+}
+// ... and the dense step whose batch is ONE pair: k_merge_ab_dense_early (k_slots2.hip) with the pair and its new
+// id taken from the device's own state (a resident grid of 256-thread workgroups, five per CU; the delta through
+// LDS, flushed into one of the pass's replica blocks; format B's adj in st->adj, all 256 removal counters).
+__global__ void __launch_bounds__(MT, 5)
+k_merge_chain_dense1(AbArgs A) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_out[MT / 64][TILE2];
+    __shared__ uint32_t s_delta[2 * LDSD_CAP + 2];
+    const DevState *st = A.st;
+    if (st->status || st->defer || st->bk != 1) return;
+    const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0];
+    A.newid = st->bz0;
+    ldsd_clear(s_delta);
+    const uint32_t nw = gridDim.x * (MT / 64);
+    for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
+        merge_ab_wave<false, false, true>(s_out[wave_id()], s_delta, t, A, a, b);
+    ldsd_flush(s_delta, A);
 }
 
 // ---------------------------------------------------------------------------
@@ -584,7 +698,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             sr->first_iter = iter;
             sr->k = k_done;
             sr->status = (status == 0 && defer) ? ST_DEFER : status;
-            sr->pad = mode_used;
+            sr->pad = mode_used | (defer << 8);  // (defer: 1 = a == b heads the list, 2 = a tie the step could not settle)
             sr->new_len = nn;
             __threadfence_system();
             sr->seq = (unsigned long long)step + 1;
@@ -613,8 +727,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 // Thread 0 of the deciding workgroup.  An empty batch with a non-empty list means a == b at its head: the
 // general path's merge.
 __device__ __forceinline__ void chain_form_batch(DevState *st, const int32_t *s_list, uint32_t n, uint32_t M,
-                                                 uint32_t iter, uint32_t nm) {
-    const uint32_t kmax = min((uint32_t)CH_KMAX, nm - iter);
+                                                 uint32_t iter, uint32_t nm, uint32_t kcap) {
+    const uint32_t kmax = min(kcap, nm - iter);
     int32_t ta[CH_KMAX], tb[CH_KMAX];
     uint32_t k = 0;
     for (uint32_t e = 0; e < n && k < kmax; e++) {
@@ -701,7 +815,7 @@ __device__ __forceinline__ uint32_t row_scan_excl(const uint32_t *__restrict__ r
 __global__ void __launch_bounds__(1024)
 k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
             CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-            unsigned long long *__restrict__ req, uint32_t extend) {
+            unsigned long long *__restrict__ req, uint32_t extend, uint32_t kcap) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     __shared__ int32_t s_tied[2 * TIE_CAP];
@@ -778,7 +892,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             st->tl_n = n;
             st->tl_skip = 0;
             if (n == 0) st->bk = 0;  // the maximum dropped: this step merges nothing, the next one selects
-            else chain_form_batch(st, s_list, n, M, iter, nm);
+            else chain_form_batch(st, s_list, n, M, iter, nm, kcap);
         }
         return;
     }
@@ -895,7 +1009,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     if (tid == 0) {
         st->tl_n = nt;
         st->tl_M = M;
-        chain_form_batch(st, s_list, nt, M, iter, nm);
+        chain_form_batch(st, s_list, nt, M, iter, nm, kcap);
         const uint32_t k = st->bk;
         s_k = k;
         for (uint32_t i = 0; i < k; i++) {
@@ -906,7 +1020,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     }
     __syncthreads();
     const uint32_t k1 = s_k;
-    const uint32_t kmax = min((uint32_t)CH_KMAX, nm - iter);
+    const uint32_t kmax = min(kcap, nm - iter);
     if (!extend || k1 == 0 || k1 != nt || k1 >= kmax) {  // the list goes on (or a == b heads it): nothing below M yet
         dismiss();
         return;
