@@ -456,7 +456,7 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
         if (K > (uint32_t)CH_KDENSE && blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_INTERNAL;
         return;
     }
-    const uint32_t z0 = st->bz0;
+    const uint32_t z0 = st->bz0, brep = st->brep;
     if (threadIdx.x < CH_KMAX) {
         s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
         s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
@@ -475,7 +475,8 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
     const uint32_t lim = min(vc, (uint32_t)LDSD_CAP);
     for (uint32_t p = 0; p < K; p++) {
         const uint32_t *sd = s_sd + p * CH_SD;
-        uint32_t *g = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (blockIdx.x & (uint32_t)(CH_RSTRIDE - 1)), vc);
+        // (as many replica blocks per pair as the table update will fold: st->brep)
+        uint32_t *g = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (blockIdx.x & (brep - 1u)), vc);
         for (uint32_t i = threadIdx.x; i < lim; i += LEAN_MT) {
             const uint32_t l = sd[i], r = sd[LDSD_CAP + i];
             if (l) atomicAdd(&g[i], l);
