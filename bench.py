@@ -17,7 +17,7 @@ tie-break, merge, pair-table update)):
   encode   BASELINE.json configs[4] shape: batch encode of documents (own vocabulary).
 
 The headline workload is timed for --steps; the --secondary workloads (default
-basic1g,cfg2,regex1g_dedup,encode at N=1) run --secondary-steps each after it and are reported under
+basic1g,cfg2,regex1g_dedup,e2e_class,encode at N=1) run --secondary-steps each after it and are reported under
 "secondary".  N > 1: the chunk list of regex1g is sharded (contiguous chunk ranges,
 --bytes per GPU = cfg4 shape, weak scaling); `value` is the rate of the ONE sharded job.
 
@@ -227,15 +227,17 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     avg_launch_s = hp["ms"] / launches * 1e-3
     roofline = {
         "bound": "hbm",
-        "kernel": {"merge": "merge pass = k_merge_ab_dense | k_merge_ab_sparse | k_merge_ab_lean (a != b: merge + "
-                            "pair-table delta) + k_merge_aa (a == b)", "pair_count": "k_pair_count", "widen": "k_widen"}[hot],
+        "kernel": {"merge": "merge pass = k_merge_chain | k_merge_chain_dense | k_merge_chain_dense1 (a chain step: 1..8 "
+                            "merges + their pair-table deltas in one sweep) | k_merge_ab_* + k_merge_aa (a general iteration)",
+                   "pair_count": "k_load_count (bytes -> ids + chunk starts + pair counts)", "widen": "k_widen"}[hot],
         "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
         "traffic": None, "traffic_source": None,
         "launches": hp["launches"], "avg_launch_ms": round(avg_launch_s * 1e3, 5),
         "alg_bytes_per_launch": hp["alg_bytes"] // launches,
         "equivalent_work_GBps": round(alg_GBps, 1), "equivalent_work_frac": round(alg_GBps / HBM_PEAK_GBPS, 4),
-        "note": "achieved / frac = PHYSICAL: HBM bytes per launch (`traffic`: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE of this "
-                "same command, committed profile, attached only when it was measured on these library sources) / the "
+        "note": "achieved / frac = PHYSICAL: HBM bytes per launch (`traffic`: 32 x the size-weighted TCC/EA request counters "
+                "of a rocprofv3 --pmc pass of this same command -- calibrated on known byte counts, profiles/r4_pmc_calibration.json "
+                "-- committed profile, attached only when it was measured on these library sources) / the "
                 "hipEvent time of the pass / 8 TB/s.  equivalent_work_* = the SURVEY 8d ALGORITHMIC bytes, 4(2N_i + "
                 "N_{i+1}) per merge (what the reference's get_stats + merge touch), over the same time: the pass does "
                 "not re-read the stream for get_stats and skips slots a merge cannot touch, so that figure exceeds the "
@@ -317,7 +319,32 @@ def run_dedup_workload(wl, eng, steps, barrier, ref):
     }
 
 
-def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters):
+def run_e2e_class_workload(wl, ref):
+    """What a minbpe user calls: RegexTokenizer().train(text, vocab_size) (regex.py:36-70) on the headline input as ONE
+    Python str -- wall clock of the whole call: utf-8 encode, native pre-split, (de-duplication), H2D upload, device
+    training, merges / vocab dicts.  Both settings of the class's `dedup` switch; the merges must be the headline's."""
+    from minbpe_amd import RegexTokenizer
+    data = synth_cached(wl["bytes"], wl["seed"])
+    text = data.decode("utf-8")
+    out = {"workload": f"RegexTokenizer().train(text, {wl['vocab']}) on the {wl['bytes']} B headline input as one str "
+                       f"({len(text)} characters): wall clock of the whole call"}
+    tok = RegexTokenizer()
+    tok.train(text[:1_000_000], 300)  # (context, allocations)
+    for label, dedup in (("dedup_auto", "auto"), ("dedup_off", False)):
+        tok = RegexTokenizer()
+        tok.dedup = dedup
+        t0 = time.perf_counter()
+        tok.train(text, wl["vocab"])
+        dt = time.perf_counter() - t0
+        pairs = [p for p, _ in sorted(tok.merges.items(), key=lambda kv: kv[1])]
+        out[label] = {"wall_s": round(dt, 3), "merges_per_s": round((wl["vocab"] - 256) / dt, 1),
+                      "same_merges_as_headline_run": None if ref is None else bool(pairs == [tuple(p) for p in ref[0]])}
+    out["python_reference"] = ("not timed here (cannot travel to this host); BASELINE.md: 1.07 s per merge at 4 MB in the build "
+                               "container, O(N) per merge -> ~268 s per merge at 1 GB, ~98 days for these 31,744 merges")
+    return out
+
+
+def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters, total_bytes=None):
     """The oracle (C port of the reference loop, one thread) on the first `cpu_bytes` of the same input
     for `cpu_iters` iterations; the rate is scaled linearly in N to the full size (the reference loop is
     O(N) per merge).  Also the unmodified Python reference on a smaller slice when it is importable."""
@@ -337,12 +364,13 @@ def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters):
     cp, _, _ = oracle.train(sample, cpu_iters, so)
     ct = time.perf_counter() - t0
     rate = cpu_iters / ct
-    scale = nb / len(data)
+    total = total_bytes or len(data)  # (a sharded job: the bytes of ALL ranks)
+    scale = nb / total
     out = {
         "value": round(rate * scale, 4), "unit": "merges/s", "cores": 1, "kind": "port",
         "sample": f"oracle/bpe_oracle.c (get_stats + max + merge, one thread): first {cpu_iters} merges of the "
                   f"first {nb} bytes of the same input in {ct:.1f} s = {rate:.2f} merges/s, scaled by "
-                  f"{scale:.3f} (O(N) per merge) to the full {len(data)} bytes",
+                  f"{scale:.3f} (O(N) per merge) to the full {total} bytes",
         "sample_merges_per_s": round(rate, 3), **host_info(),
     }
     if nb == len(data):
@@ -469,6 +497,8 @@ def run_encode_workload(eng, steps, warmup, barrier, pairs=None, tables=("cfg3",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "achieved_kind": "algorithmic (text bytes in + 4 B per token out) / hipEvent time",
                 "traffic": traffic, "traffic_source": tsrc,
+                "physical_GBps": round(traffic / dev_s / 1e9, 1) if (traffic and dev_s) else None,
+                "physical_frac": round(traffic / dev_s / 1e9 / HBM_PEAK_GBPS, 4) if (traffic and dev_s) else None,
                 "note": "every distinct chunk is encoded once and copied to its other occurrences (DESIGN 4); what is left "
                         "is one random 32-byte table access per chunk in each pass (its slot, then its owner's tokens) "
                         "-- sectors served by L2 / Infinity Cache, not counted in the algorithmic bytes -- and pass 1's "
@@ -595,13 +625,16 @@ def main():
         del data, offs, res
         sec = args.secondary
         if sec is None:
-            sec = ("basic1g,cfg2,regex1g_dedup,encode"
+            sec = ("basic1g,cfg2,regex1g_dedup,e2e_class,encode"
                    if (args.workload is None and args.bytes is None and args.vocab is None) else "none")
         secondary = {}
         for sname in [s for s in sec.split(",") if s and s != "none"]:
             try:
                 if sname == "encode":  # BASELINE.json configs[4] (see run_encode_workload)
                     secondary[sname] = run_encode_workload(eng, 2, 1, barrier, plain_ref[0] if plain_ref else None)
+                    continue
+                if sname == "e2e_class":
+                    secondary[sname] = run_e2e_class_workload(dict(WORKLOADS["regex1g"]), plain_ref)
                     continue
                 if WORKLOADS[sname].get("dedup"):
                     secondary[sname] = run_dedup_workload(dict(WORKLOADS[sname]), eng, args.secondary_steps,
@@ -624,12 +657,22 @@ def main():
         data, offs, _ = make_input(wl, rank)
         eng.load_bytes(data, offs)
         comm = TorchComm()
-        dist_path = "torch.distributed"
-        if os.environ.get("BPE_DIST", "native") == "native" and init_native_comm(eng, comm):
-            dist_path = "librccl (in-library loop)"
+        # BPE_DIST = native (default): bpe_dp_train, chain steps with the library's own librccl | torch: the same loop,
+        # every collective a torch.distributed all-reduce through a callback | steps: the per-merge protocol of dist.py
+        which = os.environ.get("BPE_DIST", "native")
+        if which == "native" and init_native_comm(eng, comm):
+            dist_path = "chain steps, librccl in the library's loop (bpe_dp_train)"
             step = lambda: eng.dp_train(num_merges)
+        elif which != "steps":
+            from minbpe_amd.dist import torch_allreduce
+            dev = torch.device("cuda", local_rank)
+            eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            ar = torch_allreduce(comm, dev)
+            dist_path = "chain steps, torch.distributed all-reduce per collective (bpe_dp_train_cb)"
+            step = lambda: eng.dp_train_cb(num_merges, rank, world, ar)
         else:
             shard = GpuShard(eng, local_rank)
+            dist_path = "per-merge protocol, torch.distributed (dist.train_sharded)"
             step = lambda: train_sharded(shard, comm, num_merges)
         for _ in range(args.warmup):
             step()
@@ -660,9 +703,28 @@ def main():
                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                     "launches": mg["launches"], "avg_launch_ms": round(mg["ms"] / mg["launches"], 5),
                     "alg_bytes_per_launch": int(alg // mg["launches"]),
+                    "achieved_kind": "algorithmic (SURVEY 8d bytes / hipEvent time)",
                     "note": "per GPU: the job's algorithmic bytes (4(2N_i + N_{i+1}) on GLOBAL lengths) / world, over "
-                            "the hipEvent time of rank 0's merge passes; no PMC traffic for sharded runs",
+                            "the hipEvent time of rank 0's merge passes",
                 }
+                # physical: counters cannot be read inside a run; a rank's merge passes work on a shard of the single-GPU
+                # headline's size with the same kernels, so the committed single-GPU PMC profile's bytes per merge give
+                # an ESTIMATE of this rank's traffic (labelled as such; the per-launch figure does not carry over:
+                # a sharded step's batch is capped lower)
+                pmc_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_regex1g_pmc.json")
+                if os.path.exists(pmc_file) and wl["bytes"] == WORKLOADS["regex1g"]["bytes"]:
+                    with open(pmc_file) as f:
+                        pmc = json.load(f)
+                    if pmc.get("source_hash") == source_hash() and pmc.get("merges"):
+                        per_merge = pmc["hbm_bytes_total"] / pmc["merges"]
+                        phys = per_merge * num_merges * args.steps / (mg["ms"] * 1e-3) / 1e9
+                        roofline.update({
+                            "achieved": round(phys, 1), "frac": round(phys / HBM_PEAK_GBPS, 4),
+                            "traffic": int(per_merge * num_merges / max(mg["launches"] / args.steps, 1)),
+                            "achieved_kind": "physical ESTIMATE: HBM bytes per merge of the single-GPU PMC profile "
+                                             f"(profiles/{PROFILE_ROUND}_regex1g_pmc.json, same sources, same shard size) "
+                                             "x merges / this rank's hipEvent time of its merge passes",
+                            "equivalent_work_GBps": round(ach, 1)})
         except Exception as e:
             roofline = None
             line["roofline_error"] = f"{type(e).__name__}: {e}"
@@ -695,11 +757,18 @@ def main():
             "config": {"workload": f"{wl['desc']} sharded over {world} GPUs by contiguous chunk ranges, "
                                    f"{wl['bytes']} B synthetic UTF-8 per GPU (seed {wl['seed']}+rank), vocab "
                                    f"{wl['vocab']} ({num_merges} merges); ranks agree: {dp_check['ranks_agree']}",
-                       "parallelism": f"dp{world} (per-merge all-reduce of tie key + table deltas; "
-                                      f"collectives via {dist_path})"},
+                       "parallelism": f"dp{world} ({dist_path}: per step of 1..K merges one MIN all-reduce of a tie's "
+                                      f"first occurrences and one SUM all-reduce of the batch's table deltas)"},
             "value_definition": "merges per second of the ONE sharded job (not summed over ranks)",
             "sharded_check": dp_check, "roofline": roofline, "cpu_baseline": None,
+            "merge_passes": eng.train_stats(),
         })
+        if rank == 0 and args.cpu_iters > 0:  # (rank 0's host, its own shard as the sample, scaled to the whole job)
+            try:
+                line["cpu_baseline"] = cpu_baseline(wl, data, offs, res, args.cpu_bytes, args.cpu_iters,
+                                                    total_bytes=wl["bytes"] * world)
+            except Exception as e:
+                line["cpu_baseline"] = f"failed: {type(e).__name__}: {e}"
 
     if rank == 0:
         print(json.dumps(line))

@@ -161,6 +161,28 @@ int bpe_comm_init(bpe_ctx *ctx, int32_t rank, int32_t nranks, const uint8_t *id1
 int bpe_comm_destroy(bpe_ctx *ctx);
 int bpe_dp_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
                  uint64_t *len_out, int32_t *n_done);
+/* bpe_dp_train runs the single-GPU engine's CHAIN STEPS across the ranks: a step merges the next 1..K pairs
+ * the reference would merge (the tied pairs at the maximum in order of first occurrence, as long as they share no
+ * token), and costs two all-reduces whatever K is:
+ *   MIN  int64 x 98              a tie's first occurrences, rank << 40 | local position per tied pair (word 0 = -status,
+ *                                word 1 = -1 from a rank that cannot order its share: the general path decides instead)
+ *   SUM  int32 x (2 K_cap S + 64)   the batch's delta vectors (S = ids in use, rounded to 64) + per-pair adj words +
+ *                                one status word: a failure inside rank r's merge pass is known to every rank BEFORE
+ *                                the table update of that same step -- all ranks stop at the same merge
+ * (the merges before the tied regime, and every a == b merge, take the per-merge schedule above).
+ * bpe_dp_train_cb is the same loop with the collectives handed to the caller: fn(user, device_buffer, count, dtype,
+ * op, hip_stream) must all-reduce `count` elements IN PLACE across the ranks, ordered after the work already enqueued on
+ * hip_stream and before whatever is enqueued next (enqueue it on that stream, or synchronise), and return 0 -- how
+ * torch.distributed (or a test's host-side reduction) drives the loop without librccl in the library.  Every rank
+ * calls fn the same number of times with the same counts, also after a rank-local failure. */
+#define BPE_DT_INT32 0
+#define BPE_DT_INT64 1
+#define BPE_OP_SUM 0
+#define BPE_OP_MIN 1
+typedef int (*bpe_allreduce_fn)(void *user, void *device_buffer, uint64_t count, int32_t dtype, int32_t op,
+                                void *hip_stream);
+int bpe_dp_train_cb(bpe_ctx *ctx, int32_t num_merges, int32_t rank, int32_t nranks, bpe_allreduce_fn fn, void *user,
+                    int32_t *pairs_out, uint64_t *counts_out, uint64_t *len_out, int32_t *n_done);
 
 /* ---- encode ----------------------------------------------------------------- */
 /* _encode_chunk for a batch of chunks (regex.py:92-121; basic.py:57-74 when

@@ -51,6 +51,9 @@ def _load_library():
 
 _lib = _load_library()
 _p = C.c_void_p
+# bpe_allreduce_fn (include/bpe_hip.h): (user, device_buffer, count, dtype, op, hip_stream) -> 0 on success
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p)
+DT_INT32, DT_INT64, OP_SUM, OP_MIN = 0, 1, 0, 1
 _u64 = C.c_uint64
 _i32 = C.c_int32
 
@@ -86,6 +89,7 @@ _SIGS = {
     "bpe_comm_init": (C.c_int, [_p, _i32, _i32, _p]),
     "bpe_comm_destroy": (C.c_int, [_p]),
     "bpe_dp_train": (C.c_int, [_p, _i32, _p, _p, _p, C.POINTER(_i32)]),
+    "bpe_dp_train_cb": (C.c_int, [_p, _i32, _i32, _i32, C.c_void_p, _p, _p, _p, _p, C.POINTER(_i32)]),
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_decode_set_vocab": (C.c_int, [_p, _p, _p, _i32]),
     "bpe_decode_batch": (C.c_int, [_p, _p, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
@@ -397,6 +401,38 @@ class Engine:
         self.last_train = dict(
             pairs=list(map(tuple, pairs[:2 * d].reshape(d, 2).tolist())),
             counts=counts[:d].tolist(), lens=lens[:d].tolist(), iter_ms=None, n_done=d)
+        self._check(rc)
+        return self.last_train
+
+    def dp_train_cb(self, num_merges: int, rank: int, nranks: int, allreduce):
+        """Sharded training (the same loop as dp_train) with the collectives handed to `allreduce(ptr, count, dtype,
+        op, stream)`: all-reduce `count` elements at device address `ptr` in place across the ranks (dtype DT_INT32 /
+        DT_INT64, op OP_SUM / OP_MIN), ordered after the work already on HIP stream `stream`; raise to fail.
+        Same result dict as train(); lens are global."""
+        nm = max(num_merges, 1)
+        pairs = np.zeros(2 * nm, np.int32)
+        counts = np.zeros(nm, np.uint64)
+        lens = np.zeros(nm, np.uint64)
+        done = _i32(0)
+        raised = []
+
+        def _cb(_user, buf, count, dtype, op, stream):
+            try:
+                allreduce(buf, count, dtype, op, stream)
+                return 0
+            except BaseException as e:  # (must not propagate through the C frames)
+                raised.append(e)
+                return 1
+
+        cb = ALLREDUCE_FN(_cb)
+        rc = _lib.bpe_dp_train_cb(self._h, num_merges, rank, nranks, C.cast(cb, C.c_void_p), None, _ptr(pairs),
+                                  _ptr(counts), _ptr(lens), C.byref(done))
+        d = done.value
+        self.last_train = dict(
+            pairs=list(map(tuple, pairs[:2 * d].reshape(d, 2).tolist())),
+            counts=counts[:d].tolist(), lens=lens[:d].tolist(), iter_ms=None, n_done=d)
+        if raised:
+            raise raised[0]
         self._check(rc)
         return self.last_train
 

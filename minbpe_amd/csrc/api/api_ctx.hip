@@ -1,6 +1,14 @@
 // api_ctx.hip -- the ctx, error / allocation helpers, profiling events, kernel-launch helpers.
 // Part of bpe_api.hip, which includes the parts in order (one translation unit).
 
+// how a sharded training loop reaches the other ranks (bpe_dp_train: librccl on the ctx's stream; bpe_dp_train_cb:
+// the caller's function)
+struct DpComm {
+    bpe_allreduce_fn fn = nullptr;
+    void *user = nullptr;
+    int rank = 0, nranks = 1;
+};
+
 struct bpe_ctx {
     int device = 0;
     int num_cus = 256;
@@ -15,6 +23,16 @@ struct bpe_ctx {
     uint64_t n_chunks = 0, cap_offsets = 0;
     bool have_bytes = false;
     uint8_t *d_wexp = nullptr;  // per chunk: weight exponent (bpe_load_bytes_weighted)
+    // sharded chain steps (dp_train_loop): the communicator of the loop in progress, the MIN payload of a tie's first
+    // occurrences (DP_KEY_WORDS int64), the SUM payload of a batch's delta (2 dp_kcap vcap + 64 words)
+    const struct DpComm *dp_comm = nullptr;
+    long long *d_dp_ckey = nullptr;
+    uint32_t *d_dp_cfold = nullptr;
+    uint64_t cap_dp_cfold = 0;
+    int dp_kcap = CH_KMAX;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
+    uint64_t *d_round_lb = nullptr;  // k_load_count: first chunk of every segment of the byte stream
+    uint64_t cap_round_lb = 0;
+    bool fuse_load = true;  // option "fuse_load": the byte stream's first get_stats rides on the widening pass
     uint64_t cap_wexp = 0;
     bool weighted = false;
 
@@ -378,6 +396,15 @@ int prof_drain(bpe_ctx *c) {
     return BPE_OK;
 }
 
+// one collective of the sharded loop in progress, enqueued behind the work already on the ctx's stream
+int dp_allreduce(bpe_ctx *c, void *buf, uint64_t count, int32_t dtype, int32_t op) {
+    const DpComm *dp = c->dp_comm;
+    if (!dp || !dp->fn) return fail(c, BPE_E_STATE, "no communicator");
+    const int rc = dp->fn(dp->user, buf, count, dtype, op, (void *)c->stream);
+    if (rc != 0) return fail(c, BPE_E_HIP, "all-reduce failed (%d)", rc);
+    return BPE_OK;
+}
+
 // ---- launch helpers -----------------------------------------------------------
 inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap) {
     uint64_t g = (work_items + per_block - 1) / per_block;
@@ -386,30 +413,58 @@ inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap) 
     return (unsigned)g;
 }
 
-// widen resident bytes into ids[0], mark chunk starts, reset state
-int start_from_bytes(bpe_ctx *c) {
+// The byte stream's first get_stats can ride on the widening pass (k_load_count): unit increments into 16-bit LDS
+// counters, so not for weighted chunks; option "fuse_load" = 0 keeps the three separate passes (cross-check).
+inline bool load_count_fusable(const bpe_ctx *c) { return c->fuse_load && c->k1 == 2 && !c->weighted && c->nbytes >= 2; }
+
+// widen resident bytes into ids[0], mark chunk starts, reset state.  count = true (the table is cleared, on this
+// stream, and load_count_fusable(c) holds): the pair counts of the byte stream go into the table in the same pass.
+int start_from_bytes(bpe_ctx *c, bool count = false) {
     const uint64_t n = c->nbytes;
     TRY(ensure_ids(c, n));
-    TRY(prof_begin(c, BPE_PROF_WIDEN, 5 * n));
-    if (n) {
-        hipLaunchKernelGGL(k_widen, dim3(grid_for(n, 256 * 16, c->num_cus * 8)), dim3(256), 0,
-                           c->stream, c->d_bytes, c->d_ids[0], n);
-        LAUNCHCHK(c, "k_widen");
-        if (c->n_chunks) {
-            hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)),
-                               dim3(256), 0, c->stream, c->d_ids[0], c->d_offsets, c->n_chunks, n);
-            LAUNCHCHK(c, "k_mark_starts");
-            if (c->weighted) {
-                hipLaunchKernelGGL(k_mark_weights, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)), dim3(256),
-                                   0, c->stream, c->d_ids[0], c->d_offsets, c->d_wexp, c->n_chunks, n);
-                LAUNCHCHK(c, "k_mark_weights");
+    if (count) {
+        const uint64_t segs = (n + LC_SEG - 1) / LC_SEG;
+        if (segs + 2 > c->cap_round_lb) {
+            TRY(dev_realloc(c, c->d_round_lb, (size_t)segs + 2));
+            c->cap_round_lb = segs + 2;
+        }
+        TRY(prof_begin(c, BPE_PROF_PAIR_COUNT, 4 * n));
+        const uint64_t *off = c->n_chunks ? c->d_offsets : nullptr;
+        if (off) {
+            hipLaunchKernelGGL(k_seg_lb, dim3((unsigned)((segs + 256) / 256)), dim3(256), 0, c->stream, off,
+                               (uint64_t)c->n_chunks, segs, c->d_round_lb);
+            LAUNCHCHK(c, "k_seg_lb");
+        }
+        const uint64_t wgs = (segs + LC_WAVES - 1) / LC_WAVES;
+        hipLaunchKernelGGL(k_load_count, dim3((unsigned)std::min<uint64_t>(wgs, (uint64_t)c->num_cus)), dim3(PC_THREADS),
+                           LC_LDS_BYTES, c->stream, c->d_bytes, off, c->d_round_lb, (uint64_t)c->n_chunks, n, c->d_ids[0],
+                           c->d_mat, c->vcap);
+        LAUNCHCHK(c, "k_load_count");
+        hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
+        LAUNCHCHK(c, "k_init_state");
+        TRY(prof_end(c));
+    } else {
+        TRY(prof_begin(c, BPE_PROF_WIDEN, 5 * n));
+        if (n) {
+            hipLaunchKernelGGL(k_widen, dim3(grid_for(n, 256 * 16, c->num_cus * 8)), dim3(256), 0,
+                               c->stream, c->d_bytes, c->d_ids[0], n);
+            LAUNCHCHK(c, "k_widen");
+            if (c->n_chunks) {
+                hipLaunchKernelGGL(k_mark_starts, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)),
+                                   dim3(256), 0, c->stream, c->d_ids[0], c->d_offsets, c->n_chunks, n);
+                LAUNCHCHK(c, "k_mark_starts");
+                if (c->weighted) {
+                    hipLaunchKernelGGL(k_mark_weights, dim3(grid_for(c->n_chunks, 256, c->num_cus * 8)), dim3(256),
+                                       0, c->stream, c->d_ids[0], c->d_offsets, c->d_wexp, c->n_chunks, n);
+                    LAUNCHCHK(c, "k_mark_weights");
+                }
             }
         }
+        hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
+        LAUNCHCHK(c, "k_init_state");
+        TRY(prof_end(c));
     }
-    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(1), 0, c->stream, c->d_st, (unsigned long long)n);
-    LAUNCHCHK(c, "k_init_state");
     c->apply_target = 0;
-    TRY(prof_end(c));
     c->par = 0;
     c->n = n;
     c->vcur = 256;
@@ -487,9 +542,9 @@ SlotRefH stream_ref_h(const bpe_ctx *c) {
     return r;
 }
 
-// single-GPU training, index live: the a == b pass of a sparse iteration visits the slots k_select lists
-// for it and adds the pairs it creates to the index (no "visit always" marks, no rebuild afterwards)
-inline bool aa_through_index(const bpe_ctx *c) { return c->aa_sparse && c->idx_live && !c->dp_active; }
+// index live: the a == b pass of a sparse iteration visits the slots k_select (sharded: k_dp_cand, once the pair is
+// known) lists for it and adds the pairs it creates to the index (no "visit always" marks, no rebuild afterwards)
+inline bool aa_through_index(const bpe_ctx *c) { return c->aa_sparse && c->idx_live; }
 
 // K2 + tie-break: after this the pair is final in st (sharded streams: resolved_pair() gives
 // this rank's candidate)
@@ -1047,11 +1102,23 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         HIPCHK(c, hipMalloc((void **)&c->d_chain_req, 64 * sizeof(unsigned long long)));
         HIPCHK(c, hipMemsetAsync(c->d_chain_req, 0, 64 * sizeof(unsigned long long), c->stream));
     }
+    // sharded training (dp_train_loop, api_rccl.hip): the step's two collectives sit between its launches -- a tie's
+    // first occurrences (MIN) before the batch is formed, the batch's delta (SUM) before the table update.  A batch
+    // goes on below the maximum only when the maximum is attained by ONE pair (k_chain_sel then decides everything
+    // from replicated state, as on one GPU); after a tie the list is made by k_chain_sel_dp, which stays at the maximum
+    const DpComm *dp = c->dp_comm;
+    uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : CH_KMAX);
+    if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
     hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                        (uint32_t)(c->chain_extend && c->chain_scan >= CH_KMAX - 1),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
-                       (uint32_t)(dense ? CH_KDENSE : CH_KMAX));
+                       kcap, dp ? c->d_dp_ckey : (long long *)nullptr, (unsigned long long)(dp ? dp->rank : 0));
     LAUNCHCHK(c, "k_chain_sel");
+    if (dp) {
+        TRY(dp_allreduce(c, c->d_dp_ckey, DP_KEY_WORDS, BPE_DT_INT64, BPE_OP_MIN));
+        hipLaunchKernelGGL(k_chain_sel_dp, dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
+        LAUNCHCHK(c, "k_chain_sel_dp");
+    }
     TRY(prof_end(c));
     AbArgs A;
     A.b0 = c->d_ids[0];
@@ -1088,9 +1155,19 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (zhi + 1 + 255) / 256;
     const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
+    const uint32_t fS = std::min<uint32_t>(c->vcap, ((zhi + 1 + 63) / 64) * 64);  // vector stride of the SUM payload
+    uint32_t *ftail = dp ? c->d_dp_cfold + (size_t)2 * kcap * fS : nullptr;
+    if (dp) {
+        hipLaunchKernelGGL(k_dp_fold_chain, dim3(na), dim3(256), 0, c->stream, c->d_delta, dl, c->d_st, c->d_dp_cfold, fS, ftail);
+        LAUNCHCHK(c, "k_dp_fold_chain");
+        TRY(dp_allreduce(c, c->d_dp_cfold, (uint64_t)2 * kcap * fS + 64, BPE_DT_INT32, BPE_OP_SUM));
+        hipLaunchKernelGGL(k_dp_after_sum, dim3(1), dim3(1), 0, c->stream, c->d_st, ftail);
+        LAUNCHCHK(c, "k_dp_after_sum");
+    }
     hipLaunchKernelGGL(k_apply_chain, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
                        c->d_st, c->d_dbits, c->par, c->h_rec, c->h_srec, step, na, c->d_hdr2[c->mq], c->d_stage,
-                       c->d_removed, c->d_smask, nwords, c->d_lean_sum);
+                       c->d_removed, c->d_smask, nwords, c->d_lean_sum, dp ? c->d_dp_cfold : (const uint32_t *)nullptr, fS,
+                       (const uint32_t *)ftail);
     LAUNCHCHK(c, "k_apply_chain");
     TRY(prof_end(c));
     c->par ^= 1;

@@ -26,9 +26,10 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     HIPCHK(c, hipMemsetAsync(c->d_dp_folded, 0, ((size_t)c->vcap * 4 + 64) * sizeof(uint32_t), c->stream));
     if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
     if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 3 * sizeof(long long)));
-    TRY(start_from_bytes(c));
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
-    TRY(launch_pair_count(c, false));
+    const bool fused_load = load_count_fusable(c);
+    TRY(start_from_bytes(c, fused_load));
+    if (!fused_load) TRY(launch_pair_count(c, false));
     // the byte-pair block of the table, packed, is the first all-reduce payload
     HIPCHK(c, hipMemcpy2DAsync(c->d_dp_table, 256 * 4, c->d_mat, (size_t)c->vcap * 4, 256 * 4, 256,
                                hipMemcpyDeviceToDevice, c->stream));
@@ -83,6 +84,7 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     }
     c->dp_sparse = false;
     if (c->slotted && c->slot2) TRY(plan_pass2(c, &c->dp_sparse));  // (counts are global: every rank decides alike)
+    TRY(flush_lean_rows(c, c->vcur));  // (row maxima a chain step's table update left to do: dp_train_loop)
     TRY(launch_select(c, false));
     if (c->slotted && c->slot2)
         hipLaunchKernelGGL(k_dp_key<SlotRefH>, dim3(1), dim3(64), 0, c->stream, stream_ref_h(c), c->par, c->d_st,
@@ -111,7 +113,7 @@ extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
             C.T = (uint32_t)c->slot_T;
             C.enable = 1;
             C.tie_index = C.tie_window = 0;
-            C.aa = 0;
+            C.aa = aa_through_index(c) ? 1u : 0u;
             hipLaunchKernelGGL(k_dp_cand, dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
             LAUNCHCHK(c, "k_dp_cand");
         }
@@ -136,6 +138,8 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     const uint32_t Z = 256u + (uint32_t)iter;
     if (c->slotted && c->slot2) {
         const int mq0 = c->mq;
+        hipLaunchKernelGGL(k_dp_after_sum, dim3(1), dim3(1), 0, c->stream, c->d_st, c->d_dp_folded + 4 * (size_t)c->vcap);
+        LAUNCHCHK(c, "k_dp_after_sum");
         TRY(launch_table2(c, Z, iter, c->h_rec, c->dp_sparse, c->dp_dl, true));
         if ((size_t)iter < c->dp_flip.size()) c->dp_flip[(size_t)iter] = (uint8_t)(c->mq != mq0);
         return BPE_OK;
@@ -167,7 +171,7 @@ extern "C" int bpe_dp_poll(bpe_ctx *c, int32_t iter, int32_t *a, int32_t *b, uin
     if (r->status == ST_OK) {
         if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
         c->last_count = r->count;  // (global count: the same on every rank)
-        if (r->a == r->b && c->idx_live) c->idx_rebuild = true;
+        if (r->a == r->b && c->idx_live && !aa_through_index(c)) c->idx_rebuild = true;
         c->dp_cur_len = r->new_len;
         c->n = r->new_len;  // tighter launch bound
         c->dp_done = iter + 1;

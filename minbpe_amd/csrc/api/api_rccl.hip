@@ -87,84 +87,246 @@ extern "C" int bpe_comm_destroy(bpe_ctx *c) {
     return BPE_OK;
 }
 
-// The whole sharded training loop on the host side of the library: same protocol as
-// minbpe_amd/dist.py (which remains the reference driver and the torch.distributed
-// path), with the two per-merge all-reduces enqueued on the ctx's stream.
-// len_out receives GLOBAL stream lengths (summed over ranks).
-extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
-                            uint64_t *len_out, int32_t *n_done) {
-    if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
-    if (!c->comm) return fail(c, BPE_E_STATE, "bpe_comm_init first");
-    RcclApi *r = rccl();
+// ---------------------------------------------------------------------------
+// The sharded training loop: bpe_train's queue of units (api_train.hip) with the collectives between the launches.
+// Two kinds of unit, chosen from GLOBAL facts only (the iteration number, the last merge's global count, what the
+// step records said) so that every rank enqueues the same units -- and with them the same collectives -- in the same
+// order, whatever its own shard looks like:
+//   GENERAL  one merge, the five-launch iteration: bpe_dp_select -> MIN (3 x int64) -> bpe_dp_merge -> SUM
+//            (4 vcap + 64 x int32) -> bpe_dp_apply.  The merges before the tied regime, and what a chain step hands
+//            back (a == b at the head of the list, a tie some rank cannot order).
+//   CHAIN    a chain step (k_chain.hip, launch_chain_step): 0..dp_kcap merges, MIN (98 x int64) + SUM (2 dp_kcap S + 64).
+// Rank-local choices (re-packing, sparse or dense pass, index builds) change which kernels a rank runs, never what
+// is exchanged.  The host runs `depth` units ahead and waits on records only, as on one GPU; a deferral drains the
+// queue on every rank at the same unit (the step records are replicas).  After a device status every later unit is a
+// no-op whose collectives still pair up.  A host-side failure (a HIP or comm call that returns an error) cannot be
+// recovered from: the stream is lost, the peers are left to their own time-outs.
+namespace {
+int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *pairs_out, uint64_t *counts_out,
+                  uint64_t *len_out, int32_t *n_done) {
     if (n_done) *n_done = 0;
-    TRY(bpe_dp_begin(c, num_merges, c->comm_rank, c->comm_nranks));
-    RCCLCHK(c, r->AllReduce(c->d_dp_table, c->d_dp_table, 256 * 256, RCCL_INT32, RCCL_SUM, c->comm, c->stream));
+    if (c->mode != 1 || c->use_slots != 2 || c->merge_impl != 0)
+        return fail(c, BPE_E_STATE, "sharded training needs the default engine (mode 1, slots 2, merge 0)");
+    struct CommScope {  // (launch_chain_step and dp_allreduce find the communicator in the ctx)
+        bpe_ctx *c;
+        ~CommScope() { c->dp_comm = nullptr; }
+    } scope{c};
+    c->dp_comm = &comm;
+    TRY(bpe_dp_begin(c, num_merges, comm.rank, comm.nranks));
+    TRY(ensure_srec(c));
+    if (!c->d_dp_ckey) HIPCHK(c, hipMalloc((void **)&c->d_dp_ckey, DP_KEY_WORDS * sizeof(long long)));
+    const uint64_t cfold_words = (uint64_t)2 * CH_KMAX * c->vcap + 64;
+    if (cfold_words > c->cap_dp_cfold) {
+        TRY(dev_realloc(c, c->d_dp_cfold, (size_t)cfold_words));
+        c->cap_dp_cfold = cfold_words;
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_dp_cfold, 0, cfold_words * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_dp_ckey, 0, DP_KEY_WORDS * sizeof(long long), c->stream));
+    TRY(dp_allreduce(c, c->d_dp_table, 256 * 256, BPE_DT_INT32, BPE_OP_SUM));
     TRY(bpe_dp_table_ready(c));
+
+    enum { U_GENERAL = 0, U_CHAIN = 2 };
+    struct Unit {
+        int kind, iter;
+        uint32_t step;
+        uint8_t hdr_flip, pass_kind;
+    };
+    std::deque<Unit> q;
     std::vector<long long> lens((size_t)std::max(num_merges, 1), 0);
-    int consumed = 0, done = 0, rc = BPE_OK;
-    bool stop = false;
-    auto consume = [&](int j) -> int {
-        int32_t a = 0, b = 0, status = 0;
-        uint64_t cnt = 0, ll = 0;
-        TRY(bpe_dp_poll(c, j, &a, &b, &cnt, &ll, &status));
-        if (status != BPE_OK) {
+    int done = 0, rc = BPE_OK, n_chain_inflight = 0;
+    uint32_t steps = 0;
+    bool stop = false, in_chain = false;
+    int general_until = -1, defer_hold = 0, defer_strikes = 0;
+    uint64_t lean_at_last_defer = 0, n_chain_merges = 0;
+    c->n_lean = c->n_deferred = 0;
+    c->n_steps = c->n_full = c->n_chained = 0;
+    c->rows_pending = false;
+    c->sum_valid = false;
+
+    auto take_record = [&](int j) -> int {
+        volatile IterRec *r = &c->h_rec[j];
+        if (r->status == ST_EMPTY) {
             stop = true;
-            rc = status == BPE_E_EMPTY_STATS
-                     ? fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j)
-                     : fail(c, BPE_E_INTERNAL, "sharded training failed at iteration %d", j);
+            rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", j);
+            return BPE_OK;
+        }
+        if (r->status != ST_OK) {
+            stop = true;
+            rc = fail(c, BPE_E_INTERNAL, "sharded training failed at iteration %d (device status %u)", j, r->status);
             return BPE_OK;
         }
         if (pairs_out) {
-            pairs_out[2 * j] = a;
-            pairs_out[2 * j + 1] = b;
+            pairs_out[2 * j] = r->a;
+            pairs_out[2 * j + 1] = r->b;
         }
-        if (counts_out) counts_out[j] = cnt;
-        lens[(size_t)j] = (long long)ll;
+        if (counts_out) counts_out[j] = r->count;
+        lens[(size_t)j] = (long long)r->new_len;
+        if (c->profile) c->prof_bytes[BPE_PROF_MERGE] += 4 * (2 * c->dp_cur_len + r->new_len);
+        c->dp_cur_len = r->new_len;
+        c->n = r->new_len;         // (this shard's length: a tighter launch bound)
+        c->last_count = r->count;  // (global: the same on every rank)
+        if (r->a == r->b && c->idx_live && !aa_through_index(c)) c->idx_rebuild = true;
         done = j + 1;
+        c->dp_done = done;
         return BPE_OK;
     };
-    // Every rank issues the SAME collectives for every i in [0, num_merges), whatever it has learnt
-    // about its own or a peer's failure in the meantime: once a device status is raised the kernels
-    // of the remaining iterations are no-ops (each checks st->status), the all-reduces still match
-    // up, and the third key word carries the status to every rank at the next merge (k_dp_key).
-    // A host-side failure (a HIP or RCCL call that returns an error) cannot be recovered from --
-    // the stream is lost -- and is reported after the peers have been released as far as possible.
-    int host_rc = BPE_OK;
-    auto keep = [&](int r_) {
-        if (r_ != BPE_OK && host_rc == BPE_OK) host_rc = r_;
-    };
-    auto allreduce = [&](void *buf, size_t count, int dtype, int op) -> int {
-        RCCLCHK(c, r->AllReduce(buf, buf, count, dtype, op, c->comm, c->stream));
+    auto wait_iter = [&](int j) -> int {
+        volatile IterRec *r = &c->h_rec[j];
+        for (uint64_t spins = 1; r->seq != (unsigned long long)j + 1; spins++) {
+            if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess && r->seq != (unsigned long long)j + 1)
+                return fail(c, BPE_E_INTERNAL, "iteration %d never reported (stream idle)", j);
+        }
+        __sync_synchronize();
         return BPE_OK;
     };
-    for (int i = 0; i < num_merges; i++) {
-        if (host_rc == BPE_OK) keep(bpe_dp_select(c, i));
-        keep(allreduce(c->d_dp_key, 3, RCCL_INT64, RCCL_MIN));
-        if (host_rc == BPE_OK) keep(bpe_dp_merge(c, i));
-        keep(allreduce(c->d_dp_folded, (size_t)c->vcap * 4 + 64, RCCL_INT32, RCCL_SUM));
-        if (host_rc == BPE_OK) keep(bpe_dp_apply(c, i));
-        if (host_rc == BPE_OK && !stop && i - consumed >= c->depth) {
-            keep(consume(consumed));
-            if (!stop) consumed++;
+    auto wait_step = [&](uint32_t s) -> int {
+        volatile StepRec *r = &c->h_srec[s % STEP_RING];
+        for (uint64_t spins = 1; r->seq != (unsigned long long)s + 1; spins++) {
+            if ((spins & 0xFFFF) == 0 && hipStreamQuery(c->stream) == hipSuccess && r->seq != (unsigned long long)s + 1)
+                return fail(c, BPE_E_INTERNAL, "chain step %u never reported (stream idle)", s);
+        }
+        __sync_synchronize();
+        return BPE_OK;
+    };
+    // a deferred chain step: it and the steps behind it merged nothing on any rank (api_train.hip, handle_deferral)
+    auto handle_deferral = [&](bool a_eq_b) -> int {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (const Unit &u : q) {
+            if (u.kind == U_CHAIN) c->n_steps--;
+            if (u.pass_kind == 1) c->n_sparse--; else if (u.pass_kind == 2) c->n_dense--;
+        }
+        q.clear();
+        n_chain_inflight = 0;
+        hipLaunchKernelGGL(k_clear_defer_chain, dim3(1), dim3(1), 0, c->stream, c->d_st);
+        LAUNCHCHK(c, "k_clear_defer_chain");
+        c->rows_pending = true;  // (flag words may stand: k_rowmax_lean before the general selection)
+        c->n_deferred++;
+        if (c->lean_backoff && !a_eq_b) {
+            defer_strikes = (n_chain_merges - lean_at_last_defer < 16) ? defer_strikes + 1 : 0;
+            lean_at_last_defer = n_chain_merges;
+            defer_hold = defer_strikes >= 2 ? std::min(32 << std::min(defer_strikes - 2, 5), 1024) : 0;
+        } else if (a_eq_b) {
+            defer_hold = 0;
+        }
+        general_until = done + 1 + defer_hold;
+        in_chain = false;
+        return BPE_OK;
+    };
+
+    while (!stop && done < num_merges) {
+        const int lb = done + (int)q.size();
+        bool enqueued = false;
+        if (lb < num_merges && (int)q.size() <= c->depth) {
+            const int i = lb;
+            // chain steps: from the first merge whose predecessor's GLOBAL count is small enough on (the same test
+            // on every rank), outside the stretch a deferral handed to the general path
+            const bool want_chain = c->chain && c->lean && c->lean_select && c->tie_index && i > 0 && i >= general_until &&
+                                    c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count;
+            const bool known = n_chain_inflight == 0;
+            if (want_chain && (known || in_chain)) {
+                c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);
+                const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
+                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE2 * (den - 1)) {
+                    TRY(slots2_leave(c));
+                    TRY(slots2_enter(c));
+                }
+                bool sparse = false;
+                TRY(plan_pass2(c, &sparse));
+                if (!c->idx_live || c->idx_rebuild) TRY(index_build(c));  // (a tie is ordered through the index, whatever the pass)
+                if (!in_chain) {
+                    TRY(flush_lean_rows(c, c->vcur));
+                    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
+                    LAUNCHCHK(c, "k_set_iter");
+                    in_chain = true;
+                }
+                const int hi = std::min(num_merges, done + (int)q.size() * c->dp_kcap + c->dp_kcap);
+                TRY(launch_chain_step(c, steps, 255u + (uint32_t)hi, sparse, true, false));
+                q.push_back(Unit{U_CHAIN, -1, steps++, 0, (uint8_t)(sparse ? 1 : 2)});
+                n_chain_inflight++;
+                enqueued = true;
+            } else if (!want_chain && known) {
+                in_chain = false;
+                const int mq0 = c->mq;
+                TRY(bpe_dp_select(c, i));
+                TRY(dp_allreduce(c, c->d_dp_key, 3, BPE_DT_INT64, BPE_OP_MIN));
+                TRY(bpe_dp_merge(c, i));
+                TRY(dp_allreduce(c, c->d_dp_folded, (uint64_t)c->vcap * 4 + 64, BPE_DT_INT32, BPE_OP_SUM));
+                TRY(bpe_dp_apply(c, i));
+                q.push_back(Unit{U_GENERAL, i, 0u, (uint8_t)(c->mq != mq0), 0});
+                enqueued = true;
+            }
+        }
+        if (!q.empty() && ((int)q.size() > c->depth || !enqueued)) {
+            const Unit u = q.front();
+            if (u.kind == U_CHAIN) {
+                TRY(wait_step(u.step));
+                const StepRec sr = *const_cast<const StepRec *>(&c->h_srec[u.step % STEP_RING]);
+                if (sr.status == ST_DEFER) {
+                    if ((int)sr.first_iter != done)
+                        return fail(c, BPE_E_INTERNAL, "chain step %u deferred merge %u, the host expected %d", u.step, sr.first_iter, done);
+                    TRY(handle_deferral((sr.pad >> 8) == 1));
+                } else if (sr.status == ST_EMPTY) {
+                    stop = true;
+                    rc = fail(c, BPE_E_EMPTY_STATS, "max() arg is an empty sequence (iteration %d)", done);
+                } else if (sr.status != ST_OK) {
+                    stop = true;
+                    rc = fail(c, BPE_E_INTERNAL, "sharded training failed at iteration %d (device status %u, chain step %u)", done,
+                              sr.status, u.step);
+                } else {
+                    if (sr.k && (int)sr.first_iter != done)
+                        return fail(c, BPE_E_INTERNAL, "chain step %u did merges from %u on, the host expected %d", u.step, sr.first_iter, done);
+                    for (uint32_t j = 0; j < sr.k && !stop; j++) {
+                        TRY(wait_iter((int)(sr.first_iter + j)));
+                        TRY(take_record((int)(sr.first_iter + j)));
+                    }
+                    if (sr.k) {
+                        c->n_lean += sr.k;
+                        n_chain_merges += sr.k;
+                        if ((sr.pad & 0xFF) == CH_FULL) c->n_full++;
+                        c->n_chained += (sr.pad & 0xFF) == CH_FULL ? sr.k - 1 : sr.k;
+                    }
+                    q.pop_front();
+                    n_chain_inflight--;
+                }
+            } else {
+                TRY(wait_iter(u.iter));
+                TRY(take_record(u.iter));
+                if (!stop) q.pop_front();
+            }
         }
     }
-    while (host_rc == BPE_OK && !stop && consumed < num_merges) {
-        keep(consume(consumed));
-        if (!stop) consumed++;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!stop) {
+        for (const Unit &u : q) {
+            if (u.kind == U_CHAIN) c->n_steps--;
+            if (u.pass_kind == 1) c->n_sparse--; else if (u.pass_kind == 2) c->n_dense--;
+        }
+        q.clear();
+        TRY(flush_lean_rows(c, 256u + (uint32_t)done));
     }
-    if (host_rc != BPE_OK) {
-        c->dp_active = false;
-        c->slotted = false;
-        return host_rc;
+    c->rows_pending = false;
+    // leave the ids contiguous; the failing unit and the no-op units behind it: undo their parity flips
+    if (stop) {
+        if (q.size() & 1) c->par ^= 1;
+        for (const Unit &u : q)
+            if (u.hdr_flip) c->mq ^= 1;
+        hipLaunchKernelGGL(k_set_status, dim3(1), dim3(1), 0, c->stream, c->d_st, 0u);
     }
-    TRY(bpe_dp_end(c));
-    // global lengths: one SUM over the per-shard lengths
+    TRY(slots2_leave(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n = c->dp_cur_len;
+    c->vcur = 256u + (uint32_t)done;
+    TRY(prof_drain(c));
+    c->dp_nranks = 1;
+    c->dp_rank = 0;
+    c->dp_active = false;
+    // global lengths: one SUM over the per-shard lengths (every rank, also after a failure: `done` is the same everywhere)
     if (num_merges > 0) {
         DevTmp t_l;
         HIPCHK(c, t_l.alloc((size_t)num_merges * 8));
         long long *d_l = t_l.as<long long>();
         HIPCHK(c, hipMemcpyAsync(d_l, lens.data(), (size_t)num_merges * 8, hipMemcpyHostToDevice, c->stream));
-        RCCLCHK(c, r->AllReduce(d_l, d_l, (size_t)num_merges, RCCL_INT64, RCCL_SUM, c->comm, c->stream));
+        TRY(dp_allreduce(c, d_l, (uint64_t)num_merges, BPE_DT_INT64, BPE_OP_SUM));
         HIPCHK(c, hipMemcpyAsync(lens.data(), d_l, (size_t)num_merges * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (len_out)
@@ -172,4 +334,36 @@ extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, 
     }
     if (n_done) *n_done = done;
     return rc;
+}
+
+int rccl_allreduce(void *user, void *buf, uint64_t count, int32_t dtype, int32_t op, void *stream) {
+    bpe_ctx *c = (bpe_ctx *)user;
+    return rccl()->AllReduce(buf, buf, (size_t)count, dtype == BPE_DT_INT64 ? RCCL_INT64 : RCCL_INT32,
+                             op == BPE_OP_MIN ? RCCL_MIN : RCCL_SUM, c->comm, (hipStream_t)stream);
+}
+}  // namespace
+
+// librccl on the ctx's stream: the collectives are enqueued like kernels, the host never waits for one.
+extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *counts_out,
+                            uint64_t *len_out, int32_t *n_done) {
+    if (!c || num_merges < 0) return fail(c, BPE_E_ARG, "bad arguments");
+    if (!c->comm || !rccl()) return fail(c, BPE_E_STATE, "bpe_comm_init first");
+    DpComm comm;
+    comm.fn = rccl_allreduce;
+    comm.user = c;
+    comm.rank = c->comm_rank;
+    comm.nranks = c->comm_nranks;
+    return dp_train_loop(c, num_merges, comm, pairs_out, counts_out, len_out, n_done);
+}
+
+// the caller's all-reduce (torch.distributed through a ctypes callback, a test's host-side reduction)
+extern "C" int bpe_dp_train_cb(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_t nranks, bpe_allreduce_fn fn, void *user,
+                               int32_t *pairs_out, uint64_t *counts_out, uint64_t *len_out, int32_t *n_done) {
+    if (!c || num_merges < 0 || !fn || rank < 0 || nranks < 1 || rank >= nranks) return fail(c, BPE_E_ARG, "bad arguments");
+    DpComm comm;
+    comm.fn = fn;
+    comm.user = user;
+    comm.rank = rank;
+    comm.nranks = nranks;
+    return dp_train_loop(c, num_merges, comm, pairs_out, counts_out, len_out, n_done);
 }

@@ -22,7 +22,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     TRY(ensure_rec(c, std::max(num_merges, 1)));
     memset(c->h_rec, 0, sizeof(IterRec) * (size_t)std::max(num_merges, 1));
     TRY(ensure_srec(c));
-    TRY(start_from_bytes(c));
     const bool delta = (c->mode == 1);
     // one event after every unit of work enqueued (an iteration, or a chain step of 1..CH_KMAX merges)
     EventList ev_list;  // destroyed on every exit path
@@ -38,7 +37,6 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         if (hipEventRecord(e, c->stream) != hipSuccess) return -1;
         return (int)evs.size() - 1;
     };
-    // statistics of the initial byte stream (iteration 0 of both modes)
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
     // (a pass that a device status cut short in an earlier call may have left partial sums behind)
@@ -49,8 +47,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     HIPCHK(c, hipMemsetAsync(c->d_dbits, 0, DBITS_WORDS * sizeof(uint32_t), c->stream));
     TRY(prof_end(c));
     if (iter_ms_out && record_event() < 0) return fail(c, BPE_E_HIP, "hipEventRecord failed");
+    // the byte stream and its statistics (iteration 0 of both modes): one pass over the bytes when it can be
+    // (k_load_count), else widen -> chunk starts -> get_stats
+    const bool fused_load = load_count_fusable(c);
+    TRY(start_from_bytes(c, fused_load));
     const uint64_t n0 = c->n;
-    TRY(launch_pair_count(c, false));
+    if (!fused_load) TRY(launch_pair_count(c, false));
 
     int done = 0, rc = BPE_OK;
     uint64_t cur_len = n0;  // exact length after `done` merges

@@ -63,6 +63,7 @@ constexpr int CH_REP = 4;                      // ... this many otherwise (the t
 static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must fit the replica blocks");
 static_assert(CH_KMAX * 32 <= 256, "removal counters: 32 per pair of a batch");
 constexpr uint32_t CH_FULL = 0, CH_LIST = 1;   // DevState::sel_mode
+constexpr int DP_KEY_WORDS = TIE_CAP + 2;      // sharded chain steps: int64 words of the MIN all-reduce (k_chain_sel)
 
 // encode: one chunk per lane, token lists in lane-private LDS columns
 constexpr int ENC_THREADS = 256;
@@ -158,6 +159,7 @@ struct DevState {
     uint32_t badj[CH_KMAX];       // delta format B, per pair of the batch: sites whose right neighbour starts a site of the SAME pair
     uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum: k_chain_sel)
     uint32_t brep;                // delta replicas per pair of this batch (CH_REP or CH_RSTRIDE)
+    uint32_t dp_wait;             // sharded chain steps: k_chain_sel left a tie for k_chain_sel_dp to order (after the MIN all-reduce)
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

@@ -515,7 +515,10 @@ __global__ void __launch_bounds__(256)
 k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
               const uint32_t *__restrict__ rowmax, DevState *st, uint32_t *__restrict__ dbits, int par, IterRec *rec,
               StepRec *srec, uint32_t step, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
-              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums) {
+              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums,
+              const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail) {
+    // folded != nullptr (sharded training): the batch's delta is the all-reduced payload of k_dp_fold_chain -- pair p's
+    // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
     const uint32_t status = st->status, defer = st->defer;
     const uint32_t K = st->bk, z0 = st->bz0;
     const bool noop = status || defer || K == 0;
@@ -538,7 +541,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
         bool flagged = false;
         if (K == 1) {
             // ---- one pair: all nrep replicas, (t,a) loaded up front (no returning atomic) ----------------
-            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0, adj = st->adj;  // (merge_ab_wave's adj)
+            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0;
+            const uint32_t adj = folded ? ftail[0] : st->adj;  // (merge_ab_wave's adj)
             uint32_t x[16][2];
             auto load_batch = [&](uint32_t r0) {
 #pragma unroll
@@ -548,10 +552,14 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                     x[k][1] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
                 }
             };
-            load_batch(0);
+            if (!folded) load_batch(0);
             const uint32_t old_ta = live ? mat[(size_t)t * stride + a] : 0u;
             uint32_t sl = 0, sr = 0;
-            for (uint32_t r0 = 0;;) {
+            if (folded) {
+                sl = live ? folded[t] : 0u;
+                sr = live ? folded[(size_t)fS + t] : 0u;
+            }
+            for (uint32_t r0 = 0; !folded;) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     if (x[k][0]) delta[delta_rep_off(r0 + k, vc) + t] = 0;
@@ -575,7 +583,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             flagged |= live && ((t == a) | (t == b) | (t == Z));
         } else {
             // ---- a batch: brep replicas per pair ------------------------------------------------------------
-            const uint32_t brep = st->brep;
+            const uint32_t brep = folded ? 0u : st->brep;
             uint32_t x[CH_KMAX][CH_REP][2];
             if (brep == (uint32_t)CH_REP) {  // (everything in flight at once)
 #pragma unroll
@@ -591,9 +599,13 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 #pragma unroll
             for (int p = 0; p < CH_KMAX; p++) {
                 if ((uint32_t)p >= K) break;  // (uniform)
-                const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + (uint32_t)p, adj = st->badj[p];
+                const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + (uint32_t)p;
+                const uint32_t adj = folded ? ftail[p] : st->badj[p];
                 uint32_t sl = 0, sr = 0;
-                if (brep == (uint32_t)CH_REP) {
+                if (folded) {
+                    sl = live ? folded[(size_t)(2 * p) * fS + t] : 0u;
+                    sr = live ? folded[(size_t)(2 * p + 1) * fS + t] : 0u;
+                } else if (brep == (uint32_t)CH_REP) {
 #pragma unroll
                     for (int r = 0; r < CH_REP; r++) {
                         const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
@@ -816,7 +828,8 @@ __device__ __forceinline__ uint32_t row_scan_excl(const uint32_t *__restrict__ r
 __global__ void __launch_bounds__(1024)
 k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
             CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-            unsigned long long *__restrict__ req, uint32_t extend, uint32_t kcap) {
+            unsigned long long *__restrict__ req, uint32_t extend, uint32_t kcap, long long *__restrict__ dpkey,
+            unsigned long long dprank) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     __shared__ int32_t s_tied[2 * TIE_CAP];
@@ -833,6 +846,14 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     const uint32_t iter = st->iter, nm = st->num_merges, mode = st->sel_mode;
     const uint32_t vcur = 256u + iter;
     const uint32_t tid = threadIdx.x;
+    // Sharded training (dpkey != nullptr, k_dp.hip): the table, the row maxima and the flag words are replicas of
+    // GLOBAL state, so every rank finds the same maximum and the same tied pairs -- but a pair's first occurrence is
+    // a rank-local fact.  The deciding workgroup leaves the MIN all-reduce payload: [0] = -status, [1] = -1 if this
+    // rank cannot order its share of a tie (short slots about), [2 + i] = rank << 40 | first local position of tied
+    // pair i (pairs in canonical order), INT64_MAX = no occurrence here.  k_chain_sel_dp makes the list from the
+    // reduced words.  Every word is written by the thread of the same number, first with its neutral value.
+    if (dpkey && blockIdx.x == 0 && tid < (uint32_t)DP_KEY_WORDS)
+        dpkey[tid] = tid == 0 ? -(long long)status : (tid == 1 ? 0ll : 0x7FFFFFFFFFFFFFFFll);
     if (status || defer) return;
     if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
         if (blockIdx.x == 0 && tid == 0) st->bk = 0;
@@ -973,6 +994,44 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         return;
     }
     // ---- the list: every tied pair, in order of first occurrence ---------------------------------------
+    if (dpkey && nt > 1 && nt <= TIE_CAP) {
+        // sharded: the tied pairs in canonical order (select_core lists them as its atomics fall), their local first
+        // occurrences into the payload; the list is made by k_chain_sel_dp after the all-reduce
+        uint32_t kx = 0;
+        if (tid < nt) {
+            kx = ((uint32_t)s_tied[2 * tid] << 16) | (uint32_t)s_tied[2 * tid + 1];
+            s_order[tid] = kx;
+        }
+        __syncthreads();
+        if (tid < nt) {
+            uint32_t r = 0;
+            for (uint32_t q = 0; q < nt; q++) r += s_order[q] < kx;
+            s_list[2 * r] = (int32_t)(kx >> 16);
+            s_list[2 * r + 1] = (int32_t)(kx & 0xFFFFu);
+        }
+        __syncthreads();
+        if (tid < 2 * nt) s_tied[tid] = s_list[tid];
+        __syncthreads();
+        const bool objection = gap != 0;
+        if (!objection) (void)tie_by_index(ref, C, s_tied, nt, s_pos);
+        __syncthreads();
+        if (tid == 1 && objection) dpkey[1] = -1ll;
+        if (tid >= 2 && tid - 2 < nt && !objection && s_pos[tid - 2] != NOPOS)
+            dpkey[tid] = (long long)((dprank << 40) | s_pos[tid - 2]);
+        if (tid < 2 * nt) st->chain[tid] = s_tied[tid];
+        if (tid == 0) {
+            st->tl_n = nt;
+            st->tl_M = M;
+            st->tl_skip = 0;
+            st->count = M;
+            st->ntied = nt;
+            st->found = 0;
+            st->bk = 0;
+            st->dp_wait = 1;
+        }
+        dismiss();
+        return;
+    }
     bool ok = nt <= TIE_CAP && (nt == 1 || gap == 0);
     if (ok && nt > 1) {
         (void)tie_by_index(ref, C, s_tied, nt, s_pos);
@@ -985,6 +1044,17 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             uint32_t rank = 0;
             for (uint32_t q = 0; q < nt; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
             s_order[rank] = tid;
+        }
+        // (my share of the row maxima again, for the levels below M: fetched a second time -- 32 loads that hit L2 --
+        // so that 32 registers are free while the tied pairs are located; held across tie_by_index they were spilled
+        // to scratch memory inside its loops)
+        {
+            const uint2 *__restrict__ rowma2 = reinterpret_cast<const uint2 *>(rowmax);
+#pragma unroll
+            for (int i = 0; i < SEL_RPT; i++) {
+                const uint32_t x = tid + 1024u * (uint32_t)i;
+                rm[i] = (x < vcur && !((s_words[x >> 5] >> (x & 31)) & 1u)) ? rowma2[x].x : 0u;
+            }
         }
     } else if (tid == 0) {
         s_order[0] = 0;
@@ -1129,6 +1199,113 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Sharded chain steps (api_dp.hip: dp_train_loop).  Per step: k_chain_sel (dpkey) -> MIN all-reduce ->
+// k_chain_sel_dp -> k_merge_chain -> k_dp_fold_chain -> SUM all-reduce -> k_dp_after_sum -> k_apply_chain (folded).
+// k_chain_sel_dp: the list of a FULL selection that found a tie, from the reduced first occurrences (lowest
+// (rank, local position) = earliest in the global stream, F3 / F5); one workgroup.
+__global__ void __launch_bounds__(128)
+k_chain_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap) {
+    __shared__ int32_t s_list[2 * TIE_CAP];
+    __shared__ uint32_t s_bad;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_bad = 0;
+    const uint32_t status = st->status;
+    if (key[0] < 0 && status == 0) {  // some rank failed: every rank stops at this merge
+        if (tid == 0) st->status = ST_INTERNAL;
+        return;
+    }
+    if (status || st->defer || !st->dp_wait) return;
+    const uint32_t nt = st->tl_n, M = st->tl_M;
+    __syncthreads();
+    const long long me = tid < nt ? key[2 + tid] : 0ll;
+    if (tid < nt && me == 0x7FFFFFFFFFFFFFFFll) s_bad = 1;  // a tied pair that no rank holds: not ours to order
+    __syncthreads();
+    if (key[1] < 0 || s_bad) {  // (some rank has short slots about: the general path decides, on every rank)
+        if (tid == 0) {
+            st->found = 0;
+            st->bk = 0;
+            st->defer = 2;
+            st->dp_wait = 0;
+        }
+        return;
+    }
+    if (tid < nt) {
+        uint32_t r = 0;
+        for (uint32_t q = 0; q < nt; q++) r += key[2 + q] < me;  // (distinct: two pairs never share a first occurrence)
+        s_list[2 * r] = st->chain[2 * tid];
+        s_list[2 * r + 1] = st->chain[2 * tid + 1];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 2 * nt; i += 128) st->chain[i] = s_list[i];  // (up to 192 words, 128 threads)
+    if (tid == 0) {
+        st->dp_wait = 0;
+        chain_form_batch(st, s_list, nt, M, st->iter, st->num_merges, kcap);
+    }
+}
+// k_dp_fold_chain: this rank's delta of the step's batch, folded over its replica blocks into the SUM payload:
+// pair p's SL at folded[2p S ..), its SR at folded[(2p + 1) S ..), S = the payload's vector stride (>= every id in
+// use + 1); tail = folded + 2 kcap S: [p] = format B's adj of pair p, [8] = 1 if this rank's status is raised (the
+// sum tells every rank before the table update: all ranks stop at the same merge).
+__global__ void __launch_bounds__(256)
+k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__restrict__ st, uint32_t *__restrict__ folded,
+                uint32_t S, uint32_t *__restrict__ tail) {
+    const uint32_t status = st->status, K = st->bk, z0 = st->bz0;
+    const bool noop = status || st->defer || K == 0;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < 16) tail[t] = t == 8 ? (status ? 1u : 0u) : ((!noop && t < K) ? (K == 1 ? st->adj : st->badj[t]) : 0u);
+#ifdef BPE_DP_DEBUG
+    if (t >= 16 && t < 64) {  // (debug builds: the step's selection state rides in the payload's padding)
+        uint32_t v = 0;
+        if (t == 16) v = st->iter;
+        else if (t == 17) v = st->sel_mode;
+        else if (t == 18) v = K;
+        else if (t == 19) v = st->tl_n;
+        else if (t == 20) v = st->tl_M;
+        else if (t == 21) v = st->tl_skip;
+        else if (t == 22) v = st->defer;
+        else if (t == 23) v = st->gap;
+        else if (t < 32) v = (uint32_t)st->ba[t - 24] << 16 | (uint32_t)st->bb[t - 24];
+        else v = (uint32_t)st->chain[2 * (t - 32)] << 16 | (uint32_t)st->chain[2 * (t - 32) + 1];
+        tail[t] = v;
+    }
+#endif
+    if (noop || t > z0 + K - 1u || t >= S) return;
+    const uint32_t nrep = 1u << (dl >> 24), vc = dl & 0xFFFFFFu;
+    if (K == 1) {
+        uint32_t sl = 0, sr = 0;
+        for (uint32_t r = 0; r < nrep; r++) {
+            const size_t o = delta_rep_off(r, vc);
+            const uint32_t x = delta[o + t], y = delta[o + vc + t];
+            if (x) delta[o + t] = 0;
+            if (y) delta[o + vc + t] = 0;
+            sl += x;
+            sr += y;
+        }
+        folded[t] = sl;
+        folded[(size_t)S + t] = sr;
+        return;
+    }
+    const uint32_t brep = st->brep;
+    for (uint32_t p = 0; p < K; p++) {
+        uint32_t sl = 0, sr = 0;
+        for (uint32_t r = 0; r < brep; r++) {
+            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + r, vc);
+            const uint32_t x = delta[o + t], y = delta[o + vc + t];
+            if (x) delta[o + t] = 0;
+            if (y) delta[o + vc + t] = 0;
+            sl += x;
+            sr += y;
+        }
+        folded[(size_t)(2 * p) * S + t] = sl;
+        folded[(size_t)(2 * p + 1) * S + t] = sr;
+    }
+}
+// after the SUM all-reduce: some rank's merge pass failed -> nobody applies this step
+__global__ void k_dp_after_sum(DevState *st, const uint32_t *__restrict__ tail) {
+    if (tail[8] != 0 && st->status == 0) st->status = ST_INTERNAL;
+}
+
 // host: entering chain steps after general iterations (the device counts the merges from here on)
 __global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
     st->iter = iter;
@@ -1138,6 +1315,7 @@ __global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
     st->bk = 0;
     st->scan_a = st->scan_b = st->scan_z = NOROW;  // (rows to re-scan are named by the flag words alone)
     st->chain_n = 0;
+    st->dp_wait = 0;
 }
 // host: a deferred chain step is about to be re-run through the general path
 __global__ void k_clear_defer_chain(DevState *st) {
@@ -1146,6 +1324,7 @@ __global__ void k_clear_defer_chain(DevState *st) {
     st->sel_mode = CH_FULL;
     st->tl_n = st->tl_skip = 0;
     st->bk = 0;
+    st->dp_wait = 0;
 }
 
 }  // namespace bpe

@@ -68,8 +68,8 @@ __global__ void k_dp_resolve(DevState *st, const long long *__restrict__ key) {
 // candidate list of a sparse pass is made here instead of inside k_select (one 1024-thread block)
 __global__ void __launch_bounds__(1024)
 k_dp_cand(DevState *st, CandArgs C) {
-    if (st->status || !st->found || st->a == st->b) return;
-    build_cand_list(C, st, (uint32_t)st->a, (uint32_t)st->b);
+    if (st->status || !st->found || (st->a == st->b && !C.aa)) return;
+    build_cand_list(C, st, (uint32_t)st->a, (uint32_t)st->b);  // (a == b: the slots that may hold (a,a) and the slot before each)
 }
 // ... and the fold of its replicated delta vectors (stride / replica count packed in `dl` as for
 // the merge kernels) into the all-reduce payload [4][vcap] + adj (format B fills vectors 0 and 1)
@@ -78,7 +78,12 @@ k_dp_fold2(uint32_t *__restrict__ delta, uint32_t dl, uint32_t Z, uint32_t *__re
            const DevState *__restrict__ st) {
     const uint32_t nrep = 1u << (dl >> 24), ds = dl & 0xFFFFFFu;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) folded[4 * (size_t)vcap] = st->status ? 0u : st->adj;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        folded[4 * (size_t)vcap] = st->status ? 0u : st->adj;
+        // (summed over the ranks: a failure inside any rank's merge pass is known to all before the table update of
+        // this same merge -- k_dp_after_sum, k_chain.hip)
+        folded[4 * (size_t)vcap + 8] = st->status ? 1u : 0u;
+    }
     if (t >= vcap) return;
 #pragma unroll
     for (int v = 0; v < 4; v++) {

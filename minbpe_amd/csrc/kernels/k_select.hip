@@ -93,7 +93,8 @@ __device__ __forceinline__ uint64_t view_tile(const SlotRefH &) { return TILE2; 
 // several columns (ROWARG_MULTI) is scanned.
 // select_core leaves the result in LDS / registers (every thread gets M and the number of tied
 // pairs, TIE_CAP + 1 = too many to list; the pairs are in s_tied); select_body also writes it to st.
-constexpr int SEL_RPT = 32;  // 32 x 1024 row maxima in registers; rows beyond (vocab > 32768) are read twice
+constexpr int SEL_RPT = 20;  // 20 x 1024 row maxima in registers; rows beyond (vocab > 20480) are read twice (L2 hits).  32 left k_chain_sel
+                               // (128 VGPRs at 1024 threads) ten of them in scratch memory, reloaded one by one inside select_core
 // A lean iteration re-scans a few rows in the same launch that selects (k_rowsel_lean, k_lean.hip):
 // those rows are EXCLUDED from the row-maxima array (a bitmap in LDS) and come in as extra
 // (row, maximum, column) items instead.

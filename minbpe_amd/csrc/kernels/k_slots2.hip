@@ -96,15 +96,25 @@ k_slot2_init(SlotHdr *__restrict__ hdr, uint64_t T, DevState *st, int par, uint3
 // empty neighbours; rare); also which slots they come from
 __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hdr, uint32_t t, uint32_t T,
                                                   uint32_t *ctx) {
-    uint32_t h[3] = {INVALID_WORD, INVALID_WORD, INVALID_WORD};
+    // (no indexed local arrays: they would live in scratch memory, and every kernel that inlines this would carry
+    // a private segment for a path that runs once in a blue moon)
+    uint32_t h0 = INVALID_WORD, h1 = INVALID_WORD, h2 = INVALID_WORD;
     uint32_t tn = 0xFFFFFFFFu;  // the next non-empty slot
     int got = 0;
     for (uint32_t u = t + 1; u < T && got < 3; u++) {
         const SlotHdr hh = hdr[u];
         const uint32_t lu = hh.meta & 0x7FFFFFFFu;
-        const uint32_t ww[3] = {hh.w0, hh.w1, hh.w2};
         if (lu && tn == 0xFFFFFFFFu) tn = u;
-        for (uint32_t i = 0; i < lu && i < 3 && got < 3; i++) h[got++] = ww[i];
+#pragma unroll
+        for (uint32_t i = 0; i < 3; i++) {
+            if (i < lu && got < 3) {
+                const uint32_t w = i == 0 ? hh.w0 : (i == 1 ? hh.w1 : hh.w2);
+                if (got == 0) h0 = w;
+                else if (got == 1) h1 = w;
+                else h2 = w;
+                got++;
+            }
+        }
     }
     uint32_t p1 = INVALID_WORD, p2 = INVALID_WORD, tp = 0xFFFFFFFFu;
     got = 0;
@@ -125,9 +135,9 @@ __device__ __forceinline__ void slot_context_walk(const SlotHdr *__restrict__ hd
             got = 2;
         }
     }
-    ctx[0] = h[0];
-    ctx[1] = h[1];
-    ctx[2] = h[2];
+    ctx[0] = h0;
+    ctx[1] = h1;
+    ctx[2] = h2;
     ctx[3] = p2;
     ctx[4] = p1;
     ctx[5] = tp;

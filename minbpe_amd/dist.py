@@ -86,6 +86,18 @@ class TorchComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
 
 
+def torch_allreduce(comm, device):
+    """The `allreduce` callable Engine.dp_train_cb wants, over a TorchComm whose backend reduces CUDA tensors (nccl =
+    RCCL): the library's buffer is aliased as a tensor and reduced on torch's current stream -- which must be the
+    engine's stream (Engine.set_stream), so the collective is ordered with the kernels without a host wait."""
+    import torch
+
+    def allreduce(ptr, count, dtype, op, _stream):
+        t = torch.as_tensor(_DevicePtr(ptr, count, "<i8" if dtype == 1 else "<i4"), device=device)
+        (comm.min_ if op == 1 else comm.sum_)(t)
+    return allreduce
+
+
 class SoloComm:
     """world of one: the protocol without a network (single-GPU test of the dp path)."""
     rank, world = 0, 1
@@ -238,14 +250,23 @@ def train_tokenizer(tok, text, vocab_size, comm=None, verbose=False, make_shard=
                 device_index = torch.cuda.current_device()
             eng = engine(device_index)
             eng.load_bytes(data, offs, wexp)
-            if init_native_comm(eng, comm):
+            # chain steps across the ranks (bpe_dp_train): collectives by the library's own librccl when it can be set
+            # up on every rank, else by torch.distributed through a callback per collective; BPE_DIST=steps keeps the
+            # per-merge protocol (train_sharded), which is also what the CPU shard model of the tests speaks
+            import os
+            if os.environ.get("BPE_DIST", "native") == "steps":
+                res = train_sharded(GpuShard(eng, device_index), comm, num_merges)
+            else:
                 try:
-                    res = eng.dp_train(num_merges)
+                    if os.environ.get("BPE_DIST", "native") == "native" and init_native_comm(eng, comm):
+                        res = eng.dp_train(num_merges)
+                    else:
+                        dev = torch.device("cuda", device_index)
+                        eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                        res = eng.dp_train_cb(num_merges, comm.rank, comm.world, torch_allreduce(comm, dev))
                 except ValueError as e:
                     e.partial = eng.last_train
                     raise
-            else:
-                res = train_sharded(GpuShard(eng, device_index), comm, num_merges)
     except ValueError as e:
         res, failure = getattr(e, "partial", None), e
         if res is None:

@@ -564,6 +564,123 @@ def test_dp_lockstep_ties_and_exhaustion(native):
     assert len(exp[0]) < 400  # the table ran empty: every rank stopped at the same merge
 
 
+def _chain_ranks(native, chunks, nm, world, opts=(), dedup=False):
+    """bpe_dp_train_cb (the sharded loop of chain steps) on `world` ctxs of the one GPU we have, one thread per rank;
+    the all-reduces are done on the host between barriers.  Returns every rank's result dict."""
+    import threading
+    import torch
+    from minbpe_amd.dist import _DevicePtr, shard_chunks
+    dev = torch.device("cuda", 0)
+    engs = []
+    for r in range(world):
+        lo, hi = shard_chunks(len(chunks), r, world)
+        mine = chunks[lo:hi]
+        eng = native.Engine(0)
+        for k, v in opts:
+            eng.set_option(k, v)
+        data = b"".join(mine)
+        offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
+        if dedup:
+            d2, o2, w, _ = native.dedup_chunks(data, offs)
+            eng.load_bytes(d2, o2, w)
+        else:
+            eng.load_bytes(data, offs)
+        engs.append(eng)
+    bar = threading.Barrier(world)
+    slot = [None] * world
+    calls = [0] * world
+
+    def make(r):
+        def allreduce(ptr, count, dtype, op, _stream):
+            calls[r] += 1
+            t = torch.as_tensor(_DevicePtr(ptr, count, "<i8" if dtype == 1 else "<i4"), device=dev)
+            torch.cuda.synchronize()
+            slot[r] = (t.cpu().numpy().copy(), count, dtype, op)
+            bar.wait(timeout=120)
+            assert all(s[1:] == slot[0][1:] for s in slot), [s[1:] for s in slot]  # the same collective on every rank
+            stack = np.stack([s[0] for s in slot])
+            red = stack.sum(0, dtype=stack.dtype) if op == 0 else stack.min(0)
+            bar.wait(timeout=120)
+            t.copy_(torch.from_numpy(red))
+            torch.cuda.synchronize()
+        return allreduce
+
+    out, errs = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            out[r] = engs[r].dp_train_cb(nm, r, world, make(r))
+        except ValueError as e:
+            out[r] = engs[r].last_train
+            errs[r] = e
+        except BaseException as e:  # noqa: BLE001 (reported by the caller; the barrier must not strand the peers)
+            errs[r] = e
+            bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    stats = [e.train_stats() for e in engs]
+    for e in engs:
+        e.close()
+    for e in errs:
+        if e is not None and not isinstance(e, ValueError):
+            raise e
+    assert len(set(calls)) == 1, calls
+    return out, errs, stats
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_dp_chain_steps_match_oracle(native, world):
+    """the sharded loop of chain steps: GPT-like chunks spread over 1, 2 and 3 ranks -> the oracle's merges, counts
+    and (summed) lengths on every rank, most of them done by chain steps"""
+    pytest.importorskip("torch")
+    chunks = _space_chunks(native.synth_text(1_500_000, 51))
+    nm = 600
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, nm, offs)
+    out, errs, stats = _chain_ranks(native, chunks, nm, world)
+    assert not any(errs)
+    for res in out:
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+    assert all(s["steps"] > 0 and s["lean"] > nm // 2 for s in stats), stats
+
+
+@pytest.mark.parametrize("opts", [(), (("dp_kcap", 1),), (("dp_kcap", 8), ("sparse", 2)), (("sparse", 0),)])
+def test_dp_chain_steps_ties_and_exhaustion(native, opts):
+    """three letters, thousands of short chunks on three ranks: nearly every selection is a tie whose pairs first
+    occur on different ranks, a == b pairs head the list again and again, and the table runs empty before the last
+    merge -- every rank stops at the same merge with the oracle's list"""
+    pytest.importorskip("torch")
+    rng = np.random.default_rng(9)
+    chunks = [b" " + bytes(97 + rng.integers(0, 3, size=rng.integers(1, 6))) for _ in range(3000)]
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, 400, offs, raise_on_empty=False)
+    assert len(exp[0]) < 400
+    out, errs, stats = _chain_ranks(native, chunks, 400, 3, opts)
+    assert all(isinstance(e, ValueError) for e in errs)
+    for res in out:
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], opts
+
+
+def test_dp_chain_steps_weighted_shards(native):
+    """every rank de-duplicates its own shard (weights in the id words): same merges as the plain chunk list"""
+    pytest.importorskip("torch")
+    chunks = _space_chunks(native.synth_text(600_000, 53))
+    nm = 300
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, nm, offs)
+    out, errs, _ = _chain_ranks(native, chunks, nm, 2, dedup=True)
+    assert not any(errs)
+    for res in out:
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1]
+
+
 def test_dp_train_sharded_solo(native, engine):
     pytest.importorskip("torch")
     from minbpe_amd.dist import GpuShard, SoloComm, train_sharded
@@ -591,6 +708,48 @@ def test_train_slotted_edge_cases(engine):
         else:
             res = engine.train(nm)
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], (len(data), nm)
+
+
+def test_fused_load_and_count_equals_the_three_passes(engine, native):
+    """k_load_count (bytes -> id words + chunk starts + the first get_stats in one pass, the default) against
+    k_widen + k_mark_starts + k_pair_count_bytes (option fuse_load = 0) and the oracle: stream lengths around the
+    kernel's 49,152-position rounds and its 4-byte groups, chunk starts on round boundaries, empty chunks
+    (repeated offsets), one chunk, no chunk list, a stream that is all chunk starts."""
+    R = 49152
+    rng = random.Random(5)
+    text = native.synth_text(3 * R + 7, 77)
+    cases = []
+    for n in (2, 3, 5, 4095, 4096, R - 1, R, R + 1, 2 * R, 2 * R + 3, 3 * R + 7):
+        data = text[:n]
+        cases.append((data, None))
+        cuts = sorted(set([0] + [rng.randrange(n) for _ in range(max(n // 6, 1))]))
+        cases.append((data, np.array(cuts, dtype=np.uint64)))
+    data = text[:2 * R + 3]
+    cases.append((data, np.array([0, 1, 2, R - 1, R, R, R, R + 1, 2 * R - 1, 2 * R, 2 * R + 2], dtype=np.uint64)))
+    cases.append((data, np.array([0], dtype=np.uint64)))
+    cases.append((data[:5000], np.arange(0, 5000, dtype=np.uint64)))  # every position starts a chunk: no pair at all
+    for data, offs in cases:
+        nm = 12
+        exp = oracle.train(data, nm, offs, raise_on_empty=False)
+        got = []
+        for fuse in (1, 0):
+            engine.set_option("fuse_load", fuse)
+            try:
+                engine.load_bytes(data, offs)
+                if len(exp[0]) < nm:
+                    with pytest.raises(ValueError):
+                        engine.train(nm)
+                    res = engine.last_train
+                else:
+                    res = engine.train(nm)
+                # (the resident stream is compared after a train() that ran to the end)
+                full = len(exp[0]) == nm
+                got.append((res["pairs"], res["counts"], res["lens"], engine.read_ids().tolist() if full else None,
+                            engine.read_chunk_starts().tolist() if full else None))
+            finally:
+                engine.set_option("fuse_load", 1)
+        assert got[0] == got[1], (len(data), None if offs is None else len(offs))
+        assert (got[0][0], got[0][1], got[0][2]) == (exp[0], exp[1], exp[2]), (len(data), None if offs is None else len(offs))
 
 
 def test_train_fused_row_maxima_option(engine, native):
