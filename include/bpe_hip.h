@@ -196,6 +196,15 @@ int bpe_encode_batch(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_i
                      const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
                      uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
                      uint64_t *n_out);
+/* The same with every large buffer already ON THE DEVICE (bytes, chunk_offsets, ids_out with room for n ids, out_offsets
+ * with n_chunks + 1 entries are device pointers; merges / merge_ids stay host arrays): the kernels read the caller's
+ * offsets and write the caller's outputs in place; only the rank table and a few counters cross PCIe.  For callers
+ * that keep their batches in HBM (a data loader on the GPU, torch tensors: tensor.data_ptr()).  Offsets are validated
+ * on the device (ascending, <= n).  Synchronises the ctx's stream before returning. */
+int bpe_encode_batch_resident(bpe_ctx *ctx, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                              const uint8_t *d_bytes, uint64_t n, const uint64_t *d_chunk_offsets,
+                              uint64_t n_chunks, int32_t *d_ids_out, uint64_t *d_out_offsets,
+                              uint64_t *n_out);
 /* Whether bpe_encode_batch's encoder WITHOUT the chunk cache (option enc_cache = 0) keeps tokens and ranks
  * in 16-bit columns for this merge table (host logic, no GPU): every rank below 65535 and every token id
  * -- merge_ids[r], or 256 + r when merge_ids is NULL -- below 65536.  The default (cached) encoder is

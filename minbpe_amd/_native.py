@@ -91,6 +91,7 @@ _SIGS = {
     "bpe_dp_train": (C.c_int, [_p, _i32, _p, _p, _p, C.POINTER(_i32)]),
     "bpe_dp_train_cb": (C.c_int, [_p, _i32, _i32, _i32, C.c_void_p, _p, _p, _p, _p, C.POINTER(_i32)]),
     "bpe_encode_batch": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
+    "bpe_encode_batch_resident": (C.c_int, [_p, _p, _p, _i32, _p, _u64, _p, _u64, _p, _p, C.POINTER(_u64)]),
     "bpe_decode_set_vocab": (C.c_int, [_p, _p, _p, _i32]),
     "bpe_decode_batch": (C.c_int, [_p, _p, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "bpe_decode_read": (C.c_int, [_p, _p, _u64, _p, _u64, _p]),
@@ -455,6 +456,20 @@ class Engine:
         return out[:n_out.value], oo
 
     # -- decoding ----------------------------------------------------------------------
+    def encode_batch_resident(self, pairs, merge_ids, d_bytes: int, n: int, d_offsets: int, n_chunks: int,
+                              d_ids_out: int, d_out_offsets: int) -> int:
+        """encode_batch with the batch and its outputs in HBM: d_bytes (n bytes), d_offsets (n_chunks uint64),
+        d_ids_out (room for n int32), d_out_offsets (n_chunks + 1 uint64) are device addresses (e.g. torch
+        tensor.data_ptr()).  Returns the number of tokens written."""
+        p = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1)
+        mids = None if merge_ids is None else np.ascontiguousarray(merge_ids, dtype=np.int32)
+        total = _u64(0)
+        self._check(_lib.bpe_encode_batch_resident(
+            self._h, _ptr(p) if len(p) else None, None if mids is None else _ptr(mids), len(p) // 2,
+            C.c_void_p(d_bytes), n, C.c_void_p(d_offsets), n_chunks, C.c_void_p(d_ids_out), C.c_void_p(d_out_offsets),
+            C.byref(total)))
+        return int(total.value)
+
     def decode_set_vocab(self, blob: bytes, offsets):
         """Vocab table: entry i = blob[offsets[i]:offsets[i+1]]; stays resident in HBM."""
         buf = np.frombuffer(blob, dtype=np.uint8)

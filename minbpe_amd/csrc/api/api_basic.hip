@@ -152,6 +152,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->lean_select = value != 0;
     } else if (!strcmp(name, "aa_sparse")) {
         c->aa_sparse = value != 0;
+    } else if (!strcmp(name, "dp_force_comm")) {
+        c->dp_force_comm = value != 0;
     } else if (!strcmp(name, "dp_kcap")) {
         if (value < 1 || value > CH_KMAX) return fail(c, BPE_E_ARG, "dp_kcap must be 1..%d", CH_KMAX);
         c->dp_kcap = (int)value;

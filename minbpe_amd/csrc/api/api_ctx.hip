@@ -29,6 +29,7 @@ struct bpe_ctx {
     long long *d_dp_ckey = nullptr;
     uint32_t *d_dp_cfold = nullptr;
     uint64_t cap_dp_cfold = 0;
+    bool dp_force_comm = false;  // option "dp_force_comm": issue the collectives in a world of one too (tests, launch-cost measurements)
     int dp_kcap = CH_KMAX;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
     uint64_t *d_round_lb = nullptr;  // k_load_count: first chunk of every segment of the byte stream
     uint64_t cap_round_lb = 0;
@@ -400,6 +401,7 @@ int prof_drain(bpe_ctx *c) {
 int dp_allreduce(bpe_ctx *c, void *buf, uint64_t count, int32_t dtype, int32_t op) {
     const DpComm *dp = c->dp_comm;
     if (!dp || !dp->fn) return fail(c, BPE_E_STATE, "no communicator");
+    if (dp->nranks == 1 && !c->dp_force_comm) return BPE_OK;  // (a world of one: the buffer is its own reduction)
     const int rc = dp->fn(dp->user, buf, count, dtype, op, (void *)c->stream);
     if (rc != 0) return fail(c, BPE_E_HIP, "all-reduce failed (%d)", rc);
     return BPE_OK;
@@ -1097,6 +1099,9 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     C.tie_window = 0;
     C.aa = 0;
     if (!c->idx_live) C.T = 0;  // (no index: a tie finds none of its pairs through it, and the step defers)
+    // (sharded dense steps: some ranks may hold an index, others not -- a tie ordered by part of the ranks would be
+    // ordered wrongly: nobody orders it, every rank reports "no occurrence" and the general path decides)
+    if (dense && c->dp_comm) C.T = 0;
     (void)records;
     if (!c->d_chain_req) {
         HIPCHK(c, hipMalloc((void **)&c->d_chain_req, 64 * sizeof(unsigned long long)));
@@ -1161,8 +1166,6 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         hipLaunchKernelGGL(k_dp_fold_chain, dim3(na), dim3(256), 0, c->stream, c->d_delta, dl, c->d_st, c->d_dp_cfold, fS, ftail);
         LAUNCHCHK(c, "k_dp_fold_chain");
         TRY(dp_allreduce(c, c->d_dp_cfold, (uint64_t)2 * kcap * fS + 64, BPE_DT_INT32, BPE_OP_SUM));
-        hipLaunchKernelGGL(k_dp_after_sum, dim3(1), dim3(1), 0, c->stream, c->d_st, ftail);
-        LAUNCHCHK(c, "k_dp_after_sum");
     }
     hipLaunchKernelGGL(k_apply_chain, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
                        c->d_st, c->d_dbits, c->par, c->h_rec, c->h_srec, step, na, c->d_hdr2[c->mq], c->d_stage,

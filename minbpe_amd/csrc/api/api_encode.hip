@@ -27,13 +27,25 @@ extern "C" int bpe_encode_uses_16bit(const int32_t *merge_ids, int32_t M) {
     return narrow ? 1 : 0;
 }
 
-extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
-                                const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
-                                uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
-                                uint64_t *n_out) {
+// bpe_encode_batch / bpe_encode_batch_resident.  resident: bytes, chunk_offsets, ids_out and out_offsets are DEVICE
+// pointers (the rank table stays a host array: it is small) -- the kernels read the caller's offsets and write the
+// caller's outputs in place, nothing crosses PCIe but the rank table and a few counters.
+namespace {
+__global__ void k_check_offsets(const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n, unsigned long long *bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_chunks; i += stride)
+        if (off[i] > n || (i && off[i] < off[i - 1])) atomicMin(bad, (unsigned long long)i);
+}
+__global__ void k_store_u64(uint64_t *p, unsigned long long v) { *p = v; }
+int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                      const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                      uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
+                      uint64_t *n_out, bool resident) {
     if (!c || M < 0 || (!merges && M) || (!bytes && n)) return fail(c, BPE_E_ARG, "bad arguments");
     if (n >= (1ull << 32)) return fail(c, BPE_E_LIMIT, "batch of %llu bytes exceeds 2^32-1", (unsigned long long)n);
-    TRY(check_offsets(c, chunk_offsets, n_chunks, n));
+    if (resident && (!chunk_offsets || !ids_out || !out_offsets))
+        return fail(c, BPE_E_ARG, "the resident form needs chunk_offsets, ids_out and out_offsets on the device");
+    if (!resident) TRY(check_offsets(c, chunk_offsets, n_chunks, n));
     static const uint64_t zero = 0;
     if (!chunk_offsets) {
         chunk_offsets = &zero;
@@ -41,11 +53,26 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     }
     if (n_out) *n_out = 0;
     if (n == 0 || n_chunks == 0) {
-        if (out_offsets)
+        if (out_offsets && !resident)
             for (uint64_t i = 0; i <= n_chunks; i++) out_offsets[i] = 0;
+        if (out_offsets && resident) {
+            HIPCHK(c, hipSetDevice(c->device));
+            HIPCHK(c, hipMemsetAsync(out_offsets, 0, (n_chunks + 1) * 8, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         return BPE_OK;
     }
     HIPCHK(c, hipSetDevice(c->device));
+    if (resident) {  // (the host form validates its offsets on the host)
+        HIPCHK(c, hipMemsetAsync(c->d_scratch, 0xFF, 8, c->stream));
+        hipLaunchKernelGGL(k_check_offsets, dim3(grid_for(n_chunks, 256, c->num_cus * 8)), dim3(256), 0, c->stream, chunk_offsets,
+                           n_chunks, n, c->d_scratch);
+        unsigned long long bad = 0;
+        HIPCHK(c, hipMemcpyAsync(&bad, c->d_scratch, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (bad != ~0ull)
+            return fail(c, BPE_E_ARG, "chunk_offsets[%llu]: offsets must ascend and stay <= n = %llu", bad, (unsigned long long)n);
+    }
     // this call reuses the ctx's input and id-stream buffers
     c->have_bytes = false;
     c->weighted = false;
@@ -87,8 +114,10 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
         c->cap_bytes = n + 16;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, hipMemcpyHostToDevice, c->stream));
-    TRY(upload_offsets(c, chunk_offsets, n_chunks));
+    // (the bytes are copied either way: the kernels read up to 16 bytes past the end of the ctx's padded buffer)
+    HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (!resident) TRY(upload_offsets(c, chunk_offsets, n_chunks));
+    const uint64_t *d_offs = resident ? chunk_offsets : c->d_offsets;
     // 3. scratch
     if (n > c->cap_enc_n) {
         TRY(dev_realloc(c, c->d_enc_tmp, (size_t)n));
@@ -106,6 +135,8 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         TRY(dev_realloc(c, c->d_enc_midn, (size_t)((n_chunks + ENC_THREADS - 1) / ENC_THREADS)));
         c->cap_enc_chunks = n_chunks;
     }
+    int32_t *d_out = resident ? ids_out : c->d_enc_out;
+    unsigned long long *d_ooff = resident ? (unsigned long long *)out_offsets : c->d_enc_off;
     // the chunk cache (k_encode.hip): a slot per four chunks, 2^12 .. 2^22 slots of 32 bytes (the distinct
     // chunks of a text are few; what does not fit is encoded on its own); chunk indices are 32-bit there
     const bool cache = c->enc_cache && n_chunks < 0xFFFFFFFFull;
@@ -132,20 +163,20 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
     if (cache) {
         const unsigned long long keep = c->enc_hash_bits ? ((1ull << c->enc_hash_bits) - 1ull) << 20 : ~0ull;
         const uint32_t tmask = (uint32_t)(tslots - 1);
-        hipLaunchKernelGGL(k_enc_pass1, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+        hipLaunchKernelGGL(k_enc_pass1, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
                            c->d_enc_tab, tmask, c->d_enc_rep, keep, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp,
                            c->d_enc_len, c->d_enc_long, d_nlong, c->d_enc_mid, c->d_enc_midn);
-        hipLaunchKernelGGL(k_enc_pass2, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+        hipLaunchKernelGGL(k_enc_pass2, dim3(gch), dim3(ENC_THREADS), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
                            c->d_enc_tab, c->d_enc_rep, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp,
                            c->d_enc_len, c->d_enc_mid, c->d_enc_midn);
     } else if (bpe_encode_uses_16bit(merge_ids, M))  // 16-bit token / rank columns when every id and every rank fits (rank 0xFFFF = "none")
         hipLaunchKernelGGL(k_encode_short<uint16_t>, dim3(gch),
-                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
                            c->d_enc_long, d_nlong);
     else
         hipLaunchKernelGGL(k_encode_short<uint32_t>, dim3(gch),
-                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, c->d_offsets, n_chunks, n,
+                           dim3(ENC_THREADS), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
                            c->d_enc_long, d_nlong);
     LAUNCHCHK(c, "k_encode_short");
@@ -162,7 +193,14 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
         unsigned long long tot = 0;
         for (uint64_t k = 0; k < n_long; k++) {
             const uint64_t ch = ids_l[k];
-            const uint64_t s0 = chunk_offsets[ch], e0 = (ch + 1 < n_chunks) ? chunk_offsets[ch + 1] : n;
+            uint64_t se[2] = {0, n};
+            if (resident) {  // (a handful of chunks: two words each from the caller's device array)
+                HIPCHK(c, hipMemcpy(se, chunk_offsets + ch, (ch + 1 < n_chunks ? 2 : 1) * 8, hipMemcpyDeviceToHost));
+            } else {
+                se[0] = chunk_offsets[ch];
+                if (ch + 1 < n_chunks) se[1] = chunk_offsets[ch + 1];
+            }
+            const uint64_t s0 = se[0], e0 = se[1];
             src[k] = s0;
             dst[k] = tot;
             tot += e0 - s0;
@@ -235,37 +273,58 @@ extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t
             const uint64_t nbp = (n_chunks + ENC_PLACE_TILE - 1) / ENC_PLACE_TILE;
             HIPCHK(c, hipMemsetAsync(c->d_enc_bsum, 0, (nbp + 1) * sizeof(unsigned long long), c->stream));
             HIPCHK(c, hipMemsetAsync(d_min, 0, 4, c->stream));  // (the tile ticket; the long-chunk rounds are over)
-            hipLaunchKernelGGL(k_enc_place_chained, dim3((unsigned)nbp), dim3(256), 0, c->stream, c->d_enc_tmp, c->d_offsets,
-                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, d_min, c->d_enc_off, n_chunks,
-                               c->d_enc_out, d_total);
+            hipLaunchKernelGGL(k_enc_place_chained, dim3((unsigned)nbp), dim3(256), 0, c->stream, c->d_enc_tmp, d_offs,
+                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, d_min, d_ooff, n_chunks,
+                               d_out, d_total);
         } else {
             hipLaunchKernelGGL(k_enc_lens, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_tab, c->d_enc_rep, n_chunks,
                                c->d_enc_len, c->d_enc_bsum);
             hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
-            hipLaunchKernelGGL(k_enc_place, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_tmp, c->d_offsets,
-                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, c->d_enc_off, n_chunks, c->d_enc_out);
+            hipLaunchKernelGGL(k_enc_place, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_tmp, d_offs,
+                               c->d_enc_tab, c->d_enc_rep, c->d_enc_len, c->d_enc_bsum, d_ooff, n_chunks, d_out);
         }
     } else {
         hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
                            c->d_enc_bsum);
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->d_enc_bsum, nb, d_total);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_enc_len, n_chunks,
-                           c->d_enc_bsum, c->d_enc_off);
+                           c->d_enc_bsum, d_ooff);
         hipLaunchKernelGGL(k_encode_place, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, c->stream,
-                           c->d_enc_tmp, c->d_offsets, c->d_enc_len, c->d_enc_off, n_chunks, c->d_enc_out);
+                           c->d_enc_tmp, d_offs, c->d_enc_len, d_ooff, n_chunks, d_out);
     }
     LAUNCHCHK(c, "k_encode_place");
     TRY(prof_end(c));
     unsigned long long total = 0;
     HIPCHK(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (ids_out && total)
-        HIPCHK(c, hipMemcpy(ids_out, c->d_enc_out, total * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out_offsets) {
-        HIPCHK(c, hipMemcpy(out_offsets, c->d_enc_off, n_chunks * 8, hipMemcpyDeviceToHost));
-        out_offsets[n_chunks] = total;
+    if (resident) {
+        hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, c->stream, out_offsets + n_chunks, total);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    } else {
+        if (ids_out && total)
+            HIPCHK(c, hipMemcpy(ids_out, c->d_enc_out, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (out_offsets) {
+            HIPCHK(c, hipMemcpy(out_offsets, c->d_enc_off, n_chunks * 8, hipMemcpyDeviceToHost));
+            out_offsets[n_chunks] = total;
+        }
     }
     if (n_out) *n_out = total;
     TRY(prof_drain(c));
     return BPE_OK;
+}
+}  // namespace
+
+extern "C" int bpe_encode_batch(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                                const uint8_t *bytes, uint64_t n, const uint64_t *chunk_offsets,
+                                uint64_t n_chunks, int32_t *ids_out, uint64_t *out_offsets,
+                                uint64_t *n_out) {
+    return encode_batch_impl(c, merges, merge_ids, M, bytes, n, chunk_offsets, n_chunks, ids_out, out_offsets, n_out, false);
+}
+
+extern "C" int bpe_encode_batch_resident(bpe_ctx *c, const int32_t *merges, const int32_t *merge_ids, int32_t M,
+                                         const uint8_t *d_bytes, uint64_t n, const uint64_t *d_chunk_offsets,
+                                         uint64_t n_chunks, int32_t *d_ids_out, uint64_t *d_out_offsets,
+                                         uint64_t *n_out) {
+    return encode_batch_impl(c, merges, merge_ids, M, d_bytes, n, d_chunk_offsets, n_chunks, d_ids_out, d_out_offsets, n_out,
+                             true);
 }

@@ -222,8 +222,30 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
             // on every rank), outside the stretch a deferral handed to the general path
             const bool want_chain = c->chain && c->lean && c->lean_select && c->tie_index && i > 0 && i >= general_until &&
                                     c->last_count != ~0ull && c->last_count <= (uint64_t)c->lean_count;
+            // dense chain steps before that regime: the early merges, several pairs per sweep over every slot (every
+            // id below LDSD_CAP: the delta through LDS tables), ties left to the general path
+            const int hi_dense = std::min(num_merges, done + (int)q.size() * CH_KDENSE + CH_KDENSE);
+            const bool want_dense = !want_chain && c->chain && c->chain_dense && c->lean && c->lds_delta && i > 0 &&
+                                    i >= general_until && c->last_count != ~0ull && 256 + hi_dense + 1 <= LDSD_CAP;
             const bool known = n_chain_inflight == 0;
-            if (want_chain && (known || in_chain)) {
+            if (want_dense && (known || in_chain)) {
+                c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);
+                const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
+                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE2 * (den - 1)) {
+                    TRY(slots2_leave(c));
+                    TRY(slots2_enter(c));
+                }
+                if (!in_chain) {
+                    TRY(flush_lean_rows(c, c->vcur));
+                    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
+                    LAUNCHCHK(c, "k_set_iter");
+                    in_chain = true;
+                }
+                TRY(launch_chain_step(c, steps, 255u + (uint32_t)hi_dense, false, true, true));
+                q.push_back(Unit{U_CHAIN, -1, steps++, 1, 2});
+                n_chain_inflight++;
+                enqueued = true;
+            } else if (want_chain && (known || in_chain)) {
                 c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);
                 const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
                 if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE2 * (den - 1)) {
@@ -244,7 +266,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
                 q.push_back(Unit{U_CHAIN, -1, steps++, 0, (uint8_t)(sparse ? 1 : 2)});
                 n_chain_inflight++;
                 enqueued = true;
-            } else if (!want_chain && known) {
+            } else if (!want_chain && !want_dense && known) {
                 in_chain = false;
                 const int mq0 = c->mq;
                 TRY(bpe_dp_select(c, i));

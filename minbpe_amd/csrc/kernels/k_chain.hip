@@ -519,7 +519,10 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
               const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail) {
     // folded != nullptr (sharded training): the batch's delta is the all-reduced payload of k_dp_fold_chain -- pair p's
     // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
-    const uint32_t status = st->status, defer = st->defer;
+    // (sharded: ftail[8] = the number of ranks whose status was raised when they folded this step's delta -- a
+    // failure inside any rank's merge pass stops every rank at this same merge)
+    const uint32_t remote = (folded && ftail[8] != 0) ? 1u : 0u;
+    const uint32_t status = st->status ? st->status : (remote ? ST_INTERNAL : 0u), defer = st->defer;
     const uint32_t K = st->bk, z0 = st->bz0;
     const bool noop = status || defer || K == 0;
     if (blockIdx.x < na) {
@@ -706,6 +709,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                 st->sel_mode = CH_FULL;  // (an emptied list, or training is over: select when asked again)
             }
             if (status == 0) st->n[par ^ 1] = nn;  // (a step that merged nothing carries the length forward)
+            if (remote && st->status == 0) st->status = ST_INTERNAL;
             st->removed = 0;
             StepRec *sr = srec + (step % STEP_RING);
             sr->first_iter = iter;
@@ -1201,7 +1205,7 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
 
 // ---------------------------------------------------------------------------
 // Sharded chain steps (api_dp.hip: dp_train_loop).  Per step: k_chain_sel (dpkey) -> MIN all-reduce ->
-// k_chain_sel_dp -> k_merge_chain -> k_dp_fold_chain -> SUM all-reduce -> k_dp_after_sum -> k_apply_chain (folded).
+// k_chain_sel_dp -> k_merge_chain -> k_dp_fold_chain -> SUM all-reduce -> k_apply_chain (folded payload, status word).
 // k_chain_sel_dp: the list of a FULL selection that found a tie, from the reduced first occurrences (lowest
 // (rank, local position) = earliest in the global stream, F3 / F5); one workgroup.
 __global__ void __launch_bounds__(128)
@@ -1301,7 +1305,8 @@ k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__res
         folded[(size_t)(2 * p + 1) * S + t] = sr;
     }
 }
-// after the SUM all-reduce: some rank's merge pass failed -> nobody applies this step
+// general iterations of the sharded loop (bpe_dp_apply): after the SUM all-reduce -- some rank's merge pass failed -> nobody
+// applies this merge (a chain step's table update reads the word itself)
 __global__ void k_dp_after_sum(DevState *st, const uint32_t *__restrict__ tail) {
     if (tail[8] != 0 && st->status == 0) st->status = ST_INTERNAL;
 }

@@ -424,6 +424,41 @@ def test_encode_one_stream_with_a_cl100k_sized_rank_table(engine, native):
     assert int(exp_ids.max()) >= 65536
 
 
+@pytest.mark.parametrize("kind", ["regex", "basic"])
+def test_encode_batch_resident_equals_host_form(engine, native, kind):
+    """bpe_encode_batch_resident (batch and outputs in HBM, the caller's buffers used in place) against bpe_encode_batch
+    and the oracle: short chunks, chunks beyond 32 bytes (the stream-wide rounds read their offsets back), one stream;
+    bad offsets are refused by the device-side check"""
+    torch = pytest.importorskip("torch")
+    pairs = _train_pairs(native, 300_000, 400, 33, kind)
+    text = native.synth_text(700_000, 34) + b" " + b"x" * 200 + b" " + bytes(range(97, 123)) * 9 + b" tail"
+    if kind == "regex":
+        data, offs = split_chunks(text.decode())
+    else:
+        data, offs = text, np.zeros(1, np.uint64)
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    assert np.array_equal(ids, exp_ids) and np.array_equal(out_off, exp_off)
+    dev = torch.device("cuda", 0)
+    d_bytes = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_ids = torch.full((len(data),), -1, dtype=torch.int32, device=dev)
+    d_ooff = torch.full((len(offs) + 1,), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    total = engine.encode_batch_resident(np.array(pairs, np.int32), None, d_bytes.data_ptr(), len(data), d_offs.data_ptr(),
+                                         len(offs), d_ids.data_ptr(), d_ooff.data_ptr())
+    assert total == len(exp_ids)
+    assert np.array_equal(d_ids[:total].cpu().numpy(), exp_ids)
+    assert np.array_equal(d_ooff.cpu().numpy().astype(np.uint64), exp_off)
+    if kind == "regex":
+        bad = d_offs.clone()
+        bad[5] = bad[7]  # (no longer ascending at 6)
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="ascend"):
+            engine.encode_batch_resident(np.array(pairs, np.int32), None, d_bytes.data_ptr(), len(data), bad.data_ptr(),
+                                         len(offs), d_ids.data_ptr(), d_ooff.data_ptr())
+
+
 def test_encode_batch_long_and_short_chunks_mixed(engine, native):
     # chunk lengths around ENC_LMAX (32) and far beyond it, runs of one symbol, empty batch
     pairs = _train_pairs(native, 200_000, 500, 23, "regex")
@@ -632,6 +667,24 @@ def _chain_ranks(native, chunks, nm, world, opts=(), dedup=False):
     return out, errs, stats
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_dp_dense_chain_steps_match_oracle(native, world):
+    """the sharded loop's DENSE chain steps (the early merges of a big corpus: several pairs per sweep over every slot,
+    ties left to the general path), forced onto a small corpus by a low lean_count; the switch to the indexed steps
+    happens mid-run"""
+    pytest.importorskip("torch")
+    chunks = _space_chunks(native.synth_text(1_200_000, 57))
+    nm = 500
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = oracle.train(data, nm, offs)
+    out, errs, stats = _chain_ranks(native, chunks, nm, world, (("lean_count", 1500),))
+    assert not any(errs)
+    for res in out:
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+    assert all(s["dense"] > 20 and s["sparse"] > 20 for s in stats), stats
+
+
 @pytest.mark.parametrize("world", [1, 2, 3])
 def test_dp_chain_steps_match_oracle(native, world):
     """the sharded loop of chain steps: GPT-like chunks spread over 1, 2 and 3 ranks -> the oracle's merges, counts
@@ -713,13 +766,13 @@ def test_train_slotted_edge_cases(engine):
 def test_fused_load_and_count_equals_the_three_passes(engine, native):
     """k_load_count (bytes -> id words + chunk starts + the first get_stats in one pass, the default) against
     k_widen + k_mark_starts + k_pair_count_bytes (option fuse_load = 0) and the oracle: stream lengths around the
-    kernel's 49,152-position rounds and its 4-byte groups, chunk starts on round boundaries, empty chunks
+    kernel's 4,096-position segments and its 4-byte groups, chunk starts on segment boundaries, empty chunks
     (repeated offsets), one chunk, no chunk list, a stream that is all chunk starts."""
-    R = 49152
+    R = 4096
     rng = random.Random(5)
-    text = native.synth_text(3 * R + 7, 77)
+    text = native.synth_text(40 * R + 7, 77)
     cases = []
-    for n in (2, 3, 5, 4095, 4096, R - 1, R, R + 1, 2 * R, 2 * R + 3, 3 * R + 7):
+    for n in (2, 3, 5, 255, 256, 257, R - 1, R, R + 1, 2 * R, 2 * R + 3, 16 * R - 1, 16 * R, 16 * R + 2, 40 * R + 7):
         data = text[:n]
         cases.append((data, None))
         cuts = sorted(set([0] + [rng.randrange(n) for _ in range(max(n // 6, 1))]))
@@ -729,6 +782,17 @@ def test_fused_load_and_count_equals_the_three_passes(engine, native):
     cases.append((data, np.array([0], dtype=np.uint64)))
     cases.append((data[:5000], np.arange(0, 5000, dtype=np.uint64)))  # every position starts a chunk: no pair at all
     for data, offs in cases:
+        # the stream the pass leaves (train(0) merges nothing): the bytes as ids, a chunk start wherever an offset points
+        want_starts = sorted(set(int(o) for o in (offs if offs is not None else [0]) if o < len(data)))
+        for fuse in (1, 0):
+            engine.set_option("fuse_load", fuse)
+            try:
+                engine.load_bytes(data, offs)
+                engine.train(0)
+                assert engine.read_ids().tolist() == list(data), (len(data), fuse)
+                assert engine.read_chunk_starts().tolist() == want_starts, (len(data), fuse)
+            finally:
+                engine.set_option("fuse_load", 1)
         nm = 12
         exp = oracle.train(data, nm, offs, raise_on_empty=False)
         got = []
@@ -793,8 +857,13 @@ def test_dp_native_rccl_solo(native):
         exp = oracle.train(data, 250, offs)
         eng.load_bytes(data, offs)
         eng.comm_init(0, 1, native.Engine.comm_unique_id())
+        eng.set_option("dp_force_comm", 1)  # (a world of one skips its collectives unless told otherwise)
         res = eng.dp_train(250)
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+        eng.set_option("dp_force_comm", 0)
+        res = eng.dp_train(250)
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+        eng.set_option("dp_force_comm", 1)
         # exhaustion through the same path
         eng.load_bytes(b"ab", None)
         with pytest.raises(ValueError):
