@@ -246,8 +246,9 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
     # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the
     # committed rocprofv3 --pmc passes of this same command, and only if they were measured on the
     # same library sources (hash below).
-    whole = {"device_ms_per_iteration": None, "traffic": None, "frac": None}
+    whole = {"device_ms_per_train": None, "device_ms_per_iteration": None, "traffic": None, "frac": None}
     dev_ms = sum(v["ms"] for v in breakdown.values())
+    whole["device_ms_per_train"] = round(dev_ms, 3)
     whole["device_ms_per_iteration"] = round(dev_ms / num_merges, 5)
     pmc_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}_pmc.json")
     if os.path.exists(pmc_file):
@@ -261,10 +262,13 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
                 roofline["traffic_source"] = src
                 roofline["achieved"] = round(per / avg_launch_s / 1e9, 1)
                 roofline["frac"] = round(per / avg_launch_s / 1e9 / HBM_PEAK_GBPS, 4)
-            if pmc.get("all_kernels_hbm_bytes_per_iteration"):
-                per_it = pmc["all_kernels_hbm_bytes_per_iteration"]
-                whole["traffic"] = int(per_it)
-                whole["frac"] = round(per_it / (dev_ms / num_merges * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            if pmc.get("all_kernels_hbm_bytes_total") and pmc.get("trains"):
+                # per TRAIN on both sides (the profile's per-launch figure is per unit of the loop -- a chain step does
+                # several merges -- and must not be set against a per-merge time)
+                per_train = pmc["all_kernels_hbm_bytes_total"] / pmc["trains"]
+                whole["traffic_per_train"] = int(per_train)
+                whole["traffic"] = int(per_train / num_merges)
+                whole["frac"] = round(per_train / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
                 whole["traffic_source"] = src
         else:
             roofline["traffic_source"] = "committed PMC profile is from other library sources: not attached"

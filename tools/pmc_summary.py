@@ -62,7 +62,7 @@ def main():
         "merges": trains * merges_per_train if merges_per_train else None,
         "hbm_bytes_total": total, "hbm_bytes_per_launch": total / units if units else None,
         "all_kernels_hbm_bytes_total": total_all,
-        "all_kernels_hbm_bytes_per_iteration": total_all / units if units else None,
+        "all_kernels_hbm_bytes_per_launch": total_all / units if units else None,
         "merge_kernels": merge,
         "check_on_the_first_pass": {**first, "expected": "k_load_count: reads n input bytes + 8 B per chunk, writes 4n "
                                     "(k_widen: reads n, writes 4n)", "n_input_bytes": n_in},
