@@ -130,24 +130,29 @@ extern "C" int bpe_dedup_chunks(const uint8_t *bytes, uint64_t n, const uint64_t
     if ((!bytes && n) || (!chunk_offsets && n_chunks) || !out_offsets || !out_weight_exp || (!out_bytes && n))
         return BPE_E_ARG;
     if (n_chunks >= (1ull << 32)) return BPE_E_LIMIT;  // multiplicities must fit the 32 weight exponents
-    for (uint64_t c = 0; c < n_chunks; c++) {
-        const uint64_t b = chunk_offsets[c], e = c + 1 < n_chunks ? chunk_offsets[c + 1] : n;
-        if (b > e || e > n) return BPE_E_ARG;  // offsets must ascend and stay inside the text
-    }
-    if (threads < 1) {  // one per million chunks, at most 32
+    if (threads < 1) {  // one per million chunks, at most 64
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n_chunks >> 20));
+        threads = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(64u, hw), n_chunks >> 20));
     }
     if (n_chunks < (1u << 16)) threads = 1;
     const Span sp{bytes, chunk_offsets, n, n_chunks};
     const unsigned T = (unsigned)threads;
 
     // 1. one table per contiguous range of chunks
+    //    (every range first checks its own offsets: they must ascend and stay inside the text)
     std::vector<Table> local(T);
+    std::vector<uint8_t> bad(T, 0);
     auto count_range = [&](unsigned t) {
         Table &tb = local[t];
         tb.init(&sp, 1 << 14);
         const uint64_t c0 = n_chunks * t / T, c1 = n_chunks * (t + 1) / T;
+        for (uint64_t c = c0; c < c1; c++) {
+            const uint64_t b = sp.begin(c), e = sp.end(c);
+            if (b > e || e > n) {
+                bad[t] = 1;
+                return;
+            }
+        }
         for (uint64_t c = c0; c < c1; c++) {
             const uint64_t b = sp.begin(c), len = sp.end(c) - b;
             tb.add(key_of(bytes + b, len), len, bytes + b, c, 1);
@@ -160,6 +165,8 @@ extern "C" int bpe_dedup_chunks(const uint8_t *bytes, uint64_t n, const uint64_t
         for (unsigned t = 0; t < T; t++) th.emplace_back(count_range, t);
         for (auto &x : th) x.join();
     }
+    for (unsigned t = 0; t < T; t++)
+        if (bad[t]) return BPE_E_ARG;
     // 2. merge in range order: the first range that holds a chunk has its first appearance
     Table *all = &local[0];
     for (unsigned t = 1; t < T; t++)

@@ -69,7 +69,7 @@ def _texts(native):
     yield "solo"
 
 
-@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("threads", [1, 3, 64])
 def test_dedup_matches_counter(native, threads):
     for text in _texts(native):
         data, offs = split_chunks(text)
@@ -95,6 +95,18 @@ def test_dedup_edge_cases(native):
     assert chunks_of(d2, o2) == [b"", b"ab"] and w.tolist() == [1, 1] and nd == 2
     with pytest.raises(RuntimeError):
         native.dedup_chunks(b"abc", np.array([2, 1], np.uint64))
+    # offsets are checked by the thread that counts their range: a descent (or an overrun) far into a long list
+    n = 200_000
+    data = bytes(n)
+    for t in (1, 8):
+        bad = np.arange(n, dtype=np.uint64)
+        bad[150_000] = 10
+        with pytest.raises(RuntimeError):
+            native.dedup_chunks(data, bad, t)
+        bad = np.arange(n, dtype=np.uint64)
+        bad[-1] = n + 5
+        with pytest.raises(RuntimeError):
+            native.dedup_chunks(data, bad, t)
 
 
 def test_weighted_distinct_chunks_train_like_the_full_list(native):

@@ -83,9 +83,12 @@ def test_longer_mixed_text_and_threads(native):
     data = text.encode()
     for which in (2, 4):  # segment-parallel scan gives the same offsets
         assert np.array_equal(native.split_offsets(data, which, 1), native.split_offsets(data, which, 5))
-    big = native.synth_text(6_000_000, 14)
+    big = native.synth_text(7_000_000, 14)
     for which in (2, 4):
-        assert np.array_equal(native.split_offsets(big, which, 1), native.split_offsets(big, which, 7))
+        one = native.split_offsets(big, which, 1)
+        assert np.array_equal(one, native.split_offsets(big, which, 7))
+        # more segments than cores, every sink copied out by its own thread (over 2^20 offsets)
+        assert len(one) > (1 << 20) and np.array_equal(one, native.split_offsets(big, which, 64))
 
 
 def test_tokenizer_chunking_matches_regex_path(native):

@@ -30,7 +30,7 @@ for x in $EXTRA; do
 case $x in
 dp1) BENCH_FORCE_DP=1 timeout -k 5 200 python bench.py --steps 2 --warmup 1 --secondary none --cpu-iters 0 > gpurun_out/${TAG}_bench_dp1_world1.json 2> gpurun_out/${TAG}_bench_dp1.err
      el "dp1 rc=$?"; cut -c1-400 gpurun_out/${TAG}_bench_dp1_world1.json ;;
-iter) timeout -k 5 200 python tools/iter_profile.py regex1g > gpurun_out/${TAG}_regex1g_iter_profile.json 2> gpurun_out/${TAG}_iter.err; el "iter rc=$?" ;;
+iter) ITER_NPY=gpurun_out/${TAG}_regex1g_iter_us.npy timeout -k 5 200 python tools/iter_profile.py regex1g > gpurun_out/${TAG}_regex1g_iter_profile.json 2> gpurun_out/${TAG}_iter.err; el "iter rc=$?" ;;
 esac
 done
 el "done"

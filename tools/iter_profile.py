@@ -32,6 +32,8 @@ bd = eng.prof_read()
 eng.set_option("profile", 0)
 res = eng.train(nm, want_iter_ms=True)
 ms = res["iter_ms"] * 1e3
+if os.environ.get("ITER_NPY"):  # per-merge device time in full (float32 us): equal neighbours = one chain step's merges
+    np.save(os.environ["ITER_NPY"], ms.astype(np.float32))
 cnt = np.array(res["counts"])
 lens = np.array(res["lens"])
 same = np.array([a == b for a, b in res["pairs"]])
