@@ -55,14 +55,19 @@ WORKLOADS = {
 }
 
 
+HOST_ONLY_SOURCES = ("synth.cpp", "split.cpp", "dedup.cpp", "unicode_tables.h")
+
+
 def source_hash():
-    """sha256 over the device/host sources of libbpe_hip.so: identifies the kernels a
-    committed PMC profile was measured on."""
+    """sha256 over the sources that make the kernels and their launches (every .hip / .h / .cpp under minbpe_amd/csrc
+    except the host-only translation units: the text generator, the pre-split scanner with its tables, the chunk
+    de-duplication -- no device code, nothing a kernel's counters depend on): identifies the kernels a committed PMC
+    profile was measured on."""
     h = hashlib.sha256()
     base = os.path.join(ROOT, "minbpe_amd", "csrc")
     for d, _, files in sorted(os.walk(base)):
         for f in sorted(files):
-            if f.endswith((".hip", ".h", ".cpp")):
+            if f.endswith((".hip", ".h", ".cpp")) and f not in HOST_ONLY_SOURCES:
                 with open(os.path.join(d, f), "rb") as fh:
                     h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]

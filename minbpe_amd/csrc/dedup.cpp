@@ -12,8 +12,8 @@
 // Host side and exact.  Each thread counts a contiguous range of chunks in its own
 // open-addressing table (32-byte entries: one cache line per probe; a chunk of up to 8
 // bytes IS its key, longer ones are hashed and confirmed with memcmp), the per-thread
-// tables are merged in range order (so "first" stays the first appearance), and the result
-// is sorted by first appearance.
+// tables are merged pairwise, the later range into the earlier one (so "first" stays the
+// first appearance), and the result is sorted by first appearance.
 #include <stdint.h>
 #include <string.h>
 
@@ -167,11 +167,21 @@ extern "C" int bpe_dedup_chunks(const uint8_t *bytes, uint64_t n, const uint64_t
     }
     for (unsigned t = 0; t < T; t++)
         if (bad[t]) return BPE_E_ARG;
-    // 2. merge in range order: the first range that holds a chunk has its first appearance
+    // 2. merge, always the later range INTO the earlier one (the earlier range's first appearance stands), as a tree:
+    //    round r folds table t + 2^r into table t for every t that is a multiple of 2^(r+1), all folds of a round at
+    //    once -- log2(T) rounds of one table's worth of inserts each instead of T tables through one thread (with 64
+    //    ranges of a text whose distinct chunks number 10^5 the serial merge was most of the pass)
+    auto fold = [&](unsigned dst, unsigned src) {
+        for (const Entry &e : local[src].slot)
+            if (e.count) local[dst].add(e.key, e.len, bytes + sp.begin(e.first), e.first, e.count);
+        std::vector<Entry>().swap(local[src].slot);
+    };
+    for (unsigned step = 1; step < T; step <<= 1) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t + step < T; t += 2 * step) th.emplace_back(fold, t, t + step);
+        for (auto &x : th) x.join();
+    }
     Table *all = &local[0];
-    for (unsigned t = 1; t < T; t++)
-        for (const Entry &e : local[t].slot)
-            if (e.count) all->add(e.key, e.len, bytes + sp.begin(e.first), e.first, e.count);
     // 3. distinct chunks by first appearance, one copy per set bit of the multiplicity
     std::vector<std::pair<uint64_t, uint64_t>> order;  // (first, count)
     order.reserve(all->used);

@@ -23,6 +23,10 @@ if [ -z "$SKIP_ENC_PMC" ]; then
 SKIP_KT=1 TAG=$TAG bash tools/gpu_pmc.sh encode > gpurun_out/${TAG}_pmc_encode.log 2>&1; el "pmc encode done"; tail -4 gpurun_out/${TAG}_pmc_encode.log | cut -c1-200
 cp gpurun_out/${TAG}_encode_pmc.json profiles/ 2>/dev/null
 fi
+for wl in $PMC_EXTRA; do   # secondary workloads' PMC passes (cfg2, basic1g): attached to their secondary entries
+    SKIP_KT=1 TAG=$TAG bash tools/gpu_pmc.sh $wl > gpurun_out/${TAG}_pmc_$wl.log 2>&1; el "pmc $wl done"; tail -3 gpurun_out/${TAG}_pmc_$wl.log | cut -c1-200
+    cp gpurun_out/${TAG}_${wl}_pmc.json profiles/ 2>/dev/null
+done
 fi
 timeout -k 5 ${BENCH_TIMEOUT:-420} python bench.py ${BENCH_ARGS} > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 el "bench rc=$?"; cut -c1-700 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err
@@ -30,6 +34,8 @@ for x in $EXTRA; do
 case $x in
 dp1) BENCH_FORCE_DP=1 timeout -k 5 200 python bench.py --steps 2 --warmup 1 --secondary none --cpu-iters 0 > gpurun_out/${TAG}_bench_dp1_world1.json 2> gpurun_out/${TAG}_bench_dp1.err
      el "dp1 rc=$?"; cut -c1-400 gpurun_out/${TAG}_bench_dp1_world1.json ;;
+big)  timeout -k 5 300 python bench.py --bytes 3900000000 --steps 1 --warmup 0 --secondary none --cpu-iters 0 > gpurun_out/${TAG}_big_3p9gb_bench.json 2> gpurun_out/${TAG}_big.err
+      el "big rc=$?"; cut -c1-400 gpurun_out/${TAG}_big_3p9gb_bench.json; tail -2 gpurun_out/${TAG}_big.err ;;
 iter) ITER_NPY=gpurun_out/${TAG}_regex1g_iter_us.npy timeout -k 5 200 python tools/iter_profile.py regex1g > gpurun_out/${TAG}_regex1g_iter_profile.json 2> gpurun_out/${TAG}_iter.err; el "iter rc=$?" ;;
 esac
 done
