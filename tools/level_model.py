@@ -8,12 +8,13 @@ against the oracle's sequence, and at every step boundary evaluates three batch 
 
   engine   what k_chain_sel does today: the pairs tied at the maximum in order (prefix without a shared token, a != b),
            then, if the whole list was taken, the levels below while each has exactly ONE pair (no shared token)
-  tied     the same, but a level with SEVERAL pairs may be entered when no pair created by the batch so far can reach it:
-           every count(L, a_j) and count(b_j, R) of the batch's pairs (other than batch pairs themselves) is below the
-           level -- the created pairs (L, Z_j), (Z_j, R) inherit at most those counts -- and the level's own pairs are taken
-           in the reference's order (known here from the sequence; on the device: the index-based tie-break) while they
-           share no token with the batch
-  free     any consecutive token-disjoint merges (tools/batch_model.py "any_level"): the bound
+  tied     the same, but a level with SEVERAL pairs may be entered when a conservative bound holds: every count(L, a_j)
+           and count(b_j, R) of the batch's pairs is below the level (what one would check with row / column maxima)
+  free     no bound at all: walk the levels from the top, inside a level the pairs in the reference's order (known here
+           from the sequence; on the device: the index-based tie-break), stop at the first pair that shares a token with
+           the batch or has a == b.  This IS exact -- a created pair reaches a level only by taking over, in place, a
+           pair of that level that shares a token with the batch, where the walk stops anyway: tests/test_level_model.py
+           pins it against the reference semantics -- so "free" is the rule to build, "tied" a weaker form of it
 
     python tools/level_model.py seq.json [cap ...] > profiles/r4_level_model.json     (seq.json: tools/batch_model.py --make)
 """
