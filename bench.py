@@ -234,7 +234,9 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode):
         "bound": "hbm",
         "kernel": {"merge": "merge pass = k_merge_chain | k_merge_chain_dense | k_merge_chain_dense1 (a chain step: 1..8 "
                             "merges + their pair-table deltas in one sweep) | k_merge_ab_* + k_merge_aa (a general iteration)",
-                   "pair_count": "k_load_count (bytes -> ids + chunk starts + pair counts)", "widen": "k_widen"}[hot],
+                   "pair_count": ("get_stats of every iteration: k_load_count (the first, on bytes) then the general histogram "
+                                  "k_pair_count_h32 / k_pair_count_lds (recount mode)" if mode == 0 else
+                                  "k_load_count (bytes -> ids + chunk starts + pair counts)"), "widen": "k_widen"}[hot],
         "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None,
         "traffic": None, "traffic_source": None,
         "launches": hp["launches"], "avg_launch_ms": round(avg_launch_s * 1e3, 5),
