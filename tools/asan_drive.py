@@ -20,7 +20,7 @@ for L in (1, 2, 3, 5, 64, 4096):
 cases += [np.frombuffer(s, np.uint8) for s in [b"'", b"a'", b"'l", b"'\xc5", b"\xf0\x9f", b" \n \n  ", b"\xe2\x80", b"12345678901", b"x" * 100 + b"'"]]
 for buf in cases:
     for which in (2, 4):
-        for T in (1, 3):
+        for T in (1, 3, 16):
             offs = split(buf, which, T)
             # docs at arbitrary cut points
             cuts = sorted(set([0] + [rng.randrange(len(buf) + 1) for _ in range(5)])) if len(buf) else [0]
