@@ -10,6 +10,10 @@ against the oracle's sequence, and at every step boundary evaluates three batch 
            then, if the whole list was taken, the levels below while each has exactly ONE pair (no shared token)
   tied     the same, but a level with SEVERAL pairs may be entered when a conservative bound holds: every count(L, a_j)
            and count(b_j, R) of the batch's pairs is below the level (what one would check with row / column maxima)
+  engine+list, free+list   the same two rules with the engine's two kinds of step: only a FULL step walks below its list's
+           level; a step that leaves pairs of a level behind is followed by LIST steps that take what is left of that list
+           and go no further (the engine: 8,401 steps, 4,799 of them FULL; the branch with the walk into tied levels: 7,177 /
+           3,144)
   free     no bound at all: walk the levels from the top, inside a level the pairs in the reference's order (known here
            from the sequence; on the device: the index-based tie-break), stop at the first pair that shares a token with
            the batch or has a == b.  This IS exact -- a created pair reaches a level only by taking over, in place, a
@@ -122,8 +126,10 @@ def main():
             t.add((x, y), w, ci)
     print(f"table built: {len(t.cnt)} pairs, {time.time() - t0:.0f} s", file=sys.stderr)
 
-    def batch_at(i, cap, rule):
-        """number of merges a step starting at merge i takes under `rule` (the table is in the state before merge i)"""
+    def batch_at(i, cap, rule, list_level=None):
+        """number of merges a step starting at merge i takes under `rule` (the table is in the state before merge i);
+        list_level: the step is a LIST step -- it takes its pairs off the list of the pairs at that count and goes no
+        further (rules ending in "+list" model the engine's two kinds of step; the others let every step walk on)"""
         a, b = pairs[i]
         if a == b:
             return 1
@@ -138,6 +144,8 @@ def main():
             if x == y or x in used or y in used or c != counts[j]:  # (c != counts[j]: a pair the batch creates or changes)
                 break
             if c < level:  # a level below
+                if list_level is not None:
+                    break
                 if rule == "free":
                     pass
                 else:
@@ -172,15 +180,24 @@ def main():
             j += 1
         return len(batch)
 
-    rules = ("engine", "tied", "free")
-    res = {f"{r}_cap{cap}": {"steps": 0, "next": 0, "by_phase": {}} for r in rules for cap in caps}
+    rules = ("engine", "tied", "free", "engine+list", "free+list")
+    res = {f"{r}_cap{cap}": {"steps": 0, "next": 0, "by_phase": {}, "list": None, "full": 0} for r in rules for cap in caps}
     edges = [0, 300, 1000, 2000, 4000, 8000, 16000, 24000, M]
     for i in range(M):
         a, b = pairs[i]
         for key, st in res.items():
             if st["next"] == i:
                 r, cap = key.split("_cap")
-                k = batch_at(i, int(cap), r)
+                if r.endswith("+list"):
+                    # the engine's two kinds of step: a FULL step walks (rule), a LIST step only takes what is left of the
+                    # list = the pairs at the count of the last pair the previous step took, while any are left
+                    lv = st["list"] if (st["list"] is not None and t.cnt.get(pairs[i], 0) == st["list"]) else None
+                    k = batch_at(i, int(cap), r[:-5], lv)
+                    st["full"] += lv is None
+                    last = counts[i + k - 1]
+                    st["list"] = last if (i + k < M and counts[i + k] == last and pairs[i][0] != pairs[i][1]) else None
+                else:
+                    k = batch_at(i, int(cap), r)
                 st["steps"] += 1
                 st["next"] = i + k
                 ph = max(e for e in edges[:-1] if e <= i)
@@ -196,6 +213,7 @@ def main():
         if i % 2000 == 0:
             print(f"merge {i}: {time.time() - t0:.0f} s, " + ", ".join(f"{k} {v['steps']}" for k, v in res.items()), file=sys.stderr)
     out = {"merges": M, "rules": __doc__.split("\n\n")[2], "result": {k: {"steps": v["steps"], "merges_per_step": round(M / v["steps"], 2),
+                                                                          **({"full_steps": v["full"]} if k.split("_cap")[0].endswith("+list") else {}),
                                                                           "steps_by_first_merge_of_phase": v["by_phase"]} for k, v in res.items()}}
     print(json.dumps(out, indent=1))
 
