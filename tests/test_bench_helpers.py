@@ -1,6 +1,8 @@
 """CPU: the pure helpers bench.py builds its line from -- the full-length invariants, the comparison
 with committed oracle digests, the library source hash that gates the PMC traffic file."""
 import json
+
+import pytest
 import os
 import sys
 
@@ -56,6 +58,30 @@ def test_pmc_profile_is_tied_to_library_sources():
     cal = pmc["calibration_k_widen"]  # reads n bytes, writes 4n: the x2 fetch correction holds
     n = cal["n_input_bytes"] * cal["calls"]
     assert abs(cal["fetch_bytes_x2"] / n - 1.0) < 0.02 and abs(cal["write_bytes"] / (4 * n) - 1.0) < 0.03
+
+
+def test_round4_pmc_profile_matches_the_sources_and_its_own_check():
+    """The committed round-4 profile is of the library sources in the tree (so bench.py attaches it), the hash leaves
+    the host-only translation units out, and the profile's self-check holds: k_load_count reads n + 8 B per chunk and
+    writes 4n bytes per train (32 B x the size-weighted request counters; profiles/r4_pmc_calibration.json)."""
+    csrc = os.path.join(ROOT, "minbpe_amd", "csrc")
+    for f in bench.HOST_ONLY_SOURCES:
+        assert os.path.exists(os.path.join(csrc, f)), f
+    with open(os.path.join(ROOT, "profiles", "r4_regex1g_pmc.json")) as f:
+        pmc = json.load(f)
+    if pmc["source_hash"] != bench.source_hash():  # (mid-development: bench.py then prints the algorithmic figure, labelled)
+        pytest.skip("device sources changed after the committed PMC pass: tools/gpu_final.sh makes a new one")
+    assert pmc["trains"] == 3 and pmc["merges"] == 3 * 31744 and pmc["launches"] > 0
+    first = pmc["check_on_the_first_pass"]
+    n, chunks = first["n_input_bytes"] * first["calls"], 170_679_779 * first["calls"]
+    assert abs(first["read_bytes"] / (n + 8 * chunks) - 1.0) < 0.03
+    assert abs(first["write_bytes"] / (4 * n) - 1.0) < 0.01
+    # per train on both sides (round 3's line set per-launch bytes against per-merge time)
+    per_train = pmc["all_kernels_hbm_bytes_total"] / pmc["trains"]
+    assert 1.5e12 < per_train < 3e12
+    for name in ("r4_cfg2_pmc.json", "r4_encode_pmc.json"):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            assert json.load(f)["source_hash"] == bench.source_hash(), name
 
 
 def test_workloads_name_the_baseline_configs():
