@@ -14,6 +14,8 @@ against the oracle's sequence, and at every step boundary evaluates three batch 
            level; a step that leaves pairs of a level behind is followed by LIST steps that take what is left of that list
            and go no further (the engine: 8,401 steps, 4,799 of them FULL; the branch with the walk into tied levels: 7,177 /
            3,144)
+  free1    "free" with at most ONE tied level per step (the walk ends with the first level of several pairs it enters: the
+           first form of the branch's k_chain_sel)
   free     no bound at all: walk the levels from the top, inside a level the pairs in the reference's order (known here
            from the sequence; on the device: the index-based tie-break), stop at the first pair that shares a token with
            the batch or has a == b.  This IS exact -- a created pair reaches a level only by taking over, in place, a
@@ -138,16 +140,18 @@ def main():
         batch = [pairs[i]]
         j = i + 1
         level = top
+        in_tied = False
         while j < M and len(batch) < cap:
             x, y = pairs[j]
             c = t.cnt.get((x, y), 0)
             if x == y or x in used or y in used or c != counts[j]:  # (c != counts[j]: a pair the batch creates or changes)
                 break
             if c < level:  # a level below
-                if list_level is not None:
+                if list_level is not None or in_tied:
                     break
-                if rule == "free":
-                    pass
+                if rule in ("free", "free1"):
+                    if rule == "free1" and t.levels.count(c) > 1:
+                        in_tied = True  # (one tied level per step: the walk ends with it)
                 else:
                     # the level must be the next one down among the pairs outside the batch ...
                     k = len(t.levels) - 1 - len(batch)  # the batch's own counts sit on top
@@ -180,7 +184,7 @@ def main():
             j += 1
         return len(batch)
 
-    rules = ("engine", "tied", "free", "engine+list", "free+list")
+    rules = ("engine", "tied", "free", "free1", "engine+list", "free+list", "free1+list")
     res = {f"{r}_cap{cap}": {"steps": 0, "next": 0, "by_phase": {}, "list": None, "full": 0} for r in rules for cap in caps}
     edges = [0, 300, 1000, 2000, 4000, 8000, 16000, 24000, M]
     for i in range(M):
