@@ -94,6 +94,14 @@ def golden_entry(name):
         return json.load(f).get(name)
 
 
+def all_golden_names():
+    p = os.path.join(ROOT, "tests", "golden", "big_golden.json")
+    if not os.path.exists(p):
+        return []
+    with open(p) as f:
+        return sorted(json.load(f).keys())
+
+
 def parity_report(name, wl, data_sha, offs, res):
     """Compare the GPU result with the committed oracle digests of this exact input: the plain oracle's
     (the reference's own loop, as far as hours of CPU reach) and, where it exists, the weighted oracle's
@@ -101,9 +109,13 @@ def parity_report(name, wl, data_sha, offs, res):
     checked against the plain oracle's when the fixture is generated)."""
     from helpers import checkpoint_digests, first_divergence
     rep = {"golden": None, "merges_checked": 0, "equal": None}
-    for gname in (name, name + "_w"):
+    # the entries named after the workload first, then any other entry of this exact input (size, seed, chunked or
+    # not, sha256 of the bytes): e.g. `--bytes 3900000000` finds regex3p9g_w
+    names = [name, name + "_w"] + [k for k in all_golden_names() if k not in (name, name + "_w")]
+    for gname in names:
         g = golden_entry(gname)
-        if not g or g["bytes"] != wl["bytes"] or g["seed"] != wl["seed"] or g["data_sha256"] != data_sha:
+        if (not g or g["bytes"] != wl["bytes"] or g["seed"] != wl["seed"] or g["data_sha256"] != data_sha
+                or bool(g.get("chunked")) != bool(wl.get("chunked"))):
             continue
         if g.get("offsets_sha256") and offs is not None:
             same_split = hashlib.sha256(offs.tobytes()).hexdigest() == g["offsets_sha256"]
