@@ -787,6 +787,40 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dp_check = {"ranks_agree": bool(lo.item() == hi.item()), "equals_single_gpu": None}
+        # the job's merges against the CPU oracle's: tests/golden/big_golden.json[regex1g_dp<world>_w] = the weighted
+        # oracle on the distinct chunks of the shards back to back (all 31,744 merges, pairs + counts + GLOBAL lengths);
+        # every rank vouches for its own shard's bytes (sha256), rank 0 compares the digests
+        g, mine = None, False
+        try:
+            g = golden_entry(f"{name}_dp{world}_w")
+            if world == 1:  # (BENCH_FORCE_DP: one shard = the single-GPU headline input)
+                g1 = golden_entry(f"{name}_w")
+                g = dict(g1, world=1, shard_sha256=[g1["data_sha256"]]) if g1 else None
+            if not (g and g.get("world") == world and g["bytes"] == wl["bytes"] and g["seed"] == wl["seed"]):
+                g = None
+            mine = bool(g) and hashlib.sha256(data).hexdigest() == g["shard_sha256"][rank]
+        except Exception:  # (a malformed entry: nothing is claimed; every rank still joins the reduction below)
+            g, mine = None, False
+        ok = torch.tensor([1 if mine else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if g is None:
+            dp_check["oracle"] = f"no committed oracle digest for {world} shard(s) of this size"
+        elif not bool(ok.item()):
+            dp_check["oracle"] = "not checked: a shard's bytes differ from the golden's"
+        elif rank == 0:
+            try:
+                from helpers import checkpoint_digests, first_divergence
+                k = min(g["done"], len(res["pairs"]))
+                got = checkpoint_digests(res["pairs"][:k], res["counts"][:k], res["lens"][:k], g["step"])
+                bad = first_divergence(got, g["digests"])
+                checked = [c for c, _ in got if c in {c2 for c2, _ in g["digests"]}]
+                dp_check["oracle"] = {"entry": f"tests/golden/big_golden.json[{name}_dp{world}_w] (weighted oracle on the "
+                                               f"distinct chunks of the {world} shard(s) back to back, {g['done']} merges)",
+                                      "merges_checked": max(checked) if checked else 0,
+                                      "equal": bool(checked) and bad is None,
+                                      **({"first_bad_checkpoint": bad} if bad is not None else {})}
+            except Exception as e:
+                dp_check["oracle"] = f"not checked: {type(e).__name__}: {e}"
         if rank == 0 and os.environ.get("BENCH_DP_CHECK", "1") == "1" and wl["bytes"] * world <= 2_000_000_000:
             try:  # the sharded result must be the single-GPU result on the concatenation of all shards
                 parts, offl, base = [], [], 0

@@ -17,6 +17,9 @@ consumed by tests/test_gpu_big.py and bench.py.
                                                     # `regex1g` digests above (plain loop, 2.6 h) are its first
                                                     # 2048 merges and must come out identical -- checked here
     python tests/golden/gen_big_golden.py cfg3s_w   # the same cross-check at 150 MB: weighted == plain, all 8192
+    python tests/golden/gen_big_golden.py regex1g_dp2_w   # (dp4, dp8) the SHARDED headline of bench.py --gpus N: rank r's
+                                                    # shard is 1 GB of seed 2 + r, split on its own; the job's text is the
+                                                    # shards back to back; all 31,744 merges by the weighted oracle
 
 The GPT-4 split of `cfg3s` is done here with the `regex` module exactly as the
 reference does (regex.py:19,41), NOT with the native splitter: the digest of the
@@ -138,8 +141,58 @@ def main_weighted(name):
           f"final digest {entry['digests'][-1][1]}", flush=True)
 
 
+def main_sharded(name, world):
+    """bench.py --gpus `world`: every rank makes and splits its own shard (seed + rank); the merges are those of the
+    shards back to back (chunks never span shards).  Weighted oracle on the distinct chunks of the whole job."""
+    from minbpe_amd import _native
+    nbytes, seed, merges = 1_000_000_000, 2, 31744
+    t0 = time.time()
+    parts, offl, shas, base = [], [], [], 0
+    for r in range(world):
+        d = synth_text(nbytes, seed + r)
+        o = np.ascontiguousarray(_native.split_offsets(d, 4), dtype=np.uint64)
+        shas.append(hashlib.sha256(d).hexdigest())
+        parts.append(d)
+        offl.append(o + np.uint64(base))
+        base += len(d)
+        print(f"{name}: shard {r}: {len(o)} chunks, {time.time() - t0:.0f}s", flush=True)
+    data = b"".join(parts)
+    del parts
+    offs = np.concatenate(offl)
+    del offl
+    t1 = time.time()
+    ddata, doffs, wts, _first = oracle.dedup(data, offs)
+    entry = {"bytes": nbytes, "seed": seed, "merges": merges, "chunked": True, "weighted": True, "world": world,
+             "shard_sha256": shas, "n_chunks": int(len(offs)), "n_distinct": int(len(doffs)),
+             "distinct_bytes": len(ddata), "weight_sum": int(wts.sum()), "dedup_seconds": round(time.time() - t1, 1),
+             "split": "native scanner (bpe_split), every shard on its own"}
+    assert entry["weight_sum"] == entry["n_chunks"]
+    n_total = len(data)
+    del data, offs
+    t1 = time.time()
+    pairs, counts, lens = oracle.train(ddata, merges, doffs, weights=wts)
+    entry["oracle_seconds"] = round(time.time() - t1, 1)
+    entry["done"] = len(pairs)
+    entry["first"] = [list(p) for p in pairs[:4]]
+    entry["last"] = [list(p) for p in pairs[-2:]]
+    entry["total_bytes"] = n_total
+    entry["final_len"] = lens[-1]
+    entry["step"] = 256
+    entry["digests"] = checkpoint_digests(pairs, counts, lens, 256)
+    with open(OUT) as f:
+        allg = json.load(f)
+    allg[name] = entry
+    with open(OUT + ".tmp", "w") as f:
+        json.dump(allg, f, indent=1)
+    os.replace(OUT + ".tmp", OUT)
+    print(f"{name}: {len(pairs)} merges, {entry['n_chunks']} chunks -> {entry['n_distinct']} distinct, weighted oracle "
+          f"{entry['oracle_seconds']}s, final digest {entry['digests'][-1][1]}", flush=True)
+
+
 def main():
     name = sys.argv[1]
+    if name.startswith("regex1g_dp") and name.endswith("_w"):
+        return main_sharded(name, int(name[len("regex1g_dp"):-2]))
     if len(CASES[name]) == 5:
         return main_weighted(name)
     nbytes, seed, merges, chunked = CASES[name]
