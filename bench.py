@@ -114,9 +114,9 @@ def parity_report(name, wl, data_sha, offs, res):
     names = [name, name + "_w"] + [k for k in all_golden_names() if k not in (name, name + "_w")]
     for gname in names:
         g = golden_entry(gname)
-        if (not g or g["bytes"] != wl["bytes"] or g["seed"] != wl["seed"] or g["data_sha256"] != data_sha
-                or bool(g.get("chunked")) != bool(wl.get("chunked"))):
-            continue
+        if (not g or g.get("world") or g["bytes"] != wl["bytes"] or g["seed"] != wl["seed"]
+                or g.get("data_sha256") != data_sha or bool(g.get("chunked")) != bool(wl.get("chunked"))):
+            continue  # (entries with a "world" are sharded jobs: the N > 1 leg's, per-shard sha256)
         if g.get("offsets_sha256") and offs is not None:
             same_split = hashlib.sha256(offs.tobytes()).hexdigest() == g["offsets_sha256"]
             rep["split_equals_regex_module"] = same_split

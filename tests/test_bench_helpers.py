@@ -84,6 +84,23 @@ def test_round4_pmc_profile_matches_the_sources_and_its_own_check():
             assert json.load(f)["source_hash"] == bench.source_hash(), name
 
 
+def test_parity_report_walks_every_committed_golden_without_tripping():
+    """The headline's parity check looks at every entry of big_golden.json that could be of its input -- the sharded
+    jobs' entries (per-shard digests, no data_sha256) and the 3.9 GB one among them -- and claims nothing for an input
+    whose bytes it does not know."""
+    for name in ("regex1g", "basic1g", "cfg2"):
+        wl = dict(bench.WORKLOADS[name])
+        rep = bench.parity_report(name, wl, "0" * 64, None, _res([(1, 2)] * 4, [9, 8, 7, 6], [90, 80, 70, 60]))
+        assert rep["golden"] is None and rep["equal"] is None and rep["merges_checked"] == 0
+    with open(os.path.join(ROOT, "tests", "golden", "big_golden.json")) as f:
+        g = json.load(f)
+    for k in ("regex1g_dp2_w", "regex1g_dp4_w", "regex1g_dp8_w"):
+        e = g[k]
+        assert e["world"] == len(e["shard_sha256"]) == int(k[len("regex1g_dp"):-2]) and e["done"] == 31744
+        assert e["shard_sha256"][0] == g["regex1g"]["data_sha256"]  # rank 0's shard is the single-GPU headline input
+    assert g["regex3p9g_w"]["bytes"] == 3_900_000_000 and g["regex3p9g_w"]["done"] == 31744
+
+
 def test_workloads_name_the_baseline_configs():
     w = bench.WORKLOADS
     assert w["regex1g"]["bytes"] == 1_000_000_000 and w["regex1g"]["vocab"] == 32000 and w["regex1g"]["chunked"]
