@@ -107,3 +107,50 @@ def test_workloads_name_the_baseline_configs():
     assert w["basic1g"]["bytes"] == 1_000_000_000 and not w["basic1g"]["chunked"]
     assert w["cfg2"]["bytes"] == 100_000_000 and w["cfg2"]["vocab"] == 4096
     assert w["regex1g_dedup"]["dedup"] and w["regex1g_dedup"]["seed"] == w["regex1g"]["seed"]
+
+
+class _BenchDouble:
+    """fake_engine.OracleEngine + the measurement plumbing bench.py calls: lets run_train_workload's assembly of the
+    line (parity report, invariants, roofline with and without a PMC profile, secondary or not) run on the CPU"""
+
+    def __init__(self):
+        from fake_engine import OracleEngine
+        self._e = OracleEngine()
+        self.opts = {}
+
+    def load_bytes(self, data, offsets=None, weight_exp=None):
+        self._e.load_bytes(data, offsets, weight_exp)
+
+    def train(self, n):
+        return self._e.train(n)
+
+    def set_option(self, k, v):
+        self.opts[k] = v
+
+    def prof_reset(self):
+        pass
+
+    def prof_read(self):
+        return {k: {"ms": ms, "launches": 7, "alg_bytes": 7_000_000}
+                for k, ms in (("widen", 0.1), ("pair_count", 0.2), ("argmax", 0.5), ("merge", 2.0), ("table", 0.4))}
+
+    def train_stats(self):
+        return {"dense": 1, "sparse": 2}
+
+
+@pytest.mark.parametrize("secondary", [False, True])
+@pytest.mark.parametrize("mode", [-1, 0])
+def test_run_train_workload_assembles_its_line_on_a_test_double(secondary, mode):
+    wl = dict(bytes=60_000, seed=5, vocab=256 + 40, chunked=True, desc="RegexTokenizer.train (test double)")
+    r, data, offs, res = bench.run_train_workload("unit", wl, _BenchDouble(), 2, 1, lambda: None, lambda dt: dt, mode,
+                                                  secondary=secondary)
+    json.dumps(r)  # the line must serialise
+    assert len(res["pairs"]) == 40 and r["invariants"]["len_drop_equals_count_and_counts_monotone"]
+    assert r["parity"]["golden"] is None and r["parity"]["equal"] is None  # (not an input any golden knows)
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["traffic"] is None and rf["equivalent_work_GBps"] > 0
+    if secondary:  # no PMC pass of this workload: no fraction is claimed
+        assert rf["frac"] is None and rf["achieved"] is None and rf["achieved_kind"].startswith("none")
+    else:          # the headline without one: the algorithmic figure, labelled
+        assert rf["frac"] is not None and rf["achieved_kind"].startswith("algorithmic")
+    assert r["whole_iteration"]["device_ms_per_train"] == pytest.approx(3.2) and r["whole_iteration"]["frac"] is None
