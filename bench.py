@@ -839,13 +839,19 @@ def main():
             except Exception as e:
                 dp_check["equals_single_gpu"] = f"not checked: {type(e).__name__}: {e}"
         line.update({
-            "value": round(num_merges * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # the units ALL ranks processed / the time (the bench contract's whole-job aggregate under weak scaling): a
+            # merge of the job is applied to every rank's 1 GB shard, so N ranks do N x num_merges shard-merges per train;
+            # the job's own rate (what a user waits for) is job_merges_per_s
+            "value": round(world * num_merges * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "job_merges_per_s": round(num_merges * args.steps / dt, 2),
             "config": {"workload": f"{wl['desc']} sharded over {world} GPUs by contiguous chunk ranges, "
                                    f"{wl['bytes']} B synthetic UTF-8 per GPU (seed {wl['seed']}+rank), vocab "
                                    f"{wl['vocab']} ({num_merges} merges); ranks agree: {dp_check['ranks_agree']}",
                        "parallelism": f"dp{world} ({dist_path}: per step of 1..K merges one MIN all-reduce of a tie's "
                                       f"first occurrences and one SUM all-reduce of the batch's table deltas)"},
-            "value_definition": "merges per second of the ONE sharded job (not summed over ranks)",
+            "value_definition": f"shard-merges per second = {world} ranks x the job's merges per second: every merge of the "
+                                f"ONE sharded job is applied to each rank's {wl['bytes']} B shard (weak scaling: the work per "
+                                "rank is fixed, the job grows with N); job_merges_per_s = the job's own rate",
             "sharded_check": dp_check, "roofline": roofline, "cpu_baseline": None,
             "merge_passes": eng.train_stats(),
         })
@@ -853,6 +859,9 @@ def main():
             try:
                 line["cpu_baseline"] = cpu_baseline(wl, data, offs, res, args.cpu_bytes, args.cpu_iters,
                                                     total_bytes=wl["bytes"] * world)
+                # (its `value` is the CPU's rate on the WHOLE job in the job's merges per second: set it against
+                # job_merges_per_s, or times N against `value`)
+                line["cpu_baseline"]["compare_with"] = "job_merges_per_s"
             except Exception as e:
                 line["cpu_baseline"] = f"failed: {type(e).__name__}: {e}"
 
