@@ -154,3 +154,40 @@ def test_run_train_workload_assembles_its_line_on_a_test_double(secondary, mode)
     else:          # the headline without one: the algorithmic figure, labelled
         assert rf["frac"] is not None and rf["achieved_kind"].startswith("algorithmic")
     assert r["whole_iteration"]["device_ms_per_train"] == pytest.approx(3.2) and r["whole_iteration"]["frac"] is None
+
+
+def test_main_prints_one_conforming_line_at_n1_on_a_test_double(monkeypatch, capsys):
+    """bench.main() at N = 1 (a small --bytes / --vocab, no secondaries) with the engine replaced by the test double:
+    the keys the driver's contract names are there, the CPU baseline leg runs, the line is one JSON object."""
+    import torch
+    import minbpe_amd
+
+    class Double(_BenchDouble):
+        def __init__(self, device=0):
+            super().__init__()
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(minbpe_amd, "Engine", Double)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--bytes", "50000", "--vocab", str(256 + 30), "--steps", "2", "--warmup", "1",
+                                      "--cpu-iters", "3", "--cpu-bytes", "20000"])
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BENCH_FORCE_DP"):
+        monkeypatch.delenv(k, raising=False)
+    bench.main()
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1
+    line = json.loads(out[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["vs_baseline"] is None
+    assert line["unit"] == "merges/s" and line["dtype"] == "int32" and line["data"] == "synthetic"
+    assert line["value"] == pytest.approx(30 / (line["ms_per_step"] * 1e-3), rel=1e-3)
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    cpu = line["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] == 1
+    assert line["secondary"] == {}
