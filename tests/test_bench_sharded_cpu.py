@@ -50,9 +50,9 @@ def _tiny_job_golden(world, nbytes, seed, merges):
             "shard_sha256": shas, "done": len(pairs), "step": 8, "digests": checkpoint_digests(pairs, counts, lens, 8)}
 
 
-def _worker(rank, world, port, argv, out_q, tmpdir, golden=None):
+def _worker(rank, world, port, argv, out_q, tmpdir, golden=None, path="steps"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", BPE_DIST="steps", BENCH_DP_CHECK="1", TMPDIR=tmpdir)
+                      LOCAL_RANK="0", BPE_DIST=path, BENCH_DP_CHECK="1", TMPDIR=tmpdir)
     import torch.distributed as dist
     import minbpe_amd
     import minbpe_amd.dist as mdist
@@ -77,6 +77,22 @@ def _worker(rank, world, port, argv, out_q, tmpdir, golden=None):
 
         def close(self):
             pass
+
+        # BPE_DIST=native: dist.init_native_comm hands the library's communicator id around (rank 0's 128 bytes reach
+        # every rank), then the whole sharded loop is ONE call -- here the per-merge protocol on the numpy shard
+        def comm_available(self):
+            return True
+
+        def comm_unique_id(self):
+            return bytes(range(1, 129))
+
+        def comm_init(self, r, w, raw):
+            assert (r, w) == (rank, world) and raw == bytes(range(1, 129))
+            self.comm_ready = True
+
+        def dp_train(self, n):
+            assert self.comm_ready
+            return mdist.train_sharded(CpuShard(self._data, self._offs), mdist.TorchComm(), n)
 
     # -- the GPU's stand-ins --------------------------------------------------------------------------------
     torch.cuda.set_device = lambda *a, **k: None
@@ -107,8 +123,8 @@ def _worker(rank, world, port, argv, out_q, tmpdir, golden=None):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("golden", ["none", "right", "wrong"])
-def test_sharded_bench_leg_runs_on_doubles_at_world_2(tmp_path, golden):
+@pytest.mark.parametrize("golden,path", [("none", "steps"), ("right", "steps"), ("wrong", "steps"), ("right", "native")])
+def test_sharded_bench_leg_runs_on_doubles_at_world_2(tmp_path, golden, path):
     world = 2
     argv = ["--gpus", str(world), "--bytes", "40000", "--vocab", str(256 + 24), "--steps", "1", "--warmup", "1",
             "--cpu-iters", "3", "--cpu-bytes", "20000"]
@@ -120,7 +136,7 @@ def test_sharded_bench_leg_runs_on_doubles_at_world_2(tmp_path, golden):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q, str(tmp_path), g)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q, str(tmp_path), g, path)) for r in range(world)]
     for p in procs:
         p.start()
     outs = sorted(q.get(timeout=500) for _ in procs)
@@ -145,6 +161,7 @@ def test_sharded_bench_leg_runs_on_doubles_at_world_2(tmp_path, golden):
         assert chk["oracle"]["merges_checked"] == 24 and chk["oracle"]["equal"] is (golden == "right")
         assert ("first_bad_checkpoint" in chk["oracle"]) == (golden == "wrong")
     assert line["config"]["parallelism"].startswith("dp2") and "sharded over 2 GPUs" in line["config"]["workload"]
+    assert ("bpe_dp_train" in line["config"]["parallelism"]) == (path == "native")
     assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] > 0
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["compare_with"] == "job_merges_per_s"
