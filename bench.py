@@ -24,7 +24,7 @@ basic1g,cfg2,regex1g_dedup,e2e_class,encode at N=1) run --secondary-steps each a
 Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel class timed with
 hipEvents on the library's own stream inside the timed steps; `cpu_baseline` = the CPU
 oracle (C restatement of the reference loop, one thread) on a bounded slice of the same
-input, on this host, plus the unmodified Python reference when /root/reference exists.
+input, on this host, plus minbpe's pure-Python loop (oracle/pyref.py, a pinned restatement) on a smaller slice.
 Parity with the oracle is CHECKED in the run against committed full-length digests
 (tests/golden/big_golden.json) and reported, never assumed.
 """
@@ -402,32 +402,30 @@ def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters, total_bytes=None):
     }
     if nb == len(data):
         out["gpu_first_merges_equal"] = bool(cp == res["pairs"][:cpu_iters])
-    # the unmodified reference (train.py:20-31 style loop) exists only in the build container
-    if os.path.isdir("/root/reference/minbpe"):
-        try:
-            import types
-            sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
-            sys.path.insert(0, "/root/reference")
-            from minbpe.base import get_stats, merge
-            py_n = min(4_000_000, nb)
-            ids = list(sample[:py_n])
-            t0 = time.perf_counter()
-            K = 3
-            for i in range(K):
-                stats = get_stats(ids)
-                pair = max(stats, key=stats.get)
-                ids = merge(ids, pair, 256 + i)
-            pt = (time.perf_counter() - t0) / K
-            out["python_reference"] = {
-                "s_per_merge_on_sample": round(pt, 3), "sample_bytes": py_n,
-                "extrapolated_merges_per_s_full_size": round(1.0 / (pt * len(data) / py_n), 6),
-                "note": "minbpe.base.get_stats + max + merge, unmodified, one thread, as one stream "
-                        "(BasicTokenizer-style), linear extrapolation in N"}
-        except Exception as e:  # the bench line must still come out
-            out["python_reference"] = f"not timed: {type(e).__name__}: {e}"
-    else:
-        out["python_reference"] = ("not timed: /root/reference is absent on this host (pure-Python reference "
-                                   "cannot travel; see BASELINE.md for its timing in the build container)")
+    # minbpe's pure-Python path, timed HERE on this host's cores: oracle/pyref.py restates base.py:13-41 + basic.py:31-42
+    # statement for statement (the reference tree cannot travel to the GPU box; the restatement is pinned against the
+    # fixtures the reference generated, tests/test_oracle_golden.py) -- one thread, like the reference
+    try:
+        from oracle import pyref
+        py_n = min(4_000_000, nb)
+        py_sample = bytes(sample[:py_n])
+        K = 3
+        t0 = time.perf_counter()
+        pp, _ = pyref.train(py_sample, K)
+        pt = (time.perf_counter() - t0) / K
+        out["python_reference"] = {
+            "kind": "restatement", "cores": 1, "nproc": os.cpu_count(),
+            "s_per_merge_on_sample": round(pt, 3), "sample_bytes": py_n, "sample_merges": K,
+            "merges_per_s_on_sample": round(1.0 / pt, 4),
+            "extrapolated_merges_per_s_full_size": round(1.0 / (pt * total / py_n), 6),
+            "note": "oracle/pyref.py = get_stats + max + merge of minbpe (base.py:13-41, basic.py:31-42) in pure Python, "
+                    "one thread, as one stream (BasicTokenizer-style), timed in this run on this host; linear "
+                    "extrapolation in N (the loop is O(N) per merge)"}
+        if so is None:
+            out["python_reference"]["equals_c_oracle_first_merges"] = bool(
+                [tuple(p) for p in pp] == [tuple(p) for p in oracle.train(py_sample, K)[0]])
+    except Exception as e:  # the bench line must still come out
+        out["python_reference"] = f"not timed: {type(e).__name__}: {e}"
     return out
 
 

@@ -163,6 +163,10 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "chain_levels")) {
+        c->chain_levels = value != 0;
+    } else if (!strcmp(name, "chain_list")) {
+        c->chain_list = value != 0;
     } else if (!strcmp(name, "chain_scan")) {
         if (value < 1 || value > 255) return fail(c, BPE_E_ARG, "chain_scan must be 1..255");
         c->chain_scan = value;

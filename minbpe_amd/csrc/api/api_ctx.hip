@@ -112,6 +112,10 @@ struct bpe_ctx {
     int chain_dense = 1;                      // option "chain_dense": chain steps from the second merge on -- dense passes, LDS delta tables, up to CH_KDENSE
                                               // pairs per sweep -- while every id is below LDSD_CAP and the index does not exist yet
     int chain_extend = 1;                     // option "chain_extend": a chain step's batch may reach below the maximum count (k_chain_sel)
+    int chain_list = 1;                       // option "chain_list": 0 = no LIST steps, every step is a full selection that walks the levels (with chain_levels;
+                                              // UNTESTED ON A GPU)
+    int chain_levels = 0;                     // option "chain_levels": ... and into a level that holds several pairs (taken in order of first occurrence;
+                                              // that level becomes the list).  UNTESTED ON A GPU (written without one): off until it is
     unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
     int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
                                               // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
@@ -1116,7 +1120,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
     hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
-                       (uint32_t)(c->chain_extend && c->chain_scan >= CH_KMAX - 1),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
+                       (uint32_t)((c->chain_extend && c->chain_scan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
                        kcap, dp ? c->d_dp_ckey : (long long *)nullptr, (unsigned long long)(dp ? dp->rank : 0));
     LAUNCHCHK(c, "k_chain_sel");
     if (dp) {

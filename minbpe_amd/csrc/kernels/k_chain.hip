@@ -704,7 +704,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                 k_done = K;
                 st->iter = iter + K;
                 // the list minus the batch: anything left -> the next step takes its pairs off it
-                st->sel_mode = (st->tl_n > K) ? CH_LIST : CH_FULL;
+                st->sel_mode = (st->tl_n > st->tl_skip) ? CH_LIST : CH_FULL;  // (tl_skip: the batch's share of the list)
             } else if (status == 0 && !defer) {
                 st->sel_mode = CH_FULL;  // (an emptied list, or training is over: select when asked again)
             }
@@ -842,12 +842,17 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     __shared__ uint32_t s_bits[2048];
     __shared__ uint32_t s_r16[16], s_c16[16];
     __shared__ uint32_t s_fail, s_nt, s_k, s_m2, s_hit, s_hitarg, s_stop;
+    __shared__ uint32_t s_nt2, s_nrows2, s_rows2[16];  // the tied level's pairs are gathered by the loop that finds the level
+    __shared__ uint32_t s_lv, s_lvn, s_lvfirst, s_lvc, s_more;  // a TIED level below the maximum: its count (0: none; s_lvc: of the one that is the list), its pairs,
+                                                                // where they start in the batch; s_more: it was taken whole, the walk goes on
     __shared__ unsigned long long s_pos[TIE_CAP];
     __shared__ uint32_t s_order[TIE_CAP], s_keep[TIE_CAP];
     __shared__ int32_t s_ba[CH_KMAX], s_bb[CH_KMAX];
     __shared__ uint32_t s_bc[CH_KMAX], s_sec[CH_KMAX];
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
-    const uint32_t iter = st->iter, nm = st->num_merges, mode = st->sel_mode;
+    // (extend bit 2, option chain_list = 0: every step selects afresh and walks the levels -- no LIST steps; the step
+    // record still says what k_apply_chain would have chosen)
+    const uint32_t iter = st->iter, nm = st->num_merges, mode = (extend & 4u) ? CH_FULL : st->sel_mode;
     const uint32_t vcur = 256u + iter;
     const uint32_t tid = threadIdx.x;
     // Sharded training (dpkey != nullptr, k_dp.hip): the table, the row maxima and the flag words are replicas of
@@ -956,6 +961,11 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         s_fail = 0;
         s_nt = 0;
         s_stop = 0;
+        s_lv = 0;
+        s_lvn = 0;
+        s_lvfirst = 0;
+        s_lvc = 0;
+        s_more = 0;
     }
     const uint32_t nd = dirty_view_build(dbits, D);
     if (tid == 0) st->sel_ran = 1;  // (this launch re-scans every flagged row)
@@ -1049,17 +1059,6 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             for (uint32_t q = 0; q < nt; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
             s_order[rank] = tid;
         }
-        // (my share of the row maxima again, for the levels below M: fetched a second time -- 32 loads that hit L2 --
-        // so that 32 registers are free while the tied pairs are located; held across tie_by_index they were spilled
-        // to scratch memory inside its loops)
-        {
-            const uint2 *__restrict__ rowma2 = reinterpret_cast<const uint2 *>(rowmax);
-#pragma unroll
-            for (int i = 0; i < SEL_RPT; i++) {
-                const uint32_t x = tid + 1024u * (uint32_t)i;
-                rm[i] = (x < vcur && !((s_words[x >> 5] >> (x & 31)) & 1u)) ? rowma2[x].x : 0u;
-            }
-        }
     } else if (tid == 0) {
         s_order[0] = 0;
     }
@@ -1102,8 +1101,27 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
     }
     // ---- below the maximum: one row maximum per level, while it is unambiguous ---------------------------
     const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
-    uint32_t cur = M;
-    for (uint32_t round = k1; round < kmax; round++) {
+    // one pass: single-pair levels from `cur` down, then a tied level; returns that level's count if it was taken whole (the
+    // walk goes on below it: straight-line calls, not a loop -- a back edge here cost 250 bytes of scratch per lane), else 0
+    auto walk = [&](uint32_t cur) -> uint32_t {
+    if (tid == 0) {
+        s_lv = 0;
+        s_more = 0;
+        s_stop = 0;
+    }
+    // (my share of the row maxima again: fetched anew -- loads that hit L2 -- so that these registers are free while
+    // tied pairs are located; held across tie_by_index they were spilled to scratch memory inside its loops.  The
+    // thread number goes through an empty asm so that the twenty addresses are made here, each time, and not hoisted
+    // out of the loop into forty registers that live across it)
+    uint32_t tl = tid;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int i = 0; i < SEL_RPT; i++) {
+        const uint32_t x = tl + 1024u * (uint32_t)i;
+        rm[i] = (x < vcur && !((s_words[x >> 5] >> (x & 31)) & 1u)) ? rowma[x].x : 0u;
+    }
+    __syncthreads();
+    for (uint32_t round = s_k; round < kmax; round++) {
         uint32_t m = 0;
 #pragma unroll
         for (int i = 0; i < SEL_RPT; i++) m = (rm[i] < cur) ? max(m, rm[i]) : m;
@@ -1146,7 +1164,65 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         }
         if (c) atomicAdd(&s_hit, c);
         __syncthreads();
-        if (s_hit != 1) break;  // (uniform)
+        const bool levels = (extend & 2u) && !dpkey && gap == 0;
+        bool tied_level = s_hit != 1;  // (uniform) several rows attain it: a TIED level (taken below, in order of first occurrence)
+        if (!tied_level && levels) {   // ... or one row with several columns
+            uint32_t y = s_hitarg;
+            if (y == 0xFFFFFFFEu) y = rowma[s_m2].y;
+            tied_level = y == ROWARG_MULTI;
+        }
+        if (tied_level) {
+            if (!levels) break;
+            // gather the level's pairs while the row maxima are at hand: a row with one column at m2 gives its pair, a
+            // row with several (ROWARG_MULTI) is scanned afterwards
+            if (tid == 0) {
+                s_nt2 = 0;
+                s_nrows2 = 0;
+            }
+            __syncthreads();
+            auto row_at = [&](uint32_t x, uint32_t y) {
+                if (y != ROWARG_MULTI) {
+                    const uint32_t s = atomicAdd(&s_nt2, 1u);
+                    if (s < TIE_CAP) {
+                        s_tied[2 * s] = (int32_t)x;
+                        s_tied[2 * s + 1] = (int32_t)y;
+                    }
+                } else {
+                    const uint32_t s = atomicAdd(&s_nrows2, 1u);
+                    if (s < 16u) s_rows2[s] = x;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < SEL_RPT; i++)
+                if (rm[i] == m2) row_at(tl + 1024u * (uint32_t)i, rowma[tl + 1024u * (uint32_t)i].y);
+            for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
+                if ((s_words[x >> 5] >> (x & 31)) & 1u) continue;
+                const uint2 v = rowma[x];
+                if (v.x == m2) row_at(x, v.y);
+            }
+            for (uint32_t i = tid; i < nd; i += 1024)
+                if (s_exm[i] == m2) row_at(s_exrow[i], s_exarg[i]);
+            __syncthreads();
+            const uint32_t nrows2 = s_nrows2;
+            if (nrows2 <= 16u && s_nt2 <= TIE_CAP) {
+                for (uint32_t r = 0; r < nrows2; r++) {
+                    const uint32_t x = s_rows2[r];
+                    const uint32_t *row = mat + (size_t)x * stride;
+                    for (uint32_t y = tid; y < vcur; y += 1024) {
+                        if (row[y] == m2) {
+                            const uint32_t s = atomicAdd(&s_nt2, 1u);
+                            if (s < TIE_CAP) {
+                                s_tied[2 * s] = (int32_t)x;
+                                s_tied[2 * s + 1] = (int32_t)y;
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_lv = (nrows2 <= 16u && s_nt2 >= 1u && s_nt2 <= TIE_CAP) ? m2 : 0u;
+            break;
+        }
         if (tid == 0) {
             const uint32_t x = s_m2;
             uint32_t y = s_hitarg;
@@ -1166,6 +1242,71 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
         __syncthreads();
         if (s_stop) break;
         cur = m2;
+    }
+    __syncthreads();
+    // ---- a tied level below the maximum (tests/test_level_model.py): every level above it is in the batch, so nothing
+    // outside the batch counts more than its pairs do; they are taken in order of first occurrence until one shares a
+    // token with the batch (a pair a merge of the batch creates reaches this level only by taking over, in place, one
+    // of its pairs that shares a token with the batch -- where the walk stops anyway).  The level's pairs become THE
+    // LIST: the next steps take the rest of it off the list like the pairs tied at a maximum.
+    if (!s_lv) return 0u;  // (uniform)
+    {
+        const uint32_t lv = s_lv;
+        const uint32_t nt2 = s_nt2;  // (1 .. TIE_CAP pairs in s_tied, as the gather's atomics fell)
+        bool ok2 = true;
+        if (ok2 && nt2 > 1) {
+            (void)tie_by_index(ref, C, s_tied, nt2, s_pos);
+            __syncthreads();
+            if (tid < nt2 && s_pos[tid] == NOPOS) s_fail = 1;  // (a pair the index does not lead to: not ours to order)
+            __syncthreads();
+            ok2 = s_fail == 0;
+            if (ok2 && tid < nt2) {
+                const unsigned long long me = s_pos[tid];
+                uint32_t rank = 0;
+                for (uint32_t q = 0; q < nt2; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
+                s_order[rank] = tid;
+            }
+        } else if (tid == 0) {
+            s_order[0] = 0;
+        }
+        __syncthreads();
+        if (ok2) {
+            if (tid < nt2) {
+                s_list[2 * tid] = s_tied[2 * s_order[tid]];
+                s_list[2 * tid + 1] = s_tied[2 * s_order[tid] + 1];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t k = s_k;
+                s_lvfirst = k;
+                s_lvn = nt2;
+                s_lvc = lv;
+                uint32_t e = 0;
+                for (; e < nt2 && k < kmax; e++) {
+                    const int32_t x = s_list[2 * e], y = s_list[2 * e + 1];
+                    bool clash = x == y;
+                    for (uint32_t i = 0; i < k && !clash; i++) clash = (x == s_ba[i]) | (x == s_bb[i]) | (y == s_ba[i]) | (y == s_bb[i]);
+                    if (clash) break;
+                    s_ba[k] = x;
+                    s_bb[k] = y;
+                    s_bc[k] = lv;
+                    k++;
+                }
+                s_k = k;
+                s_more = (e == nt2 && k < kmax) ? 1u : 0u;  // the whole level is in the batch: the levels below it are next
+            }
+        } else if (tid == 0) {
+            s_fail = 0;  // (the level stays out of the batch; nothing else failed)
+        }
+        __syncthreads();
+        return s_more ? lv : 0u;  // (uniform)
+    }
+    };
+    {
+        uint32_t c = walk(M);
+        if (c) c = walk(c);
+        if (c) c = walk(c);
+        if (c) (void)walk(c);
     }
     __syncthreads();
     const uint32_t k2 = s_k;
@@ -1199,7 +1340,15 @@ k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t 
             st->bcnt[i] = s_bc[i];
         }
         st->bk = m;
-        // (the list holds the k1 pairs at M only: the batch takes them all, so the next step selects again)
+        // (the list holds the k1 pairs at M only: the batch takes them all, so the next step selects again) -- unless the
+        // batch went into a tied level: then that level's pairs are the list and the batch took the first of them
+        if (s_lvn && m > s_lvfirst) {  // (the LAST tied level entered: s_list still holds its pairs)
+            const uint32_t n = s_lvn;
+            for (uint32_t i = 0; i < 2 * n; i++) st->chain[i] = s_list[i];
+            st->tl_n = n;
+            st->tl_M = s_lvc;
+            st->tl_skip = m - s_lvfirst;  // (more than n when the batch went on below the level: the list is used up)
+        }
     }
 }
 

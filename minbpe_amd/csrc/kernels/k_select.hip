@@ -116,7 +116,8 @@ __device__ __forceinline__ void select_load(const uint32_t *__restrict__ rowmax,
 __device__ __forceinline__ void select_core(const uint32_t *__restrict__ rowmax,
                                             const uint32_t *__restrict__ mat, uint32_t stride,
                                             uint32_t vcur, int32_t *s_tied, uint32_t *s_bits, uint32_t &M_out,
-                                            uint32_t &nt_out, uint32_t (&rm)[SEL_RPT], const SelExtra &E) {
+                                            uint32_t &nt_out, uint32_t (&rm)[SEL_RPT], const SelExtra &E,
+                                            const uint32_t below = 0xFFFFFFFFu) {
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_M, s_nrows, s_nt;
     __shared__ uint32_t s_rows[ARGMAX_ROWS];
@@ -125,15 +126,19 @@ __device__ __forceinline__ void select_core(const uint32_t *__restrict__ rowmax,
     const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
     constexpr int RPT = SEL_RPT;
     auto excluded = [&](uint32_t x) -> bool { return E.excl && ((E.excl[x >> 5] >> (x & 31)) & 1u); };
+    // `below` (k_chain_sel's second look, at a level under the maximum): row maxima of `below` or more do not count --
+    // their pairs are already taken
+    auto capped = [&](uint32_t v) -> uint32_t { return v < below ? v : 0u; };
     uint32_t m = 0;
 #pragma unroll
     for (int i = 0; i < RPT; i++) {
         if (excluded(threadIdx.x + 1024u * i)) rm[i] = 0u;
+        rm[i] = capped(rm[i]);
         m = max(m, rm[i]);
     }
     for (uint32_t x = threadIdx.x + 1024u * RPT; x < vcur; x += 1024)
-        if (!excluded(x)) m = max(m, rowma[x].x);
-    for (uint32_t i = threadIdx.x; i < E.n; i += 1024) m = max(m, E.m[i]);
+        if (!excluded(x)) m = max(m, capped(rowma[x].x));
+    for (uint32_t i = threadIdx.x; i < E.n; i += 1024) m = max(m, capped(E.m[i]));
     m = wave_max_u32(m);
     if (lane_id() == 0) s_red[wave_id()] = m;
     if (threadIdx.x == 0) {

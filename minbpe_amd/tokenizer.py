@@ -441,10 +441,11 @@ class GPT4Tokenizer(RegexTokenizer):
         if ranks is None:
             try:
                 import tiktoken
-            except ImportError as e:
+                get_encoding = tiktoken.get_encoding  # (a namespace stub or a broken install is no tiktoken either)
+            except (ImportError, AttributeError) as e:
                 raise ImportError("GPT4Tokenizer needs the `tiktoken` package for cl100k_base ranks "
                                   "(or pass ranks= a dict / a .tiktoken file)") from e
-            ranks = tiktoken.get_encoding("cl100k_base")._mergeable_ranks
+            ranks = get_encoding("cl100k_base")._mergeable_ranks
         elif not isinstance(ranks, dict):
             ranks = load_tiktoken_ranks(ranks)
         self.merges = _recover_merges(ranks)

@@ -76,7 +76,7 @@ def test_custom_pattern_takes_the_regex_module_path(classes, native):
     assert tok.decode(tok.encode(text)) == text
 
 
-def test_gpt4_tokenizer_from_a_rank_table(classes, native, tmp_path):
+def test_gpt4_tokenizer_from_a_rank_table(classes, native, tmp_path, monkeypatch):
     """GPT4Tokenizer end to end (gpt4.py:57-130: merge recovery, byte shuffle, ids = ranks) on a
     toy rank table -- the cl100k_base ranks themselves are not available offline."""
     import base64
@@ -106,3 +106,9 @@ def test_gpt4_tokenizer_from_a_rank_table(classes, native, tmp_path):
             g.train("x", 300)
     with pytest.raises(ImportError):
         classes.GPT4Tokenizer()  # no tiktoken in this environment
+    # ... and a `tiktoken` that is not the package (a namespace stub some other code planted) is no tiktoken either
+    import sys
+    import types
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
+    with pytest.raises(ImportError):
+        classes.GPT4Tokenizer()

@@ -238,3 +238,149 @@ def test_batches_below_the_maximum_are_the_references_merges(name, k, n, seed):
     assert done > 40
     if name in ("k12", "words", "chunks"):
         assert multi_level > 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# ... and INTO A TIED LEVEL below the maximum (k_chain_sel with option chain_levels; the rule itself:
+# tests/test_level_model.py).  What the device does, restated:
+#   * levels below the maximum as above while each is one unambiguous row maximum;
+#   * the first level that several rows attain -- or one row with several columns -- is gathered like the pairs at a
+#     maximum (every column at that count of every row whose maximum it is), ordered by first occurrence, and its
+#     longest prefix with a != b and no token shared with the batch joins the batch;
+#   * the second-maxima check is the one above (a row taken at that level hides nothing at the level itself: all of
+#     its columns at the level are in the list);
+#   * if any of the level's pairs stay in the batch, THAT LEVEL IS THE LIST from now on: the next steps take the rest
+#     of it off the list (four-way replacement at the level's count), exactly as after a tie at a maximum.
+
+def device_batch_levels(chunks, left):
+    table = table_of(chunks)
+    pairs, counts = stats_in_order(chunks)
+    order = {p: i for i, p in enumerate(pairs)}
+    rows = {}
+    for (a, b), c in table.items():
+        rows.setdefault(a, []).append((c, b))
+    rowmax = {a: max(v)[0] for a, v in rows.items()}
+    M = max(rowmax.values())
+    tl = [p for p, c in zip(pairs, counts) if c == M]
+    batch = batch_of(tl, left)
+    cnts = [M] * len(batch)
+    level_list, level_first, level_c = [], 0, 0
+    if batch and len(batch) == len(tl):
+        used = set(t for p in batch for t in p)
+        cur = M
+        kmax = min(KMAX, left)
+        while len(batch) < kmax:
+            lower = [m for m in rowmax.values() if m < cur]
+            if not lower:
+                break
+            m2 = max(lower)
+            at = [a for a, m in rowmax.items() if m == m2]
+            cols = [b for c, b in rows[at[0]] if c == m2] if len(at) == 1 else []
+            if len(at) != 1 or len(cols) != 1:
+                # a tied level: all of its pairs among the row maxima, in order of first occurrence
+                level = sorted(((a, b) for a in at for c, b in rows[a] if c == m2), key=order.get)
+                level_list, level_first, level_c = level, len(batch), m2
+                took = 0
+                for x, y in level:
+                    if x == y or x in used or y in used or len(batch) >= kmax:
+                        break
+                    batch.append((x, y))
+                    cnts.append(m2)
+                    used.update((x, y))
+                    took += 1
+                if took == len(level):  # taken whole: the walk goes on below it
+                    cur = m2
+                    continue
+                break
+            x = at[0]
+            if cols[0] == x or x in used or cols[0] in used:
+                break
+            batch.append((x, cols[0]))
+            cnts.append(m2)
+            used.update((x, cols[0]))
+            cur = m2
+
+        def second(a, b):
+            rest = [c for c, y in rows[a] if y != b]
+            return max(rest) if rest else 0
+        S, m = 0, 1
+        for t in range(1, len(batch)):
+            S = max(S, second(*batch[t - 1]))
+            if S < cnts[t]:
+                m = t + 1
+            else:
+                break
+        batch, cnts = batch[:m], cnts[:m]
+    if level_list and len(batch) > level_first:
+        return batch, cnts, level_list, level_c, len(batch) - level_first
+    return batch, cnts, tl, M, min(len(batch), len(tl))
+
+
+@pytest.mark.parametrize("name,k,n", STREAMS)
+@pytest.mark.parametrize("seed", [6, 7, 8])
+def test_batches_into_a_tied_level_and_its_list_are_the_references_merges(name, k, n, seed):
+    chunks = make_stream(name, k, n, 131 * seed + n)
+    total, next_id, done = 220, 256, 0
+    entered = listed = 0
+    while done < total:
+        pairs, counts = stats_in_order(chunks)
+        if not len(counts) or counts.max() < 2:
+            break
+        batch, cnts, tl, Ml, skip = device_batch_levels(chunks, total - done)   # a FULL step
+        if not batch:  # a == b at the head of the list: the general path's merge
+            chunks = [merge(c, tl[0], next_id) for c in chunks]
+            next_id += 1
+            done += 1
+            continue
+        entered += Ml < cnts[0]
+        while True:
+            znew = list(range(next_id, next_id + len(batch)))
+            for pair, cnt, z in zip(batch, cnts, znew):
+                ref_pairs, ref_counts = stats_in_order(chunks)
+                j = int(np.argmax(ref_counts))
+                assert ref_pairs[j] == pair and int(ref_counts[j]) == cnt, (name, seed, done, pair, cnt, ref_pairs[j])
+                chunks = [merge(c, pair, z) for c in chunks]
+            next_id += len(batch)
+            done += len(batch)
+            if skip >= len(tl) or done >= total:
+                break  # the list is used up: the next step selects
+            # LIST steps: what is left of the list, four-way replacement at the LIST's count (which may be a level
+            # below the maximum the FULL step started from), then the next batch off it
+            table = table_of(chunks)
+            tl = maintain_after(tl, skip, batch, znew, table, Ml)
+            now_pairs, now_counts = stats_in_order(chunks)
+            if len(now_counts) and int(now_counts.max()) == Ml:
+                assert tl == [p for p, c in zip(now_pairs, now_counts) if c == Ml], (name, seed, done)
+            else:
+                assert tl == []
+            if not tl or tl[0][0] == tl[0][1]:
+                break  # the maximum dropped, or a == b heads the list (the general path): select again
+            batch = batch_of(tl, total - done)
+            cnts = [Ml] * len(batch)
+            skip = len(batch)
+            listed += 1
+    assert done > 40
+    if name in ("k12", "words", "chunks"):
+        assert entered > 0, entered
+        assert listed > 0, listed
+
+
+def maintain_after(tl, skip, batch, znew, table, M):
+    """maintain() for a list whose first `skip` entries were in the batch (the batch may hold more pairs than that:
+    the ones it took at higher levels)"""
+    ends = {b: z for (a, b), z in zip(batch, znew)}
+    starts = {a: z for (a, b), z in zip(batch, znew)}
+    out = []
+    for x, y in tl[skip:]:
+        cands = [(x, y)]
+        if x in ends:
+            cands.append((ends[x], y))
+        if y in starts:
+            cands.append((x, starts[y]))
+        if x in ends and y in starts:
+            cands.append((ends[x], starts[y]))
+        hit = [p for p in cands if table.get(p, 0) == M]
+        assert len(hit) <= 1
+        if hit:
+            out.append(hit[0])
+    return out

@@ -66,8 +66,8 @@ REF = "/root/reference"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
-def test_against_live_reference_taylorswift(golden):
-    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+def test_against_live_reference_taylorswift(golden, monkeypatch):
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
     sys.path.insert(0, REF)
     text = open(os.path.join(REF, "tests", "taylorswift.txt"), encoding="utf-8").read()
     g = golden["taylorswift"]
@@ -92,11 +92,11 @@ def test_against_live_reference_taylorswift(golden):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
-def test_against_live_reference_random(native):
+def test_against_live_reference_random(native, monkeypatch):
     """Differential check: the reference itself (imported from its read-only tree) against the
     oracle on random inputs -- tie-heavy alphabets, runs, multi-byte text, special tokens."""
     import random
-    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
     if REF not in sys.path:
         sys.path.insert(0, REF)
     from minbpe import BasicTokenizer as RefBasic, RegexTokenizer as RefRegex
@@ -200,10 +200,10 @@ def test_oracle_dedup_equals_library_dedup(native):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
-def test_weighted_oracle_against_live_reference(native):
+def test_weighted_oracle_against_live_reference(native, monkeypatch):
     """RegexTokenizer.train of the reference itself on the full text vs the weighted oracle on the distinct
     chunks: the same merges (regex.py:41-63)."""
-    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
     if REF not in sys.path:
         sys.path.insert(0, REF)
     from minbpe import RegexTokenizer as RefRegex
@@ -242,12 +242,12 @@ def test_big_golden_weighted_entries_continue_the_plain_ones():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
-def test_oracle_encode_with_a_cl100k_sized_table_against_live_reference(native):
+def test_oracle_encode_with_a_cl100k_sized_table_against_live_reference(native, monkeypatch):
     """oracle.encode with 100,000 ranks -- ids 256 + rank up to 100,255, and a merges dict whose values are
     not consecutive (what GPT4Tokenizer's are) -- against the reference's own _encode_chunk
     (regex.py:92-121) given the same merges dict."""
     import numpy as np
-    sys.modules.setdefault("tiktoken", types.ModuleType("tiktoken"))
+    monkeypatch.setitem(sys.modules, "tiktoken", types.ModuleType("tiktoken"))
     if REF not in sys.path:
         sys.path.insert(0, REF)
     from minbpe import RegexTokenizer as RefRegex
@@ -268,3 +268,44 @@ def test_oracle_encode_with_a_cl100k_sized_table_against_live_reference(native):
         got, _ = oracle.encode(pairs, pd, po, merge_ids=mids)
         assert got.tolist() == want
         assert max(want) >= 65536 and len(set(want)) > 500
+
+
+def test_pure_python_restatement_against_the_reference_fixtures(golden, native):
+    """oracle/pyref.py (what bench.py times as minbpe's pure-Python path on the GPU host) against the vectors the
+    reference generated: primitives (get_stats order and counts, max()'s tie-break, merge incl. a == a runs), every
+    BasicTokenizer training case, and the reference's own hash of the 256 merges of tests/taylorswift.txt."""
+    from oracle import pyref
+    for prim in golden["primitives"]:
+        ids = prim["ids"]
+        st = pyref.get_stats(ids)
+        assert [[a, b, c] for (a, b), c in st.items()] == prim["stats"]
+        if prim["stats"]:
+            assert list(max(st, key=st.get)) == prim["argmax"]
+            assert pyref.merge(ids, tuple(prim["argmax"]), 1000) == prim["merged"]
+            assert pyref.merge(ids, tuple(prim["merged_same"]["pair"]), 1001) == prim["merged_same"]["out"]
+    n = 0
+    for case in golden["train"]:
+        if case["kind"] != "basic":
+            continue
+        data, _ = data_for(case, native)
+        nm = case["vocab_size"] - 256
+        if case["raises_value_error"]:
+            with pytest.raises(ValueError):
+                pyref.train(data, nm)
+            continue
+        if len(data) * nm > 30_000_000:  # (keep the CPU suite short: the C oracle covers the long cases)
+            continue
+        pairs, counts = pyref.train(data, nm)
+        assert [list(p) for p in pairs] == case["merges"], case["name"]
+        n += 1
+    assert n >= 3
+    # ... and equal to the C oracle on a text with ties, counts included
+    data = native.synth_text(30_000, 9)
+    pairs, counts = pyref.train(data, 40)
+    op, oc, _ = oracle.train(data, 40)
+    assert [tuple(p) for p in pairs] == [tuple(p) for p in op] and list(counts) == list(oc)
+    # the reference's own taylorswift.txt answer (SURVEY 8c), as far as a few seconds of Python reach: the first 24 merges
+    p = os.path.join(os.path.dirname(__file__), "golden", "taylorswift.txt")
+    text = open(p, encoding="utf-8").read().encode()
+    pairs, _ = pyref.train(text, 24)
+    assert [tuple(p) for p in pairs] == [tuple(p) for p in oracle.train(text, 24)[0]]
