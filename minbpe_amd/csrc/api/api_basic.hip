@@ -68,7 +68,7 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
                     c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1],
                     c->d_dec_blob, c->d_dec_out, c->d_dec_voff, c->d_dec_off, c->d_dec_bsum, c->d_dec_ids,
-                    c->d_dec_len, c->d_wexp, c->d_round_lb, c->d_dp_ckey, c->d_dp_cfold, c->d_hdr2[0], c->d_hdr2[1], c->d_stage, c->d_idx, c->d_idx_tmp, c->d_idx_dirty, c->d_removed, c->d_smask, c->d_cand, c->d_dbits, c->d_lean_res, c->d_lean_sum, c->d_enc_tab, c->d_enc_rep, c->d_enc_mid, c->d_enc_midn, c->d_chain_req};
+                    c->d_dec_len, c->d_wexp, c->d_round_lb, c->d_dp_ckey, c->d_dp_cfold, c->d_hdr2[0], c->d_hdr2[1], c->d_stage, c->d_idx, c->d_idx_tmp, c->d_idx_dirty, c->d_removed, c->d_smask, c->d_cand, c->d_dbits, c->d_lean_res, c->d_lean_sum, c->d_enc_tab, c->d_enc_rep, c->d_enc_mid, c->d_enc_midn, c->d_chain_req, c->d_pool, c->d_pool_gather};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -155,7 +155,7 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "dp_force_comm")) {
         c->dp_force_comm = value != 0;
     } else if (!strcmp(name, "dp_kcap")) {
-        if (value < 1 || value > CH_KMAX) return fail(c, BPE_E_ARG, "dp_kcap must be 1..%d", CH_KMAX);
+        if (value < 1 || value > DP_KCAP_MAX) return fail(c, BPE_E_ARG, "dp_kcap must be 1..%d", DP_KCAP_MAX);
         c->dp_kcap = (int)value;
     } else if (!strcmp(name, "fuse_load")) {
         c->fuse_load = value != 0;
@@ -163,6 +163,14 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "chain_kcap")) {
+        if (value < 1 || value > CH_KSWEEP) return fail(c, BPE_E_ARG, "chain_kcap must be 1..%d", CH_KSWEEP);
+        c->chain_kcap = (int)value;
+    } else if (!strcmp(name, "pool")) {
+        c->pool = value != 0;
+    } else if (!strcmp(name, "pool_hint")) {
+        if (value < 0 || value > 128) return fail(c, BPE_E_ARG, "pool_hint must be 0..128");
+        c->pool_hint = (int)value;
     } else if (!strcmp(name, "chain_levels")) {
         c->chain_levels = value != 0;
     } else if (!strcmp(name, "chain_list")) {

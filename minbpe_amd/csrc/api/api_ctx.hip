@@ -30,7 +30,7 @@ struct bpe_ctx {
     uint32_t *d_dp_cfold = nullptr;
     uint64_t cap_dp_cfold = 0;
     bool dp_force_comm = false;  // option "dp_force_comm": issue the collectives in a world of one too (tests, launch-cost measurements)
-    int dp_kcap = CH_KMAX;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
+    int dp_kcap = DP_KCAP_MAX;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
     uint64_t *d_round_lb = nullptr;  // k_load_count: first chunk of every segment of the byte stream
     uint64_t cap_round_lb = 0;
     bool fuse_load = true;  // option "fuse_load": the byte stream's first get_stats rides on the widening pass
@@ -117,6 +117,12 @@ struct bpe_ctx {
     int chain_levels = 0;                     // option "chain_levels": ... and into a level that holds several pairs (taken in order of first occurrence;
                                               // that level becomes the list).  UNTESTED ON A GPU (written without one): off until it is
     unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
+    int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
+    int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
+                                              // across steps) instead of k_chain_sel (one count level at a time); sharded training keeps k_chain_sel
+    int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
+    PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
+    uint32_t *d_pool_gather = nullptr;
     int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
                                               // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
     int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
@@ -887,7 +893,8 @@ inline uint32_t delta_layout(const bpe_ctx *c, uint32_t Z) {
     const uint32_t dstride = std::min<uint32_t>(c->vcap, ((Z + 1 + 63) / 64) * 64);
     const uint64_t buf_words = (uint64_t)c->vcap * 4 * DELTA_REPL;
     int shift = 0;
-    while (shift < 8 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;  // (the skew has its own room)
+    while (shift < 7 && ((uint64_t)dstride * 4 << (shift + 1)) <= buf_words) shift++;  // (the skew has its own room; a single pair's
+                                                                                          // pass uses at most 128 of the DELTA_REPL blocks)
     const uint64_t cnt = c->last_count;
     const int want = cnt >= (1u << 20) ? 8 : (cnt >= (1u << 16) ? 5 : (cnt >= (1u << 12) ? 3 : 0));
     return dstride | ((uint32_t)std::min(std::min(shift, std::max(want, c->rep_min)), c->rep_max) << 24);
@@ -1108,16 +1115,27 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     if (dense && c->dp_comm) C.T = 0;
     (void)records;
     if (!c->d_chain_req) {
-        HIPCHK(c, hipMalloc((void **)&c->d_chain_req, 64 * sizeof(unsigned long long)));
-        HIPCHK(c, hipMemsetAsync(c->d_chain_req, 0, 64 * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMalloc((void **)&c->d_chain_req, PL_REQ_WORDS * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_chain_req, 0, PL_REQ_WORDS * sizeof(unsigned long long), c->stream));
+    }
+    if (!c->d_pool) {
+        HIPCHK(c, hipMalloc((void **)&c->d_pool, PL_CAP * sizeof(PoolEnt)));
+        HIPCHK(c, hipMalloc((void **)&c->d_pool_gather, (2 + 2 * PL_GATHER) * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_pool, 0, PL_CAP * sizeof(PoolEnt), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pool_gather, 0, (2 + 2 * PL_GATHER) * sizeof(uint32_t), c->stream));
     }
     // sharded training (dp_train_loop, api_rccl.hip): the step's two collectives sit between its launches -- a tie's
     // first occurrences (MIN) before the batch is formed, the batch's delta (SUM) before the table update.  A batch
     // goes on below the maximum only when the maximum is attained by ONE pair (k_chain_sel then decides everything
     // from replicated state, as on one GPU); after a tie the list is made by k_chain_sel_dp, which stays at the maximum
     const DpComm *dp = c->dp_comm;
-    uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : CH_KMAX);
+    uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : std::min(CH_KSWEEP, c->chain_kcap));
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
+    if (c->pool && !dp)
+        hipLaunchKernelGGL(k_pool_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+                           c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
+                           kcap, c->d_pool, c->d_pool_gather, (uint32_t)(c->pool_hint > 0 ? c->pool_hint : (int)kcap));
+    else
     hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                        (uint32_t)((c->chain_extend && c->chain_scan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)

@@ -115,7 +115,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
     TRY(bpe_dp_begin(c, num_merges, comm.rank, comm.nranks));
     TRY(ensure_srec(c));
     if (!c->d_dp_ckey) HIPCHK(c, hipMalloc((void **)&c->d_dp_ckey, DP_KEY_WORDS * sizeof(long long)));
-    const uint64_t cfold_words = (uint64_t)2 * CH_KMAX * c->vcap + 64;
+    const uint64_t cfold_words = (uint64_t)2 * DP_KCAP_MAX * c->vcap + 64;
     if (cfold_words > c->cap_dp_cfold) {
         TRY(dev_realloc(c, c->d_dp_cfold, (size_t)cfold_words));
         c->cap_dp_cfold = cfold_words;

@@ -37,7 +37,7 @@ constexpr int ARGMAX_ROWS = 2048;  // rows attaining the max examined by k_selec
 constexpr uint32_t TIE_WINDOW0 = 0;  // positions k_select's block 0 searches alone on a tie (0: all blocks sweep together)
 constexpr int TIE_BLOCKS = 256;     // k_select blocks: block 0 decides, all of them sweep the stream on a tie
 constexpr int ROW_BLOCKS = 64;      // extra k_apply_delta blocks that recompute queued row maxima
-constexpr int DELTA_REPL = 128;    // replica blocks of the delta vectors (spreads hot atomics; a chain step's batch
+constexpr int DELTA_REPL = 256;    // replica blocks of the delta vectors (spreads hot atomics; a chain step's batch
                                    // gives each of its pairs CH_RSTRIDE of them, k_chain.hip)
 // Device-scope atomics execute at the memory channel that owns the address, ~11 ns apiece and ONE AT
 // A TIME per channel (measured: a pass whose atomics fall on few channels runs at a fraction of the
@@ -56,12 +56,16 @@ __host__ __device__ inline size_t delta_rep_off(uint32_t r, uint32_t stride) {
 
 // Chain steps (k_chain.hip): the tied pairs at the maximum are kept as a LIST in first-occurrence order, and the
 // longest prefix of it whose pairs have a != b and share no token -- at most CH_KMAX of them -- is merged in ONE pass.
-constexpr int CH_KMAX = 8;
+constexpr int CH_KMAX = 16;                    // (array sizes)
+constexpr int CH_KSWEEP = 15;                  // most pairs one sweep merges: a word's pair number + 1 is a nibble (merge_chain_wave)
 constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per pair of a batch: all of them while its pairs have
 constexpr uint32_t CH_REP_COUNT = 4096;        // more sites than this (hot tokens queue ~11 ns per same-address atomic) ...
 constexpr int CH_REP = 4;                      // ... this many otherwise (the table update folds every replica it is told to)
+constexpr int CH_RMV = 16;                     // removal counters per pair of a batch (of the 256)
+constexpr int DP_KCAP_MAX = 8;                 // sharded chain steps: most pairs of a batch (the SUM payload's tail keeps word 8 for the status)
 static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must fit the replica blocks");
-static_assert(CH_KMAX * 32 <= 256, "removal counters: 32 per pair of a batch");
+static_assert(CH_KMAX * CH_RMV <= 256, "removal counters of a batch");
+static_assert(CH_KSWEEP < 16 && CH_KSWEEP <= CH_KMAX, "pair number + 1 must fit a nibble");
 constexpr uint32_t CH_FULL = 0, CH_LIST = 1;   // DevState::sel_mode
 constexpr int DP_KEY_WORDS = TIE_CAP + 2;      // sharded chain steps: int64 words of the MIN all-reduce (k_chain_sel)
 
@@ -160,6 +164,11 @@ struct DevState {
     uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum: k_chain_sel)
     uint32_t brep;                // delta replicas per pair of this batch (CH_REP or CH_RSTRIDE)
     uint32_t dp_wait;             // sharded chain steps: k_chain_sel left a tie for k_chain_sel_dp to order (after the MIN all-reduce)
+    // the pool (k_pool.hip): every pair that counts pool_theta or more, pool_n entries in the ctx's pool buffer
+    uint32_t pool_n, pool_theta;
+    uint32_t pool_hint;           // the next selection launch may have to rebuild the pool: its row-scanning workgroups stay
+    uint32_t pool_pad_;
+    unsigned long long pool_epoch;  // launches that located entries so far (order keys of one epoch are comparable)
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in
     // front of block 0's own accesses to the fields above.

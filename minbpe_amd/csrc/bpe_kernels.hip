@@ -40,6 +40,7 @@
 #include "kernels/k_table.hip"
 #include "kernels/k_lean.hip"
 #include "kernels/k_chain.hip"
+#include "kernels/k_pool.hip"
 #include "kernels/k_dp.hip"
 #include "kernels/k_encode.hip"
 #include "kernels/k_decode.hip"

@@ -68,7 +68,8 @@ constexpr uint32_t CH_SD = 2 * LDSD_CAP + 2;  // words of one pair's LDS delta t
 template <bool DENSE>
 __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t, const AbArgs &A,
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
-                                                 const uint32_t K, const uint32_t z0, const uint32_t brep) {
+                                                 const uint32_t K, const uint32_t z0, const uint32_t brep,
+                                                 const uint32_t *ph = nullptr, const uint32_t hm = 0) {
     const int lane = lane_id();
     const uint32_t Tl = min(A.T, A.st->tlive);
     // ---- (1) every load that does not depend on another one -------------------------------
@@ -149,14 +150,31 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
 #pragma unroll
     for (int j = 0; j < MJ; j++) ia[j] = 0;
     uint32_t ip = 0;
-    for (uint32_t p = 0; p < K; p++) {
-        const uint32_t a = pa[p];
+    if (hm) {
+        // a batch of five pairs or more: ONE look-up per word instead of K compares -- ph is a 256-entry table in LDS,
+        // (id * hm >> 8) & 255 is free of collisions among the batch's first tokens (chain_hash_build), an entry is
+        // id << 8 | pair number + 1
+        auto code = [&](uint32_t w) -> uint32_t {
+            const uint32_t id = w & IDMASK;
+            const uint32_t e = ph[(__umul24(id, hm) >> 8) & 255u];
+            return (e >> 8) == id ? (e & 15u) : 0u;
+        };
 #pragma unroll
         for (int j = 0; j < MJ; j++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) ia[j] |= ((x[j][k] & IDMASK) == a) ? (p + 1u) << (4 * k) : 0u;
+            for (int k = 0; k < 4; k++) ia[j] |= code(x[j][k]) << (4 * k);
         }
-        ip = ((prev1 & IDMASK) == a) ? p + 1u : ip;
+        ip = code(prev1);
+    } else {
+        for (uint32_t p = 0; p < K; p++) {
+            const uint32_t a = pa[p];
+#pragma unroll
+            for (int j = 0; j < MJ; j++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) ia[j] |= ((x[j][k] & IDMASK) == a) ? (p + 1u) << (4 * k) : 0u;
+            }
+            ip = ((prev1 & IDMASK) == a) ? p + 1u : ip;
+        }
     }
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
@@ -309,8 +327,8 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
                 atomicAdd(&dl[2 * LDSD_CAP + 1], 1u);
             } else {
                 // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
-                // site, 32 counters per pair)
-                atomicAdd(&A.removed[(p * 32u + (t & 31u)) * REMOVED_STRIDE], 1u);
+                // site, CH_RMV counters per pair)
+                atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (t & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], 1u);
                 dl = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u)), vc);
                 dr = dl + vc;
             }
@@ -349,6 +367,31 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
     }
 }
 
+// The look-up table of a batch's first tokens (merge_chain_wave): wave 0 tries 64 multipliers at once, lane l its own,
+// and takes the first under which no two of the K tokens fall into the same of the 256 buckets (K <= 15: two in three
+// multipliers do); returns it to every thread (0: none found, or a batch too small to pay -- the pass compares).
+// s_ph: 256 words, s_hm: one word.  Every thread calls.
+__device__ __forceinline__ uint32_t chain_hash_build(uint32_t *s_ph, uint32_t *s_hm, const uint32_t *s_pa, uint32_t K) {
+    if (threadIdx.x < 256) s_ph[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) *s_hm = 0;
+    __syncthreads();
+    if (K >= 5 && wave_id() == 0) {
+        const uint32_t m = 129u + 2u * (uint32_t)lane_id();
+        bool ok = true;
+        for (uint32_t i = 1; i < K; i++) {
+            const uint32_t hi = (__umul24(s_pa[i], m) >> 8) & 255u;
+            for (uint32_t j = 0; j < i; j++) ok &= hi != ((__umul24(s_pa[j], m) >> 8) & 255u);
+        }
+        const unsigned long long bal = __ballot(ok);
+        if (lane_id() == 0 && bal) *s_hm = 129u + 2u * (uint32_t)(__ffsll((long long)bal) - 1);
+    }
+    __syncthreads();
+    const uint32_t hm = *s_hm;
+    if (hm && threadIdx.x < K) s_ph[(__umul24(s_pa[threadIdx.x], hm) >> 8) & 255u] = (s_pa[threadIdx.x] << 8) | (threadIdx.x + 1u);
+    __syncthreads();
+    return hm;
+}
+
 // ---------------------------------------------------------------------------
 // merge pass of a chain step: k_merge_ab_lean for the st->bk pairs of the batch (index live)
 __global__ void __launch_bounds__(LEAN_MT)
@@ -357,6 +400,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     __shared__ uint32_t s_list[LEAN_SUB * 32];
     __shared__ uint32_t s_tot[2];
     __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
+    __shared__ uint32_t s_ph[256], s_hm;
     DevState *st = A.st;
     // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
     const uint32_t ran = st->sel_ran;
@@ -375,6 +419,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
         if (threadIdx.x == 0) s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
     }
     __syncthreads();
+    const uint32_t hm = chain_hash_build(s_ph, &s_hm, s_pa, K);
     const uint32_t Tl = min(A.T, st->tlive);
     constexpr uint32_t NWV = LEAN_MT / 64;
     // a batch of one: the single-pair rewrite (merge_ab_wave, k_slots2.hip) -- no per-pair loops, format B's
@@ -384,7 +429,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
         if (K == 1) merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
-        else merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep);
+        else merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, s_ph, hm);
     };
     if (!use_index || st->gap != 0) {  // short slots about: visit everything
         const uint32_t nw = gridDim.x * NWV;
@@ -485,7 +530,7 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
         if (threadIdx.x == 0) {
             const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
             if (adj) atomicAdd(&st->badj[p], adj);
-            if (rem) atomicAdd(&A.removed[(p * 32u + (blockIdx.x & 31u)) * REMOVED_STRIDE], rem);
+            if (rem) atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (blockIdx.x & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], rem);
         }
     }
 }
@@ -585,67 +630,71 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             if (live && t == b) mat[(size_t)a * stride + b] = 0;  // no (a,b) survives the merge (F2)
             flagged |= live && ((t == a) | (t == b) | (t == Z));
         } else {
-            // ---- a batch: brep replicas per pair ------------------------------------------------------------
+            // ---- a batch: brep replicas per pair, eight pairs' worth of loads in flight at a time -------------------------
             const uint32_t brep = folded ? 0u : st->brep;
-            uint32_t x[CH_KMAX][CH_REP][2];
-            if (brep == (uint32_t)CH_REP) {  // (everything in flight at once)
+            constexpr int G = 8;
+            for (uint32_t g = 0; g < K; g += G) {  // (uniform)
+                uint32_t x[G][CH_REP][2];
+                if (brep == (uint32_t)CH_REP) {
 #pragma unroll
-                for (int p = 0; p < CH_KMAX; p++) {
+                    for (int q = 0; q < G; q++) {
 #pragma unroll
-                    for (int r = 0; r < CH_REP; r++) {
-                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                        x[p][r][0] = (live && (uint32_t)p < K) ? delta[o + t] : 0u;
-                        x[p][r][1] = (live && (uint32_t)p < K) ? delta[o + vc + t] : 0u;
+                        for (int r = 0; r < CH_REP; r++) {
+                            const size_t o = delta_rep_off((g + (uint32_t)q) * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+                            x[q][r][0] = (live && g + (uint32_t)q < K) ? delta[o + t] : 0u;
+                            x[q][r][1] = (live && g + (uint32_t)q < K) ? delta[o + vc + t] : 0u;
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int p = 0; p < CH_KMAX; p++) {
-                if ((uint32_t)p >= K) break;  // (uniform)
-                const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + (uint32_t)p;
-                const uint32_t adj = folded ? ftail[p] : st->badj[p];
-                uint32_t sl = 0, sr = 0;
-                if (folded) {
-                    sl = live ? folded[(size_t)(2 * p) * fS + t] : 0u;
-                    sr = live ? folded[(size_t)(2 * p + 1) * fS + t] : 0u;
-                } else if (brep == (uint32_t)CH_REP) {
+                for (int q = 0; q < G; q++) {
+                    const uint32_t p = g + (uint32_t)q;
+                    if (p >= K) break;  // (uniform)
+                    const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + p;
+                    const uint32_t adj = folded ? ftail[p] : st->badj[p];
+                    uint32_t sl = 0, sr = 0;
+                    if (folded) {
+                        sl = live ? folded[(size_t)(2 * p) * fS + t] : 0u;
+                        sr = live ? folded[(size_t)(2 * p + 1) * fS + t] : 0u;
+                    } else if (brep == (uint32_t)CH_REP) {
 #pragma unroll
-                    for (int r = 0; r < CH_REP; r++) {
-                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                        if (x[p][r][0]) delta[o + t] = 0;
-                        if (x[p][r][1]) delta[o + vc + t] = 0;
-                        sl += x[p][r][0];
-                        sr += x[p][r][1];
+                        for (int r = 0; r < CH_REP; r++) {
+                            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+                            if (x[q][r][0]) delta[o + t] = 0;
+                            if (x[q][r][1]) delta[o + vc + t] = 0;
+                            sl += x[q][r][0];
+                            sr += x[q][r][1];
+                        }
+                    } else {  // (pairs with thousands of sites: all CH_RSTRIDE replicas, one pair at a time)
+                        uint32_t y[CH_RSTRIDE][2];
+#pragma unroll
+                        for (int r = 0; r < CH_RSTRIDE; r++) {
+                            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+                            y[r][0] = live ? delta[o + t] : 0u;
+                            y[r][1] = live ? delta[o + vc + t] : 0u;
+                        }
+#pragma unroll
+                        for (int r = 0; r < CH_RSTRIDE; r++) {
+                            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+                            if (y[r][0]) delta[o + t] = 0;
+                            if (y[r][1]) delta[o + vc + t] = 0;
+                            sl += y[r][0];
+                            sr += y[r][1];
+                        }
                     }
-                } else {  // (pairs with thousands of sites: all CH_RSTRIDE replicas, one pair at a time)
-                    uint32_t y[CH_RSTRIDE][2];
-#pragma unroll
-                    for (int r = 0; r < CH_RSTRIDE; r++) {
-                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                        y[r][0] = live ? delta[o + t] : 0u;
-                        y[r][1] = live ? delta[o + vc + t] : 0u;
+                    const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
+                    if (sl) {
+                        // (the value before: decides whether row t's maximum may have moved.  Rows of the batch's own
+                        // tokens are flagged anyway, every other row is touched by this thread alone)
+                        const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], sl);
+                        atomicAdd(&mat[(size_t)t * stride + Z], sl);
+                        flagged |= old == rm.x;
                     }
-#pragma unroll
-                    for (int r = 0; r < CH_RSTRIDE; r++) {
-                        const size_t o = delta_rep_off((uint32_t)(p * CH_RSTRIDE + r), vc);
-                        if (y[r][0]) delta[o + t] = 0;
-                        if (y[r][1]) delta[o + vc + t] = 0;
-                        sl += y[r][0];
-                        sr += y[r][1];
-                    }
+                    if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
+                    if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
+                    if (live && t == b) mat[(size_t)a * stride + b] = 0;
+                    flagged |= live && ((t == a) | (t == b) | (t == Z));
                 }
-                const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
-                if (sl) {
-                    // (the value before: decides whether row t's maximum may have moved.  Rows of the batch's own
-                    // tokens are flagged anyway, every other row is touched by this thread alone)
-                    const uint32_t old = atomicSub(&mat[(size_t)t * stride + a], sl);
-                    atomicAdd(&mat[(size_t)t * stride + Z], sl);
-                    flagged |= old == rm.x;
-                }
-                if (dr) atomicSub(&mat[(size_t)b * stride + t], dr);
-                if (ir) atomicAdd(&mat[(size_t)Z * stride + t], ir);
-                if (live && t == b) mat[(size_t)a * stride + b] = 0;
-                flagged |= live && ((t == a) | (t == b) | (t == Z));
             }
         }
         if (flagged && !prevflag) atomicOr(&dbits[t >> 5], 1u << (t & 31));
@@ -662,8 +711,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
         return;
     }
     if (blockIdx.x == na && threadIdx.x < 64) {
-        // ids removed by the merge pass: 32 counters per pair of the batch, one per 256-byte line (lane l: counters
-        // 4l .. 4l + 3, all of pair l / 8)
+        // ids removed by the merge pass: CH_RMV counters per pair of the batch, one per 256-byte line (lane l: counters
+        // 4l .. 4l + 3, all of pair l / 4)
         uint32_t v = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -671,12 +720,12 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
             v += x;
         }
+        static_assert(CH_RMV == 16, "lanes 4p .. 4p + 3 hold the removals of pair p");
         v += (uint32_t)__shfl_xor((int)v, 1);
         v += (uint32_t)__shfl_xor((int)v, 2);
-        v += (uint32_t)__shfl_xor((int)v, 4);  // lanes 8p .. 8p + 7 hold the removals of pair p
         uint32_t rem[CH_KMAX];
 #pragma unroll
-        for (int p = 0; p < CH_KMAX; p++) rem[p] = (uint32_t)__shfl((int)v, 8 * p);
+        for (int p = 0; p < CH_KMAX; p++) rem[p] = (uint32_t)__shfl((int)v, 4 * p);
         if (K == 1) {  // (a pair merged alone spreads over all the counters)
             uint32_t tot = 0;
 #pragma unroll
@@ -1470,6 +1519,9 @@ __global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
     st->scan_a = st->scan_b = st->scan_z = NOROW;  // (rows to re-scan are named by the flag words alone)
     st->chain_n = 0;
     st->dp_wait = 0;
+    st->pool_n = 0;  // (k_pool.hip: the first selection gathers the pool)
+    st->pool_hint = 1;
+    st->pool_epoch = 0;
 }
 // host: a deferred chain step is about to be re-run through the general path
 __global__ void k_clear_defer_chain(DevState *st) {
@@ -1479,6 +1531,8 @@ __global__ void k_clear_defer_chain(DevState *st) {
     st->tl_n = st->tl_skip = 0;
     st->bk = 0;
     st->dp_wait = 0;
+    st->pool_n = 0;  // (the general path's merge is not one the pool was maintained for)
+    st->pool_hint = 1;
 }
 
 }  // namespace bpe

@@ -1,0 +1,568 @@
+// k_pool.hip -- K2 of a chain step, third form: THE POOL.
+//
+// k_chain_sel (k_chain.hip) keeps the pairs tied at the maximum as a list and needs a FULL selection -- every flagged
+// row re-scanned, the row maxima read, the tied pairs located through the index -- once per count level, ~25 us against
+// ~5 us for a step that takes its pairs off the list; and only a FULL selection can walk below its level.  Late in
+// training a level holds three or four pairs, so most steps are FULL ones and most batches are cut short by the end of
+// their level, not by a shared token.
+//
+// The pool is the list generalised to EVERY pair that counts at least a threshold theta (tests/test_pool_model.py: the
+// CPU model of exactly this, against the reference semantics of base.py:13-41, basic.py:31-42, regex.py:49-63):
+//   invariant   every pair with count >= theta is an entry, with its exact count;
+//   order key   epoch << 40 | first-occurrence position: positions taken in one launch (one epoch) are a valid relative
+//               order for as long as the entries stay untouched; keys of different epochs are never compared;
+//   a step      maintain (below) -> sort by (count descending, key) -> the levels the walk can reach that hold several
+//               entries and are not CLEAN (all entries of one epoch) are located afresh through the index, all at once
+//               -> the batch = the longest prefix with a != b and no shared token (tests/test_level_model.py: walking
+//               the levels from the top, inside a level in order of first occurrence, is what the reference merges) ->
+//               the rest of the entries is the pool of the next step;
+//   maintain    after a batch, an entry (x, y) with x the SECOND token of a batch pair (-> Zx) or y the FIRST token of
+//               one (-> Zy) has its occurrences spread over (x, y), (Zx, y), (x, Zy), (Zx, Zy): each of the four that
+//               counts >= theta in the updated table is an entry; the one whose count EQUALS the entry's old count
+//               took over every occurrence and stands where the entry stood (it inherits the key), the others have no
+//               order.  Every other entry is untouched.  No pair from outside the pool can reach theta: a created pair
+//               (L, Z) / (Z, R) / (Zi, Zj) counts at most what (L, a) / (b, R) / (bi, aj) counted before;
+//   rebuild     pool (nearly) empty: the flagged rows are re-scanned (workgroups 1..), the deciding workgroup picks a new
+//               theta from the row maxima -- the deepest of eight candidates M - (M >> s) that at most PL_ROWS rows
+//               reach --, hands those rows to workgroups 1.., which gather every entry >= theta of their rows.
+// A step that takes its pairs off the pool is one workgroup and two dependent round trips (entries, then the table
+// words of the touched ones) plus the index look-ups of the levels that need an order; a rebuild is announced one step
+// ahead (st->pool_hint, set when fewer untouched entries than `hint_below` are left) so that the scanning workgroups
+// know at launch whether to stay.
+// Part of bpe_kernels.hip, which includes the parts in order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../bpe_device.h"
+#include "k_chain.hip"
+
+namespace bpe {
+
+constexpr uint32_t PL_CAP = 128;      // entries the pool holds
+constexpr uint32_t PL_ROWS = 64;      // rows a rebuild hands to the scanning workgroups
+constexpr uint32_t PL_GATHER = 512;   // pairs a rebuild may gather (and 4 x PL_CAP: what maintain can make of a full pool)
+static_assert(PL_GATHER >= 4 * PL_CAP, "maintain: four variants per entry");
+// request / answer words of a rebuild (all self-validating: tag << 32 | value, the launch tag never repeats):
+// [0] = rows to scan (0: the scanning workgroups are dismissed), [1 + j] = row j, [1 + PL_ROWS] = theta,
+// [2 + PL_ROWS + w] = workgroup w has gathered its rows
+constexpr uint32_t PL_REQ_WORDS = 2 + PL_ROWS + 256;
+struct PoolEnt {
+    uint32_t xy, c;            // x << 16 | y (training ids are below 65536), the pair's count
+    unsigned long long key;    // epoch << 40 | first-occurrence position; 0 = no order known
+};
+
+// entries ranked by count (descending; equal counts keep their order): out[rank] = in[i].  n <= PL_GATHER, every thread
+// calls.  The order INSIDE a level is made later, from the keys, by a loop over the level alone.
+__device__ __forceinline__ void pool_sort(const uint32_t *ixy, const uint32_t *ic, const unsigned long long *ikey,
+                                          uint32_t *oxy, uint32_t *oc, unsigned long long *okey, uint32_t n) {
+    const uint32_t i = threadIdx.x;
+    if (i < n) {
+        const uint32_t c = ic[i];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t cj = ic[j];
+            r += (cj > c) | ((cj == c) & (j < i));
+        }
+        oxy[r] = ixy[i];
+        oc[r] = c;
+        okey[r] = ikey[i];
+    }
+    __syncthreads();
+}
+// a level (entries [lo, hi) of a pool sorted by count) needs an order it does not have: several entries, not all of one epoch
+__device__ __forceinline__ uint32_t pool_level_dirty(const unsigned long long *key, uint32_t lo, uint32_t hi) {
+    if (hi - lo <= 1) return 0u;
+    const unsigned long long e0 = key[lo] >> 40;
+    uint32_t d = e0 == 0;
+    for (uint32_t j = lo + 1; j < hi; j++) d |= (key[j] >> 40) != e0;
+    return d;
+}
+
+__global__ void __launch_bounds__(1024)
+k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
+           CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+           unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
+           uint32_t hint_below) {
+    __shared__ unsigned long long s_red[32];
+    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
+    __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
+    __shared__ uint32_t a_xy[PL_GATHER], a_c[PL_GATHER], b_xy[PL_GATHER], b_c[PL_GATHER];
+    __shared__ unsigned long long a_key[PL_GATHER], b_key[PL_GATHER];
+    __shared__ uint32_t s_ls[PL_CAP], s_le[PL_CAP], s_dirty[PL_CAP], s_clash[PL_CAP];
+    __shared__ int32_t s_tied[2 * TIE_CAP];
+    __shared__ unsigned long long s_pos[TIE_CAP];
+    __shared__ uint32_t s_lidx[TIE_CAP];
+    __shared__ uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[2];
+    __shared__ uint32_t s_fail, s_n, s_theta, s_nrows, s_nl, s_reach, s_k, s_unt, s_x;
+    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
+    const uint32_t iter = st->iter, nm = st->num_merges, hint = st->pool_hint;
+    const uint32_t tid = threadIdx.x;
+    if (status || defer) return;
+    if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
+        if (blockIdx.x == 0 && tid == 0) st->bk = 0;
+        return;
+    }
+    const uint32_t vcur = 256u + iter;
+    const DirtyView D{s_words, s_pref};
+    // ================= workgroups 1..: a rebuild's row work (only in a launch that was told to expect one) ===========
+    if (blockIdx.x != 0) {
+        if (!hint) return;
+        const uint32_t nd = dirty_view_build(dbits, D);
+        if (nd) lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
+                               true, s_red, 3);
+        if (tid == 0) {
+            uint32_t n = 0, th = 0;
+            if (!granule_get(req, tag, n)) n = 0;  // (never asked: the deciding workgroup reports its own failures)
+            if (n && !granule_get(req + 1 + PL_ROWS, tag, th)) n = 0;
+            s_n = n;
+            s_theta = th;
+        }
+        __syncthreads();
+        const uint32_t n = s_n, theta = s_theta;
+        if (blockIdx.x - 1 >= n) return;
+        for (uint32_t j = blockIdx.x - 1; j < n; j += gridDim.x - 1) {
+            if (tid == 0) {
+                uint32_t x = 0;
+                s_x = granule_get(req + 1 + j, tag, x) ? x : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            const uint32_t x = s_x;
+            if (x != 0xFFFFFFFFu) {
+                const uint32_t *row = mat + (size_t)x * stride;
+                const uint32_t n4 = (vcur + 3) & ~3u;
+                constexpr int U = 8;
+                for (uint32_t base = 0; base < n4; base += U * 4096) {
+                    uint4 q[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t y = base + ((uint32_t)u * 1024u + tid) * 4u;
+                        q[u] = (y < n4) ? *reinterpret_cast<const uint4 *>(row + y) : make_uint4(0u, 0u, 0u, 0u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t y = base + ((uint32_t)u * 1024u + tid) * 4u;
+                        const uint32_t v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (v[k] >= theta && y + k < vcur) {
+                                const uint32_t s = atomicAdd(&gather[0], 1u);
+                                if (s < PL_GATHER) {
+                                    __hip_atomic_store(&gather[2 + 2 * s], (x << 16) | (y + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(&gather[3 + 2 * s], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // (s_x is rewritten by the next round)
+        }
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) granule_put(req + 2 + PL_ROWS + blockIdx.x, tag, 1u);
+        return;
+    }
+    // ================= the deciding workgroup ========================================================================
+    auto dismiss = [&]() {
+        if (hint && tid == 0) granule_put(req, tag, 0u);
+    };
+    uint32_t rm[SEL_RPT];
+    if (hint) select_load(rowmax, vcur, rm);  // (a rebuild is likely: the row maxima travel while the pool is looked at)
+    uint32_t theta = st->pool_theta;
+    unsigned long long epoch = st->pool_epoch;
+    const uint32_t n0 = min(st->pool_n, PL_CAP);
+    if (tid == 0) {
+        s_fail = 0;
+        s_nrows = 0;
+        s_nl = 0;
+        s_unt = 0;
+    }
+    if (tid < 8) s_cnt[tid] = 0;
+    // ---- maintain: what the last batch made of my entry ------------------------------------------------------------
+    uint32_t vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0}, keepm = 0, ec = 0;
+    unsigned long long ekey = 0;
+    if (tid < n0) {
+        const uint32_t Kp = st->bk, zp = st->bz0;
+        const PoolEnt e = pool[tid];
+        const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
+        ec = e.c;
+        ekey = e.key;
+        int32_t zx = -1, zy = -1;
+        for (uint32_t p = 0; p < Kp; p++) {
+            if ((uint32_t)st->bb[p] == x) zx = (int32_t)(zp + p);
+            if ((uint32_t)st->ba[p] == y) zy = (int32_t)(zp + p);
+        }
+        vx[0] = vx[2] = x;
+        vx[1] = vx[3] = zx >= 0 ? (uint32_t)zx : x;
+        vy[0] = vy[1] = y;
+        vy[2] = vy[3] = zy >= 0 ? (uint32_t)zy : y;
+        if (zx < 0 && zy < 0) {  // shares no token that matters: untouched
+            cv[0] = e.c;
+            keepm = 1u;
+        } else {
+            const bool on[4] = {true, zx >= 0, zy >= 0, zx >= 0 && zy >= 0};
+#pragma unroll
+            for (int v = 0; v < 4; v++) cv[v] = on[v] ? mat[(size_t)vx[v] * stride + vy[v]] : 0u;
+#pragma unroll
+            for (int v = 0; v < 4; v++) keepm |= (on[v] && cv[v] >= theta) ? 1u << v : 0u;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t no = (uint32_t)__popc(keepm);
+        const uint32_t inc = wave_iscan_add(no);
+        if (tid < 128 && lane_id() == 63) s_wtot[wave_id()] = inc;
+        __syncthreads();
+        if (tid < 128) {
+            uint32_t o = inc - no + (wave_id() == 1 ? s_wtot[0] : 0u);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                if ((keepm >> v) & 1u) {
+                    a_xy[o] = (vx[v] << 16) | vy[v];
+                    a_c[o] = cv[v];
+                    a_key[o] = cv[v] == ec ? ekey : 0ull;  // took over every occurrence: stands where the entry stood
+                    o++;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    uint32_t n1 = n0 ? s_wtot[0] + s_wtot[1] : 0u;
+    bool rebuilt = false;
+    // (a hinted launch -- the scanning workgroups stayed -- whose pool could not fill a batch any more gathers a fresh,
+    // deeper one instead of merging the last few entries in small batches: the old entries are in it, without their keys)
+    if (hint && n1 < min(kcap, nm - iter)) n1 = 0;
+    if (n1 == 0) {
+        if (!hint) {  // nobody stayed to scan rows: this step merges nothing, the next one rebuilds
+            if (tid == 0) {
+                st->bk = 0;
+                st->found = 0;
+                st->pool_n = 0;
+                st->pool_hint = 1;
+                st->sel_mode = CH_LIST;
+                st->tl_n = st->tl_skip = 0;
+            }
+            return;
+        }
+        // ---- rebuild ---------------------------------------------------------------------------------------------
+        rebuilt = true;
+        const uint32_t nd = dirty_view_build(dbits, D);
+        if (tid == 0) st->sel_ran = 1;  // (this launch re-scans every flagged row)
+        if (nd > CH_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
+            if (tid == 0) {
+                st->found = 0;
+                st->bk = 0;
+                st->defer = 2;
+            }
+            dismiss();
+            return;
+        }
+        for (uint32_t i = tid; i < nd; i += 1024) {
+            const uint32_t x = dirty_view_row(D, i);
+            uint32_t m = 0, arg = 0;
+            const bool ok = granule_get(res + 2 * (size_t)i, tag, m) && granule_get(res + 2 * (size_t)i + 1, tag, arg);
+            if (!ok) s_fail = 1;
+            s_exrow[i] = x;
+            s_exm[i] = m;
+            s_exarg[i] = arg;
+        }
+        __syncthreads();
+        if (s_fail) {  // a row never arrived: never decide on a stale maximum
+            if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
+            dismiss();
+            return;
+        }
+        const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
+        auto stale = [&](uint32_t x) -> bool { return (s_words[x >> 5] >> (x & 31)) & 1u; };
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < SEL_RPT; i++) {
+            const uint32_t x = tid + 1024u * (uint32_t)i;
+            if (x >= vcur || stale(x)) rm[i] = 0u;
+            m = max(m, rm[i]);
+        }
+        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024)
+            if (!stale(x)) m = max(m, rowma[x].x);
+        for (uint32_t i = tid; i < nd; i += 1024) m = max(m, s_exm[i]);
+        m = wave_umax_dpp(m);
+        if (lane_id() == 0) s_r16[wave_id()] = m;
+        __syncthreads();
+        uint32_t M = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) M = max(M, s_r16[w]);
+        if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
+            if (tid == 0) {
+                st->status = ST_EMPTY;
+                st->count = 0;
+                st->found = 0;
+                st->bk = 0;
+                st->sel_tie = 0;
+            }
+            dismiss();
+            return;
+        }
+        // eight candidate thresholds, deepest first: M - M/4, M - M/8, ..., M - M/256, M; rows that reach each
+        uint32_t th[8], cn[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            th[k] = k < 7 ? M - (M >> (2 + k)) : M;
+            cn[k] = 0;
+        }
+        auto tally = [&](uint32_t v) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) cn[k] += v >= th[k];
+        };
+#pragma unroll
+        for (int i = 0; i < SEL_RPT; i++) tally(rm[i]);
+        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024)
+            if (!stale(x)) tally(rowma[x].x);
+        for (uint32_t i = tid; i < nd; i += 1024) tally(s_exm[i]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t s = wave_sum_u32(cn[k]);
+            if (lane_id() == 0 && s) atomicAdd(&s_cnt[k], s);
+        }
+        __syncthreads();
+        int ks = -1;
+#pragma unroll
+        for (int k = 7; k >= 0; k--)
+            if (s_cnt[k] <= PL_ROWS) ks = k;  // (the deepest threshold that few enough rows reach)
+        if (ks < 0) {  // more rows at the maximum itself than a rebuild scans: the general path decides
+            if (tid == 0) {
+                st->count = M;
+                st->found = 0;
+                st->bk = 0;
+                st->defer = 2;
+            }
+            dismiss();
+            return;
+        }
+        theta = th[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) theta = (k == ks) ? th[k] : theta;
+        if (ks == 0) theta = th[0];
+        auto row_in = [&](uint32_t x, uint32_t v) {
+            if (v >= theta) {
+                const uint32_t s = atomicAdd(&s_nrows, 1u);
+                if (s < PL_ROWS) s_rows[s] = x;
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < SEL_RPT; i++) row_in(tid + 1024u * (uint32_t)i, rm[i]);
+        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024)
+            if (!stale(x)) row_in(x, rowma[x].x);
+        for (uint32_t i = tid; i < nd; i += 1024) row_in(s_exrow[i], s_exm[i]);
+        if (tid == 0) __hip_atomic_store(&gather[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+        const uint32_t nrows = min(s_nrows, PL_ROWS);
+        if (tid < nrows) granule_put(req + 1 + tid, tag, s_rows[tid]);
+        if (tid == 0) {
+            granule_put(req + 1 + PL_ROWS, tag, theta);
+            granule_put(req, tag, nrows);
+        }
+        const uint32_t nh = min(gridDim.x - 1, nrows);
+        if (tid < nh) {
+            uint32_t d = 0;
+            if (!granule_get(req + 2 + PL_ROWS + (tid + 1), tag, d)) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) {
+            if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
+            return;
+        }
+        const uint32_t ng = __hip_atomic_load(&gather[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ng > PL_GATHER || ng == 0) {  // (more pairs at theta or above than a rebuild looks at: the general path decides this merge)
+            if (tid == 0) {
+                st->count = M;
+                st->found = 0;
+                st->bk = 0;
+                if (ng) st->defer = 2; else atomicExch(&st->status, ST_INTERNAL);
+            }
+            return;
+        }
+        if (tid < ng) {
+            a_xy[tid] = __hip_atomic_load(&gather[2 + 2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a_c[tid] = __hip_atomic_load(&gather[3 + 2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a_key[tid] = 0ull;
+        }
+        n1 = ng;
+        __syncthreads();
+    } else {
+        dismiss();  // (a hinted launch whose pool still holds entries: the row scans were not needed)
+        if (hint && tid == 0) st->sel_ran = 1;  // (... but workgroups 1.. do re-scan every flagged row)
+    }
+    // ---- sort by count; more entries than the pool holds: whole levels leave from the bottom, theta rises above them ----
+    pool_sort(a_xy, a_c, a_key, b_xy, b_c, b_key, n1);
+    uint32_t n = n1;
+    if (n1 > PL_CAP) {
+        if (tid == 0) {
+            uint32_t cut = PL_CAP;
+            while (cut > 0 && b_c[cut - 1] == b_c[cut]) cut--;
+            s_n = cut;
+        }
+        __syncthreads();
+        n = s_n;
+        if (n == 0) {  // one level larger than the pool: the general path decides
+            if (tid == 0) {
+                st->count = b_c[0];
+                st->found = 0;
+                st->bk = 0;
+                st->defer = 2;
+                st->pool_n = 0;
+                st->pool_hint = 1;
+            }
+            return;
+        }
+        theta = b_c[n] + 1;
+        __syncthreads();
+    }
+    // ---- the levels the walk can reach; the ones that need an order are located through the index ----------------------
+    const uint32_t kmax = min(kcap, nm - iter);
+    const uint32_t nwalk = min(n, kmax);  // the batch is a prefix of at most this many entries
+    if (tid < n) {
+        const uint32_t ci = b_c[tid];
+        uint32_t lo = tid, hi = tid + 1;
+        while (lo > 0 && b_c[lo - 1] == ci) lo--;
+        while (hi < n && b_c[hi] == ci) hi++;
+        s_ls[tid] = lo;
+        s_le[tid] = hi;
+        s_dirty[tid] = pool_level_dirty(b_key, lo, hi);
+        if (tid < nwalk) {  // does this entry end a batch that reaches its level (a == b, or a token shared with anything above its level's end)?
+            const uint32_t x = b_xy[tid] >> 16, y = b_xy[tid] & 0xFFFFu;
+            uint32_t cl = x == y;
+            for (uint32_t j = 0; j < hi; j++) {
+                const uint32_t xj = b_xy[j] >> 16, yj = b_xy[j] & 0xFFFFu;
+                cl |= (j != tid) & ((xj == x) | (xj == y) | (yj == x) | (yj == y));
+            }
+            s_clash[tid] = cl;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t lim = nwalk - 1u;
+        for (uint32_t i = 0; i <= lim; i++)
+            if (s_clash[i]) {
+                lim = i;
+                break;
+            }
+        const uint32_t reach = s_le[lim];
+        uint32_t nl = 0;
+        if (C.T != 0 && gap == 0) {
+            // every level the walk can reach that lacks an order -- and, while the round of sixteen waves has room, the
+            // next ones below (the same latency now, a clean level when the walk gets there)
+            const uint32_t scan_end = min(n, reach + 48u);
+            for (uint32_t i = 0; i < scan_end; i = s_le[i]) {
+                if (!s_dirty[i]) continue;
+                const uint32_t size = s_le[i] - i;
+                if (i >= reach && nl + size > 16u) break;
+                if (nl + size > (uint32_t)TIE_CAP) break;  // (this level does not fit: the walk stops before it)
+                for (uint32_t j = i; j < i + size; j++) {
+                    s_tied[2 * nl] = (int32_t)(b_xy[j] >> 16);
+                    s_tied[2 * nl + 1] = (int32_t)(b_xy[j] & 0xFFFFu);
+                    s_lidx[nl] = j;
+                    nl++;
+                }
+            }
+        }
+        s_nl = nl;
+    }
+    __syncthreads();
+    const uint32_t nl = s_nl;
+    if (nl) {
+        (void)tie_by_index(ref, C, s_tied, nl, s_pos);
+        __syncthreads();
+        epoch++;
+        if (tid < nl) b_key[s_lidx[tid]] = s_pos[tid] != NOPOS ? (epoch << 40) | s_pos[tid] : 0ull;
+        __syncthreads();
+    }
+    // ---- the order inside every level: by key (a level whose keys are not of one epoch stays without an order) ----------
+    if (tid < n) {
+        const uint32_t lo = s_ls[tid], hi = s_le[tid];
+        const unsigned long long k = b_key[tid];
+        uint32_t r = lo;
+        for (uint32_t j = lo; j < hi; j++) {
+            const unsigned long long kj = b_key[j];
+            r += (kj < k) | ((kj == k) & (j < tid));
+        }
+        a_xy[r] = b_xy[tid];
+        a_c[r] = b_c[tid];
+        a_key[r] = k;
+        s_dirty[r] = pool_level_dirty(b_key, lo, hi);
+    }
+    __syncthreads();
+    // ---- the batch: the longest prefix with a != b, no shared token, every level it enters in a known order -------------
+    if (tid < nwalk) {
+        const uint32_t x = a_xy[tid] >> 16, y = a_xy[tid] & 0xFFFFu;
+        uint32_t bad = (x == y) | s_dirty[tid];
+        for (uint32_t j = 0; j < tid; j++) {
+            const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
+            bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
+        }
+        s_clash[tid] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t k = 0;
+        while (k < nwalk && !s_clash[k]) k++;
+        s_k = k;
+    }
+    __syncthreads();
+    const uint32_t K = s_k;
+    if (tid == 0) {
+        st->adj = 0;
+        st->count = a_c[0];
+        st->ntied = s_le[0];
+        st->firstpos = NOPOS;
+        st->sel_tie = 0;
+        st->a = (int32_t)(a_xy[0] >> 16);
+        st->b = (int32_t)(a_xy[0] & 0xFFFFu);
+        st->fin_a = st->a;
+        st->fin_b = st->b;
+        st->bk = K;
+        st->bz0 = 256u + iter;
+        st->tl_n = st->tl_skip = 0;
+        st->sel_mode = rebuilt ? CH_FULL : CH_LIST;  // (statistics: what kind of step this was)
+        if (K == 0) {
+            st->found = 0;
+            // a == b at the head: the general path's merge | a level the step cannot order: the general path's selection
+            st->defer = ((a_xy[0] >> 16) == (a_xy[0] & 0xFFFFu) && !s_dirty[0]) ? 1u : 2u;
+            st->pool_n = 0;
+            st->pool_hint = 1;
+        } else {
+            st->found = 1;
+            uint32_t cmax = 0;
+            for (uint32_t i = 0; i < K; i++) {
+                st->ba[i] = (int32_t)(a_xy[i] >> 16);
+                st->bb[i] = (int32_t)(a_xy[i] & 0xFFFFu);
+                st->badj[i] = 0;
+                st->bcnt[i] = a_c[i];
+                cmax = max(cmax, a_c[i]);
+            }
+            st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
+        }
+    }
+    if (K == 0) return;
+    // ---- the rest is the next step's pool ----------------------------------------------------------------------------------
+    if (tid >= K && tid < n) {
+        PoolEnt e;
+        e.xy = a_xy[tid];
+        e.c = a_c[tid];
+        e.key = a_key[tid];
+        pool[tid - K] = e;
+        const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
+        bool touched = false;
+        for (uint32_t p = 0; p < K; p++) touched |= ((a_xy[p] & 0xFFFFu) == x) | ((a_xy[p] >> 16) == y);
+        if (!touched) atomicAdd(&s_unt, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st->pool_n = n - K;
+        st->pool_theta = theta;
+        st->pool_epoch = epoch;
+        st->pool_hint = s_unt < hint_below ? 1u : 0u;
+    }
+}
+
+}  // namespace bpe

@@ -21,7 +21,7 @@ def short(name):
     return s
 
 
-SEL = ("k_select<", "k_rowsel_lean", "k_sel_lean", "k_chain_sel")
+SEL = ("k_select<", "k_rowsel_lean", "k_sel_lean", "k_chain_sel", "k_pool_sel")
 it = -1
 per = defaultdict(lambda: defaultdict(lambda: [0, 0.0, []]))  # bin -> kernel -> [calls, us, durations]
 span = defaultdict(lambda: [None, None, 0])
