@@ -250,7 +250,9 @@ int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
  * merges they handed back to the general path (pairs with a == b, ties they could not settle), out[6] = merges
  * that needed no selection of their own (their pair came off the list of tied pairs an earlier selection made:
  * the reference merges those in order of first occurrence while their counts stand), out[7] = chain steps,
- * out[8] = chain steps that selected (the others took their pairs off the list).  Writes min(n, 9) values. */
+ * out[8] = chain steps that selected (gathered the pool of pairs anew; the others took their pairs off it), out[9] = ids
+ * per slot the stream ended in (1024; 256 once it was re-packed for sparse passes, option "small_slots").  Writes
+ * min(n, 10) values. */
 int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */

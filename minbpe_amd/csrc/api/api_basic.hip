@@ -41,8 +41,8 @@ int bpe_create(int device_id, bpe_ctx **out) {
             return bail("hipFuncSetAttribute(dynamic LDS)", e);
     if ((e = hipFuncSetAttribute((const void *)k_load_count, hipFuncAttributeMaxDynamicSharedMemorySize, LC_LDS_BYTES)) != hipSuccess)
         return bail("hipFuncSetAttribute(dynamic LDS)", e);
-    if ((e = hipFuncSetAttribute((const void *)k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 IDX_H * 4)) != hipSuccess)
+    if ((e = hipFuncSetAttribute((const void *)bpe::bpe_g4::k_index_build, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 bpe::bpe_g4::IDX_H * 4)) != hipSuccess)
         return bail("hipFuncSetAttribute(dynamic LDS)", e);
     if ((e = hipMalloc((void **)&c->d_st, sizeof(DevState))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void **)&c->d_scratch, 4 * sizeof(unsigned long long))) != hipSuccess)
@@ -163,6 +163,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "small_slots")) {
+        if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "small_slots: 0, 1 or 2");
+        c->small_slots = (int)value;
     } else if (!strcmp(name, "chain_kcap")) {
         if (value < 1 || value > CH_KSWEEP) return fail(c, BPE_E_ARG, "chain_kcap must be 1..%d", CH_KSWEEP);
         c->chain_kcap = (int)value;

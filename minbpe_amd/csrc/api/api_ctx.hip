@@ -117,6 +117,11 @@ struct bpe_ctx {
     int chain_levels = 0;                     // option "chain_levels": ... and into a level that holds several pairs (taken in order of first occurrence;
                                               // that level becomes the list).  UNTESTED ON A GPU (written without one): off until it is
     unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
+    int ts = TILE2_MAX;                       // ids per slot of the second slotted form as the stream stands: 1024 (kernels of namespace bpe_g4)
+                                              // or 256 (bpe_g1) -- see GK below
+    int small_slots = 1;                      // option "small_slots": re-pack into 256-id slots when the inverted index is first built (a large
+                                              // stream going sparse: a merge site then costs 1 KiB of its slot, not 4); 2 = streams of a few thousand
+                                              // slots too (tests)
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
                                               // across steps) instead of k_chain_sel (one count level at a time); sharded training keeps k_chain_sel
@@ -202,6 +207,10 @@ struct bpe_ctx {
     uint64_t prof_bytes[BPE_PROF_NKINDS] = {0};
 };
 
+// the kernel of the geometry the slotted stream is in (bpe_device.h: BPE_GEOMETRY; kernels of one name have one signature)
+#define GK(c, kern) ((c)->ts == TILE2_MIN ? bpe::bpe_g1::kern : bpe::bpe_g4::kern)
+inline uint32_t idx_h(const bpe_ctx *c) { return c->ts == TILE2_MIN ? bpe::bpe_g1::IDX_H : bpe::bpe_g4::IDX_H; }
+
 namespace {
 
 int fail(bpe_ctx *c, int code, const char *fmt, ...) {
@@ -277,7 +286,7 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         c->cap_ids = need;
     }
     const uint64_t nt = ntiles_of(n) + 1;
-    const uint64_t nt2 = (TILE / TILE2) * nt + 4;  // slots of the second slotted form (TILE2 ids each)
+    const uint64_t nt2 = (TILE / TILE2_MIN) * nt + 4;  // slots of the second slotted form (as few as TILE2_MIN ids each)
     if (nt > c->cap_tiles) {
         TRY(dev_realloc(c, c->d_tsum, nt));
         TRY(dev_realloc(c, c->d_tile_off, nt));
@@ -580,7 +589,7 @@ int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     C.tie_window = c->tie_window ? 1u : 0u;
     C.aa = (sparse_next && aa_through_index(c)) ? 1u : 0u;
     if (c->slotted && c->slot2)
-        hipLaunchKernelGGL(k_select<SlotRefH>, dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+        hipLaunchKernelGGL(GK(c, k_select<SlotRefH>), dim3(blocks), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->vcur, c->d_st, stream_ref_h(c), c->par, c->dp_active ? 1 : 0,
                            ++c->sel_epoch, C);
     else
@@ -606,7 +615,7 @@ int launch_rowsel_lean(bpe_ctx *c) {
     C.tie_index = 1;
     C.tie_window = 0;
     C.aa = 0;
-    hipLaunchKernelGGL(k_rowsel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+    hipLaunchKernelGGL(GK(c, k_rowsel_lean), dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag);
     LAUNCHCHK(c, "k_rowsel_lean");
     TRY(prof_end(c));
@@ -629,7 +638,7 @@ int launch_sel_lean(bpe_ctx *c) {
     C.aa = 0;
     // the update before this selection made token vcur - 1: one record per wave of its token workgroups
     const uint32_t nwv = ((c->vcur + 255u) / 256u) * 4u;
-    hipLaunchKernelGGL(k_sel_lean, dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+    hipLaunchKernelGGL(GK(c, k_sel_lean), dim3(1 + (unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->vcur, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag,
                        c->d_lean_sum, nwv, (uint32_t)c->lean_chain);
     LAUNCHCHK(c, "k_sel_lean");
@@ -642,7 +651,7 @@ int launch_sel_lean(bpe_ctx *c) {
 int flush_lean_rows(bpe_ctx *c, uint32_t ncols) {
     if (!c->rows_pending) return BPE_OK;
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
-    hipLaunchKernelGGL(k_rowmax_lean, dim3((unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_mat, c->vcap,
+    hipLaunchKernelGGL(GK(c, k_rowmax_lean), dim3((unsigned)c->lean_scan), dim3(1024), 0, c->stream, c->d_mat, c->vcap,
                        c->d_rowmax, c->d_st, ncols, c->d_dbits);
     LAUNCHCHK(c, "k_rowmax_lean");
     TRY(prof_end(c));
@@ -823,17 +832,17 @@ int index_build(bpe_ctx *c) {
         const uint64_t cap = (nwords + 4 + 63) / 64 * 64;  // row stride: 16-byte aligned rows, a padded tail
         if (c->d_idx_tmp) HIPCHK(c, hipFree(c->d_idx_tmp));
         c->d_idx_tmp = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * IDX_H * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void **)&c->d_idx_tmp, cap * IDX_H * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * bpe::bpe_g4::IDX_H * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_idx_tmp, cap * bpe::bpe_g4::IDX_H * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void **)&c->d_idx_dirty, cap * sizeof(uint32_t)));
         c->idx_cap_words = cap;
     }
     if (nwords) {
-        hipLaunchKernelGGL(k_index_build, dim3((unsigned)nwords), dim3(1024), (size_t)IDX_H * 4, c->stream,
+        hipLaunchKernelGGL(GK(c, k_index_build), dim3((unsigned)nwords), dim3(1024), (size_t)idx_h(c) * 4, c->stream,
                            c->d_ids[0], c->d_ids[1], c->d_hdr2[c->mq], (uint32_t)c->slot_T, c->d_idx_tmp,
                            c->d_idx_dirty, c->d_st);
         LAUNCHCHK(c, "k_index_build");
-        hipLaunchKernelGGL(k_index_transpose, dim3((unsigned)((nwords + 31) / 32), IDX_H / 32), dim3(256), 0,
+        hipLaunchKernelGGL(GK(c, k_index_transpose), dim3((unsigned)((nwords + 31) / 32), idx_h(c) / 32), dim3(256), 0,
                            c->stream, c->d_idx_tmp, (uint32_t)nwords, c->d_idx, (uint32_t)c->idx_cap_words);
         LAUNCHCHK(c, "k_index_transpose");
     }
@@ -844,9 +853,9 @@ int index_build(bpe_ctx *c) {
 }
 
 int slots2_enter(bpe_ctx *c) {
-    c->slot_T = (c->n + TILE2 - 1) / TILE2;
+    c->slot_T = (c->n + (uint64_t)c->ts - 1) / (uint64_t)c->ts;
     c->mq = 0;
-    hipLaunchKernelGGL(k_slot2_init, dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
+    hipLaunchKernelGGL(GK(c, k_slot2_init), dim3(grid_for(std::max<uint64_t>(c->slot_T, 1), 256, c->num_cus * 4)),
                        dim3(256), 0, c->stream, c->d_hdr2[0], c->slot_T, c->d_st, c->par, (uint32_t)c->par,
                        c->d_ids[c->par]);
     LAUNCHCHK(c, "k_slot2_init");
@@ -863,7 +872,7 @@ int slots2_leave(bpe_ctx *c) {
     const uint64_t T = c->slot_T;
     if (T) {
         const uint64_t nb = (T + SCAN_TILE - 1) / SCAN_TILE;
-        hipLaunchKernelGGL(k_slot2_lens, dim3(grid_for(T, 256, c->num_cus * 4)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(GK(c, k_slot2_lens), dim3(grid_for(T, 256, c->num_cus * 4)), dim3(256), 0, c->stream,
                            c->d_hdr2[c->mq], T, c->d_slot_lens);
         hipLaunchKernelGGL(k_scan_blocksum, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
                            c->d_slot_bsum);
@@ -871,7 +880,7 @@ int slots2_leave(bpe_ctx *c) {
                            c->d_scratch + 3);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, c->stream, c->d_slot_lens, T,
                            c->d_slot_bsum, c->d_slot_off);
-        hipLaunchKernelGGL(k_slot2_compact, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, c->stream, c->d_ids[0],
+        hipLaunchKernelGGL(GK(c, k_slot2_compact), dim3((unsigned)((T + 3) / 4)), dim3(256), 0, c->stream, c->d_ids[0],
                            c->d_ids[1], c->d_hdr2[c->mq], T, c->d_slot_off, c->d_ids2);
         LAUNCHCHK(c, "k_slot2_compact");
     }
@@ -917,6 +926,13 @@ int plan_pass2(bpe_ctx *c, bool *sparse_out) {
     const bool sparse = can_index && (c->use_sparse == 2 || rare);
     // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
     // one go by, the index is rebuilt so that those marks do not pile up)
+    if (sparse && !c->idx_live && c->small_slots && c->ts != TILE2_MIN && (!small || c->small_slots == 2)) {
+        // a large stream goes sparse: from here on a merge site costs the slot it sits in -- re-pack into 256-id slots
+        // (kernels of namespace bpe_g1 from the next launch on; the index is built over the new slots below)
+        TRY(slots2_leave(c));
+        c->ts = TILE2_MIN;
+        TRY(slots2_enter(c));
+    }
     if (sparse && (!c->idx_live || c->idx_rebuild)) TRY(index_build(c));
     *sparse_out = sparse;
     return BPE_OK;
@@ -928,7 +944,7 @@ int plan_pass2(bpe_ctx *c, bool *sparse_out) {
 int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if ((++c->epoch & EPOCH_MASK) == 0) {  // tag wrapped: retire every old descriptor
-        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, ((TILE / TILE2) * c->cap_tiles + 4) * sizeof(unsigned long long), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_desc, 0, ((TILE / TILE2_MIN) * c->cap_tiles + 4) * sizeof(unsigned long long), c->stream));
         c->epoch++;
     }
     const uint32_t T = (uint32_t)c->slot_T;
@@ -953,21 +969,21 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     const bool ldsd = c->lds_delta && newid + 1 <= (uint32_t)LDSD_CAP;
     if (sparse) {
         if (ldsd)
-            hipLaunchKernelGGL(k_merge_ab_sparse<true>, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_sparse<true>), dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
         else
-            hipLaunchKernelGGL(k_merge_ab_sparse<false>, dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_sparse<false>), dim3(SPARSE_GRID), dim3(MT), 0, c->stream, A);
         c->n_sparse++;
     } else {
         const unsigned g = std::max((T + MT / 64 - 1) / (MT / 64), 1u);  // one wave per slot
         const unsigned ge = std::min(g, 5u * (unsigned)c->num_cus);       // ... or a resident grid
         if (ldsd && A.idx)
-            hipLaunchKernelGGL(k_merge_ab_dense_early<true>, dim3(ge), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_dense_early<true>), dim3(ge), dim3(MT), 0, c->stream, A);
         else if (ldsd)
-            hipLaunchKernelGGL(k_merge_ab_dense_early<false>, dim3(ge), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_dense_early<false>), dim3(ge), dim3(MT), 0, c->stream, A);
         else if (A.idx)
-            hipLaunchKernelGGL(k_merge_ab_dense<true>, dim3(g), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_dense<true>), dim3(g), dim3(MT), 0, c->stream, A);
         else
-            hipLaunchKernelGGL(k_merge_ab_dense<false>, dim3(g), dim3(MT), 0, c->stream, A);
+            hipLaunchKernelGGL(GK(c, k_merge_ab_dense<false>), dim3(g), dim3(MT), 0, c->stream, A);
         c->n_dense++;
     }
     LAUNCHCHK(c, "k_merge_ab");
@@ -996,7 +1012,7 @@ int launch_passes2(bpe_ctx *c, uint32_t newid, bool sparse, uint32_t dl) {
     c->last_aa_indexed = aas;
     // (a resident grid of single-wave workgroups -- a slot may wait for its predecessor's carry:
     // ~140 VGPRs admit three waves per SIMD, twelve per CU; eight are launched)
-    hipLaunchKernelGGL(k_merge_aa, dim3(std::max(1u, std::min(T, 8u * (unsigned)c->num_cus))), dim3(64), 0,
+    hipLaunchKernelGGL(GK(c, k_merge_aa), dim3(std::max(1u, std::min(T, 8u * (unsigned)c->num_cus))), dim3(64), 0,
                        c->stream, B);
     LAUNCHCHK(c, "k_merge_aa");
     TRY(prof_end(c));
@@ -1067,10 +1083,10 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
     if (c->idx_live)
-        hipLaunchKernelGGL(k_merge_ab_lean<true>, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
+        hipLaunchKernelGGL(GK(c, k_merge_ab_lean<true>), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
                            use_index ? 1u : 0u, c->d_dbits);
     else
-        hipLaunchKernelGGL(k_merge_ab_lean<false>, dim3(g), dim3(LEAN_MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u,
+        hipLaunchKernelGGL(GK(c, k_merge_ab_lean<false>), dim3(g), dim3(LEAN_MT), 0, c->stream, A, (const uint32_t *)nullptr, 0u,
                            c->d_dbits);
     LAUNCHCHK(c, "k_merge_ab_lean");
     TRY(prof_end(c));
@@ -1078,7 +1094,7 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     const uint32_t na = (newid + 1 + 255) / 256;
     // (+ workgroups that commit the staged headers: a mask word or two per thread)
     const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
-    hipLaunchKernelGGL(k_apply_lean, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
+    hipLaunchKernelGGL(GK(c, k_apply_lean), dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
                        c->d_rowmax, c->d_st, newid, c->d_dbits, c->par, rec, iter, na, c->d_hdr2[c->mq], c->d_stage,
                        c->d_removed, c->d_smask, nwords, c->d_lean_sum);
     LAUNCHCHK(c, "k_apply_lean");
@@ -1132,18 +1148,18 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : std::min(CH_KSWEEP, c->chain_kcap));
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
     if (c->pool && !dp)
-        hipLaunchKernelGGL(k_pool_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+        hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                            kcap, c->d_pool, c->d_pool_gather, (uint32_t)(c->pool_hint > 0 ? c->pool_hint : (int)kcap));
     else
-    hipLaunchKernelGGL(k_chain_sel, dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+    hipLaunchKernelGGL(GK(c, k_chain_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                        (uint32_t)((c->chain_extend && c->chain_scan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
                        kcap, dp ? c->d_dp_ckey : (long long *)nullptr, (unsigned long long)(dp ? dp->rank : 0));
     LAUNCHCHK(c, "k_chain_sel");
     if (dp) {
         TRY(dp_allreduce(c, c->d_dp_ckey, DP_KEY_WORDS, BPE_DT_INT64, BPE_OP_MIN));
-        hipLaunchKernelGGL(k_chain_sel_dp, dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
+        hipLaunchKernelGGL(GK(c, k_chain_sel_dp), dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
         LAUNCHCHK(c, "k_chain_sel_dp");
     }
     TRY(prof_end(c));
@@ -1169,13 +1185,13 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     if (dense) {
         // every slot, one 1024-thread workgroup per CU at most (sixteen slots in flight each)
         const unsigned g = std::max(1u, std::min((T + 15) / 16, (unsigned)c->num_cus));
-        hipLaunchKernelGGL(k_merge_chain_dense, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_dbits);
+        hipLaunchKernelGGL(GK(c, k_merge_chain_dense), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_dbits);
         // (the batch of one has its own kernel -- five 256-thread workgroups per CU, 96 VGPRs: the other one returns at once)
         const unsigned g1 = std::max(1u, std::min((T + MT / 64 - 1) / (MT / 64), 5u * (unsigned)c->num_cus));
-        hipLaunchKernelGGL(k_merge_chain_dense1, dim3(g1), dim3(MT), 0, c->stream, A);
+        hipLaunchKernelGGL(GK(c, k_merge_chain_dense1), dim3(g1), dim3(MT), 0, c->stream, A);
     } else {
         const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
-        hipLaunchKernelGGL(k_merge_chain, dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
+        hipLaunchKernelGGL(GK(c, k_merge_chain), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
     }
     LAUNCHCHK(c, "k_merge_chain");
     TRY(prof_end(c));
@@ -1185,11 +1201,11 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     const uint32_t fS = std::min<uint32_t>(c->vcap, ((zhi + 1 + 63) / 64) * 64);  // vector stride of the SUM payload
     uint32_t *ftail = dp ? c->d_dp_cfold + (size_t)2 * kcap * fS : nullptr;
     if (dp) {
-        hipLaunchKernelGGL(k_dp_fold_chain, dim3(na), dim3(256), 0, c->stream, c->d_delta, dl, c->d_st, c->d_dp_cfold, fS, ftail);
+        hipLaunchKernelGGL(GK(c, k_dp_fold_chain), dim3(na), dim3(256), 0, c->stream, c->d_delta, dl, c->d_st, c->d_dp_cfold, fS, ftail);
         LAUNCHCHK(c, "k_dp_fold_chain");
         TRY(dp_allreduce(c, c->d_dp_cfold, (uint64_t)2 * kcap * fS + 64, BPE_DT_INT32, BPE_OP_SUM));
     }
-    hipLaunchKernelGGL(k_apply_chain, dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
+    hipLaunchKernelGGL(GK(c, k_apply_chain), dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
                        c->d_st, c->d_dbits, c->par, c->h_rec, c->h_srec, step, na, c->d_hdr2[c->mq], c->d_stage,
                        c->d_removed, c->d_smask, nwords, c->d_lean_sum, dp ? c->d_dp_cfold : (const uint32_t *)nullptr, fS,
                        (const uint32_t *)ftail);

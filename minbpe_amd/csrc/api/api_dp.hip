@@ -41,6 +41,7 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     c->last_count = ~0ull;
     c->n_sparse = c->n_dense = c->n_index_builds = 0;
     c->dp_flip.assign((size_t)std::max(num_merges, 1), 0);
+    c->ts = TILE2_MAX;
     if (c->use_slots) TRY(c->use_slots == 2 ? slots2_enter(c) : slots_enter(c));
     return BPE_OK;
 }
@@ -73,7 +74,7 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     HIPCHK(c, hipSetDevice(c->device));
     c->vcur = 256u + (uint32_t)iter;
     const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-    if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)(c->slot2 ? TILE2 : TILE) * (den - 1)) {
+    if (c->slotted && c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)(c->slot2 ? c->ts : TILE) * (den - 1)) {
         if (c->slot2) {
             TRY(slots2_leave(c));
             TRY(slots2_enter(c));
@@ -87,7 +88,7 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
     TRY(flush_lean_rows(c, c->vcur));  // (row maxima a chain step's table update left to do: dp_train_loop)
     TRY(launch_select(c, false));
     if (c->slotted && c->slot2)
-        hipLaunchKernelGGL(k_dp_key<SlotRefH>, dim3(1), dim3(64), 0, c->stream, stream_ref_h(c), c->par, c->d_st,
+        hipLaunchKernelGGL(GK(c, k_dp_key<SlotRefH>), dim3(1), dim3(64), 0, c->stream, stream_ref_h(c), c->par, c->d_st,
                            (unsigned long long)c->dp_rank, c->d_dp_key);
     else
         hipLaunchKernelGGL(k_dp_key<SlotRef>, dim3(1), dim3(64), 0, c->stream, stream_ref(c), c->par, c->d_st,
@@ -99,7 +100,7 @@ extern "C" int bpe_dp_select(bpe_ctx *c, int32_t iter) {
 extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_dp_resolve, dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
+    hipLaunchKernelGGL(GK(c, k_dp_resolve), dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_dp_key);
     LAUNCHCHK(c, "k_dp_resolve");
     c->dp_enq = iter + 1;
     if (c->slotted && c->slot2) {
@@ -114,12 +115,12 @@ extern "C" int bpe_dp_merge(bpe_ctx *c, int32_t iter) {
             C.enable = 1;
             C.tie_index = C.tie_window = 0;
             C.aa = aa_through_index(c) ? 1u : 0u;
-            hipLaunchKernelGGL(k_dp_cand, dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
+            hipLaunchKernelGGL(GK(c, k_dp_cand), dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
             LAUNCHCHK(c, "k_dp_cand");
         }
         c->dp_dl = delta_layout(c, Z);
         TRY(launch_passes2(c, Z, c->dp_sparse, c->dp_dl));
-        hipLaunchKernelGGL(k_dp_fold2, dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta, c->dp_dl, Z,
+        hipLaunchKernelGGL(GK(c, k_dp_fold2), dim3((c->vcap + 255) / 256), dim3(256), 0, c->stream, c->d_delta, c->dp_dl, Z,
                            c->d_dp_folded, c->vcap, c->d_st);
         LAUNCHCHK(c, "k_dp_fold2");
         return BPE_OK;
@@ -138,7 +139,7 @@ extern "C" int bpe_dp_apply(bpe_ctx *c, int32_t iter) {
     const uint32_t Z = 256u + (uint32_t)iter;
     if (c->slotted && c->slot2) {
         const int mq0 = c->mq;
-        hipLaunchKernelGGL(k_dp_after_sum, dim3(1), dim3(1), 0, c->stream, c->d_st, c->d_dp_folded + 4 * (size_t)c->vcap);
+        hipLaunchKernelGGL(GK(c, k_dp_after_sum), dim3(1), dim3(1), 0, c->stream, c->d_st, c->d_dp_folded + 4 * (size_t)c->vcap);
         LAUNCHCHK(c, "k_dp_after_sum");
         TRY(launch_table2(c, Z, iter, c->h_rec, c->dp_sparse, c->dp_dl, true));
         if ((size_t)iter < c->dp_flip.size()) c->dp_flip[(size_t)iter] = (uint8_t)(c->mq != mq0);

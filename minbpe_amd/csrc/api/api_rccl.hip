@@ -197,7 +197,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
         }
         q.clear();
         n_chain_inflight = 0;
-        hipLaunchKernelGGL(k_clear_defer_chain, dim3(1), dim3(1), 0, c->stream, c->d_st);
+        hipLaunchKernelGGL(GK(c, k_clear_defer_chain), dim3(1), dim3(1), 0, c->stream, c->d_st);
         LAUNCHCHK(c, "k_clear_defer_chain");
         c->rows_pending = true;  // (flag words may stand: k_rowmax_lean before the general selection)
         c->n_deferred++;
@@ -231,13 +231,13 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
             if (want_dense && (known || in_chain)) {
                 c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);
                 const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE2 * (den - 1)) {
+                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)c->ts * (den - 1)) {
                     TRY(slots2_leave(c));
                     TRY(slots2_enter(c));
                 }
                 if (!in_chain) {
                     TRY(flush_lean_rows(c, c->vcur));
-                    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
+                    hipLaunchKernelGGL(GK(c, k_set_iter), dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
                     LAUNCHCHK(c, "k_set_iter");
                     in_chain = true;
                 }
@@ -248,7 +248,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
             } else if (want_chain && (known || in_chain)) {
                 c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);
                 const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)TILE2 * (den - 1)) {
+                if (c->slot_T > 64 && c->n * den < c->slot_T * (uint64_t)c->ts * (den - 1)) {
                     TRY(slots2_leave(c));
                     TRY(slots2_enter(c));
                 }
@@ -257,7 +257,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
                 if (!c->idx_live || c->idx_rebuild) TRY(index_build(c));  // (a tie is ordered through the index, whatever the pass)
                 if (!in_chain) {
                     TRY(flush_lean_rows(c, c->vcur));
-                    hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
+                    hipLaunchKernelGGL(GK(c, k_set_iter), dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
                     LAUNCHCHK(c, "k_set_iter");
                     in_chain = true;
                 }

@@ -96,6 +96,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     bool lean_on = false;     // latched: the general path's kernels do not know a deferred iteration
     bool in_chain = false;    // the device counts the merges (k_set_iter ran, no GENERAL / LEAN unit enqueued since)
     bool records_ok = false;  // the last unit enqueued was a chain step: its table update's per-wave records are current
+    c->ts = TILE2_MAX;  // (the early sweeps run on 1024-id slots; plan_pass2 re-packs into 256-id slots when the stream goes sparse)
     if (slots) TRY(form2 ? slots2_enter(c) : slots_enter(c));
 
     // ---- the record of merge j is final: outputs, statistics, what the next launches are sized by -------
@@ -183,11 +184,11 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         // (the deferred unit's own selection launch re-scanned the rows flagged before it -- or left the flags
         // standing, for flush_lean_rows; the no-op table updates behind it left nothing new to re-scan)
         if (in_chain) {
-            hipLaunchKernelGGL(k_clear_defer_chain, dim3(1), dim3(1), 0, c->stream, c->d_st);
+            hipLaunchKernelGGL(GK(c, k_clear_defer_chain), dim3(1), dim3(1), 0, c->stream, c->d_st);
             c->rows_pending = true;  // (flag words may stand: k_rowmax_lean before the general selection)
         } else {
             c->rows_pending = false;
-            hipLaunchKernelGGL(k_clear_defer, dim3(1), dim3(1), 0, c->stream, c->d_st);
+            hipLaunchKernelGGL(GK(c, k_clear_defer), dim3(1), dim3(1), 0, c->stream, c->d_st);
         }
         LAUNCHCHK(c, "k_clear_defer");
         c->n_deferred++;
@@ -224,7 +225,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             // an index build: re-pack at 7/8 there)
             const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
             const bool repack = c->slotted && c->slot_T > 64 &&
-                                c->n * den < c->slot_T * (uint64_t)(c->slot2 ? TILE2 : TILE) * (den - 1);
+                                c->n * den < c->slot_T * (uint64_t)(c->slot2 ? c->ts : TILE) * (den - 1);
             bool sparse = false;
             // lean iterations (k_lean.hip) / chain steps (k_chain.hip): every sparse pass whose pair is rare enough,
             // and every pass of a stream too small for the index (a few thousand slots: visiting them all costs nothing)
@@ -268,7 +269,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                     if (!chain_dense) lean_on = true;
                     if (!in_chain) {  // general iterations so far: the device counts from here
                         TRY(flush_lean_rows(c, c->vcur));  // (rows a lean table update left, if lean iterations ran before)
-                        hipLaunchKernelGGL(k_set_iter, dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
+                        hipLaunchKernelGGL(GK(c, k_set_iter), dim3(1), dim3(1), 0, c->stream, c->d_st, (uint32_t)i, (uint32_t)num_merges);
                         LAUNCHCHK(c, "k_set_iter");
                         in_chain = true;
                         records_ok = false;

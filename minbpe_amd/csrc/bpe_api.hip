@@ -23,6 +23,7 @@
 #include "bpe_kernels.hip"
 
 using namespace bpe;
+using namespace bpe::bpe_g4;  // (host code names the 1024-id geometry unless it says otherwise: GK below)
 
 #ifndef REPACK_DEN
 #define REPACK_DEN 32  // re-pack the slots when their fill drops below (REPACK_DEN-1)/REPACK_DEN

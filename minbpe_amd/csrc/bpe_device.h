@@ -17,14 +17,28 @@ constexpr uint32_t INVALID_WORD = 0xFFFFFFFFu;  // positions >= n inside a tile
 constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;     // LDS cache: free slot
 constexpr unsigned long long NOPOS = ~0ull;
 
-// merge tile geometry: 4 waves x MJ stripes x 64 lanes x 4 ids
+// merge tile geometry: 4 waves x MJ stripes x 64 lanes x 4 ids.  The kernels that know the geometry (kernels/k_index ..
+// k_dp, bpe_kernels.hip) are compiled ONCE PER GEOMETRY, each in its own namespace: bpe_g4 -- MJ = 4, slots of 1024 ids:
+// the dense sweeps of the early merges want 4 KiB per wave in flight -- and bpe_g1 -- MJ = 1, slots of 256 ids: once
+// passes are sparse a merge site costs the slot it sits in, and a slot of 1 KiB is a quarter of the traffic and of the
+// per-slot work.  The host re-packs the stream from one into the other when the inverted index is first built
+// (option "small_slots") and launches the kernels of the geometry the stream is in (api_ctx.hip: GK).
 constexpr int MT = 256;
-#ifndef BPE_MJ
-#define BPE_MJ 4
-#endif
-constexpr int MJ = BPE_MJ;  // <= 8: a group of 64 tiles must fit 20-bit aggregates
-constexpr int WAVE_SPAN = MJ * 256;
-constexpr int TILE = (MT / 64) * WAVE_SPAN;  // 4096 ids = 16 KiB
+#define BPE_GEOMETRY(NS, MJV, IDXH_LOG2)                                                                         \
+    namespace NS {                                                                                               \
+    constexpr int MJ = MJV; /* <= 8: a group of 64 tiles must fit 20-bit aggregates */                           \
+    constexpr int WAVE_SPAN = MJ * 256;                                                                          \
+    constexpr int TILE = (MT / 64) * WAVE_SPAN; /* first slotted form / contiguous kernels: 4 waves per tile */ \
+    /* Slot size of the second slotted form: what ONE WAVE holds (MJ stripes x 64 lanes x 4 ids).  A slot is   \
+       read, compacted and written back by a single wave -- no barrier anywhere in the pass */                  \
+    constexpr int TILE2 = WAVE_SPAN;                                                                             \
+    /* inverted slot index (k_index.hip): buckets of a slot group's pair filter */                              \
+    constexpr uint32_t IDX_H = 1u << IDXH_LOG2;                                                                  \
+    constexpr int IDX_SHIFT = 32 - IDXH_LOG2;                                                                    \
+    }
+BPE_GEOMETRY(bpe_g4, 4, 15)
+BPE_GEOMETRY(bpe_g1, 1, 13)
+constexpr int TILE2_MAX = 1024, TILE2_MIN = 256;
 
 // pair-count kernels: one 1024-thread workgroup per CU using all 128 KiB of dynamic LDS
 constexpr int PC_BITS = 14;       // general kernel: 2^14 {key,count} slots
@@ -88,12 +102,6 @@ struct SlotRef {
     const uint32_t *meta;
     unsigned long long T;
 };
-
-// Slot size of the second slotted form: what ONE WAVE holds (4 stripes x 64 lanes x 4 ids).  A slot
-// is read, compacted and written back by a single wave -- no barrier anywhere in the pass -- and a
-// merge that touches one id of a slot moves 4 KiB, not 16.
-constexpr int TILE2 = WAVE_SPAN;
-static_assert(TILE2 == 1024, "k_slots2.hip assumes 1024-id slots");
 
 // Slotted stream, second form (the training loop's default, k_slots2.hip): one 32-byte header
 // per slot instead of a meta word + a 16-byte header, so that a workgroup gets everything it
@@ -174,6 +182,67 @@ struct DevState {
     // front of block 0's own accesses to the fields above.
     alignas(128) uint32_t sel_flag;
     uint32_t pad_flag_[31];
+};
+
+// ---- kernel argument blocks the host fills (the same types for both geometries) --------------------------------------
+// the candidate list of a sparse pass / the index a tie is broken through (k_index.hip, k_select.hip)
+struct CandArgs {
+    const uint32_t *idx, *dirty;
+    uint32_t *cand;
+    uint32_t stride;     // of the index rows (groups allocated)
+    uint32_t T;
+    uint32_t enable;     // 0: this iteration's a != b pass is a dense one
+    uint32_t tie_index;  // the index is live: block 0 of k_select breaks ties through it
+    uint32_t tie_window; // block 0 first looks through the first TIE_WIN slots by itself (experiment)
+    uint32_t aa;         // a list for a pair with a == b too (its pass then works through the list, k_merge_aa)
+};
+// an a != b merge pass of the second slotted form (k_slots2.hip, k_lean.hip, k_chain.hip)
+struct AbArgs {
+    uint32_t *b0, *b1;        // the two id buffers
+    const SlotHdr *hdr_in;    // headers as they stand before this pass
+    SlotHdr *hdr_out;         // dense: the other header array; sparse: unused
+    StageRec *stage;          // sparse: staged headers, stage[t] for slot t ...
+    uint32_t *smask;          // ... and [slot / 32]: which slots have one (no shared counter: every
+                              // changed slot would queue up behind it, ~11 ns each)
+    uint32_t T;
+    DevState *st;
+    uint32_t newid;
+    uint32_t *delta;          // [replica][4][vcap]
+    uint32_t vcap;            // row stride | log2(replicas) << 24
+    uint32_t *idx;            // inverted index [IDX_H][istride] (word = slot / 32, bit = slot % 32), or nullptr
+    uint32_t istride;
+    const uint32_t *cand;     // sparse: the slots to visit (st->ncand of them, from k_select)
+    uint32_t *removed;        // [256] ids removed by this pass, spread over counters (t & 255): one
+                              // counter would serialise every changed slot of a dense pass (~11 ns each)
+    uint32_t *dirty_n;        // reset here for the table update that follows
+};
+// the a == b pass (k_slots2.hip: k_merge_aa)
+struct AaArgs {
+    const uint32_t *b0, *b1;
+    uint32_t *w0, *w1;
+    const SlotHdr *hdr_in;
+    SlotHdr *hdr_out;         // every slot's header is written here ...
+    StageRec *stage;          // ... unless this is set (the a != b kernel of this iteration is the
+                              // sparse one, whose staged headers get committed): changed slots only
+    uint32_t *smask;
+    uint32_t T;
+    DevState *st;
+    uint32_t newid;
+    uint32_t *delta;
+    uint32_t vcap;
+    unsigned long long *sdesc;
+    uint32_t epoch;
+    uint32_t *dirty;          // index live and not kept current by this pass: [slot / 32], set for the slots it rewrites
+    uint32_t *removed;        // [256]
+    const uint32_t *cand;     // the slots to visit (st->ncand of them, from k_select: the slots whose filter admits
+                              // (a,a), the slot before each, the marked ones), or nullptr: every slot
+    uint32_t *idx;            // the index, kept current by this pass (the pairs it creates enter the filters), or nullptr
+    uint32_t istride;
+};
+// an entry of the pool (k_pool.hip)
+struct PoolEnt {
+    uint32_t xy, c;            // x << 16 | y (training ids are below 65536), the pair's count
+    unsigned long long key;    // epoch << 40 | first-occurrence position; 0 = no order known
 };
 
 constexpr uint32_t STEP_RING = 4096;  // step records form a ring (far more than the steps the host runs ahead: depth <= 64)

@@ -32,16 +32,32 @@
 #include "kernels/k_common.hip"
 #include "kernels/k_load.hip"
 #include "kernels/k_stats.hip"
+#include "kernels/k_table.hip"
+// the parts that know the slot geometry, once per geometry (bpe_device.h: BPE_GEOMETRY)
+#define BPE_G bpe_g4
+#include "kernels/k_index.hip"
 #include "kernels/k_select.hip"
 #include "kernels/k_merge.hip"
 #include "kernels/k_lookback.hip"
 #include "kernels/k_slots.hip"
 #include "kernels/k_slots2.hip"
-#include "kernels/k_table.hip"
 #include "kernels/k_lean.hip"
 #include "kernels/k_chain.hip"
 #include "kernels/k_pool.hip"
 #include "kernels/k_dp.hip"
+#undef BPE_G
+#define BPE_G bpe_g1
+#include "kernels/k_index.hip"
+#include "kernels/k_select.hip"
+#include "kernels/k_merge.hip"
+#include "kernels/k_lookback.hip"
+#include "kernels/k_slots.hip"
+#include "kernels/k_slots2.hip"
+#include "kernels/k_lean.hip"
+#include "kernels/k_chain.hip"
+#include "kernels/k_pool.hip"
+#include "kernels/k_dp.hip"
+#undef BPE_G
 #include "kernels/k_encode.hip"
 #include "kernels/k_decode.hip"
 #include "kernels/k_util.hip"

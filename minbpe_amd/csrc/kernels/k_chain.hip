@@ -37,14 +37,14 @@
 // settle (more than TIE_CAP tied pairs, short slots about, a == b at the head of the list) is deferred to the
 // general path exactly as a lean iteration's is.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_lean.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 constexpr uint32_t CH_EX_CAP = 2048;  // flagged rows one FULL selection takes from the re-scanning workgroups
 
@@ -213,16 +213,25 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
         kb[j] = ~((mb[j] << 1) | mp) & valid[j] & 0xFu;
         cnt[j] = (uint32_t)__popc(kb[j]);
     }
-    static_assert(MJ == 4, "packed scan below assumes four stripes");
-    const uint32_t i01 = wave_iscan_add(cnt[0] | (cnt[1] << 16));
-    const uint32_t i23 = wave_iscan_add(cnt[2] | (cnt[3] << 16));
-    const uint32_t t01 = lane_last(i01), t23 = lane_last(i23);
-    const uint32_t tot0 = t01 & 0xFFFFu, tot1 = t01 >> 16, tot2 = t23 & 0xFFFFu, tot3 = t23 >> 16;
-    ex[0] = (i01 & 0xFFFFu) - cnt[0];
-    ex[1] = tot0 + (i01 >> 16) - cnt[1];
-    ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
-    ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
-    const uint32_t total = tot0 + tot1 + tot2 + tot3;
+    uint32_t total = 0;
+    if constexpr (MJ == 4) {  // (two stripes' counts per scan)
+        const uint32_t i01 = wave_iscan_add(cnt[0] | (cnt[1] << 16));
+        const uint32_t i23 = wave_iscan_add(cnt[2] | (cnt[3] << 16));
+        const uint32_t t01 = lane_last(i01), t23 = lane_last(i23);
+        const uint32_t tot0 = t01 & 0xFFFFu, tot1 = t01 >> 16, tot2 = t23 & 0xFFFFu, tot3 = t23 >> 16;
+        ex[0] = (i01 & 0xFFFFu) - cnt[0];
+        ex[1] = tot0 + (i01 >> 16) - cnt[1];
+        ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
+        ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
+        total = tot0 + tot1 + tot2 + tot3;
+    } else {
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const uint32_t inc = wave_iscan_add(cnt[j]);
+            ex[j] = total + inc - cnt[j];
+            total += lane_last(inc);
+        }
+    }
     // ---- (6) stage the compacted slot in LDS, then 16-byte stores back to its home -------------
     uint32_t fstore = 0;  // a dropped first word moves everything
     if (!s) {
@@ -1535,4 +1544,5 @@ __global__ void k_clear_defer_chain(DevState *st) {
     st->pool_hint = 1;
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

@@ -1,14 +1,13 @@
 // k_dp.hip -- data-parallel (sharded chunks) helpers.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_select.hip"
-#include "k_index.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // Data-parallel training over sharded chunks: every rank holds a
@@ -119,4 +118,5 @@ k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__r
     }
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

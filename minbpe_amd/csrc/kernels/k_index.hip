@@ -1,14 +1,14 @@
 // k_index.hip -- the inverted slot index of the second slotted form (k_slots2.hip): hashing,
 // updates, and the candidate list of a sparse merge pass (built inside k_select).
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_common.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // Inverted slot index (sparse passes): for every group of 32 slots, a Bloom filter of the PAIRS
 // its slots hold -- IDX_H buckets of 32 bits (bit s = slot 32*g + s), three hash functions.  A pair
@@ -21,8 +21,7 @@ namespace bpe {
 // hashes, false positives around 0.07 %.  With 16 Ki buckets they were 0.46 %: ~800 of the 195 k slots of a
 // late 1 GB stream per pair, more than the ~650 slots that do hold a late pair -- and a chain step's pass
 // (k_chain.hip) visits the candidates of all its pairs.)
-constexpr uint32_t IDX_H = 32768;
-constexpr int IDX_SHIFT = 17;  // 32 - log2(IDX_H)
+// (IDX_H, IDX_SHIFT: the geometry's, bpe_device.h -- 32 Ki buckets for 1024-id slots, 8 Ki for 256-id slots: the same density)
 static_assert((1u << (32 - IDX_SHIFT)) == IDX_H, "hash width");
 __device__ __forceinline__ void pair_hash(uint32_t x, uint32_t y, uint32_t &h1, uint32_t &h2, uint32_t &h3) {
     h1 = ((x * 0x9E3779B1u) ^ (y * 0x85EBCA77u)) >> IDX_SHIFT;
@@ -42,16 +41,6 @@ __device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t s
 // The candidate list of a sparse pass, made by ONE 1024-thread block (the block of k_select
 // that makes the pair final): a mask per group of 32 slots from the filter rows of the pair's
 // three hashes, compacted with a block-wide scan -- no atomics, order = slot order.
-struct CandArgs {
-    const uint32_t *idx, *dirty;
-    uint32_t *cand;
-    uint32_t stride;     // of the index rows (groups allocated)
-    uint32_t T;
-    uint32_t enable;     // 0: this iteration's a != b pass is a dense one
-    uint32_t tie_index;  // the index is live: block 0 of k_select breaks ties through it
-    uint32_t tie_window; // block 0 first looks through the first TIE_WIN slots by itself (experiment)
-    uint32_t aa;         // a list for a pair with a == b too (its pass then works through the list, k_merge_aa)
-};
 // a == b: the pass charges every pair to its LEFT element, so the slot before a candidate owes table
 // updates too (the pair that ends at the candidate's first word): the list holds both.
 __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st, uint32_t a, uint32_t b) {
@@ -127,4 +116,5 @@ __device__ __forceinline__ void build_cand_list(const CandArgs &C, DevState *st,
     if (threadIdx.x == 0) st->ncand = s_base;
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

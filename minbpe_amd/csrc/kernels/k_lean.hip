@@ -32,17 +32,14 @@
 // and the host re-runs the iteration through the general path.  75 of 31,744 merges have a == b;
 // the general path pays a k_merge_aa launch in every iteration for them.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_index.hip"
-#include "k_select.hip"
-#include "k_slots2.hip"
-#include "k_table.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 constexpr uint32_t NOROW = 0xFFFFFFFFu;
 constexpr int DBITS_WORDS = 2048;     // one bit per row (vocab <= 65536)
@@ -844,4 +841,5 @@ __global__ void k_clear_defer(DevState *st) {
     st->chain_n = 0;  // (a chain of merges lined up by k_sel_lean ends here)
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

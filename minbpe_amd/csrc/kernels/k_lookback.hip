@@ -1,13 +1,13 @@
 // k_lookback.hip -- K3 (option merge=1): single-pass merge with decoupled look-back.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_merge.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // Single-pass merge: summary, carry/offset resolution and rewrite in ONE sweep
@@ -310,4 +310,5 @@ k_merge_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, De
                                nullptr);
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

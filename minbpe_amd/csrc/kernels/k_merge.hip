@@ -1,15 +1,13 @@
 // k_merge.hip -- K3: the merge tile code, the three-pass merge.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_common.hip"
-#include "k_index.hip"
-#include "k_select.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // K3: merge  (base.py:25-41, applied to every chunk regex.py:60)
@@ -567,4 +565,5 @@ k_merge_scatter(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                delta, vcap, (int)min((uint64_t)TILE, n - tile_base), nullptr, nullptr);
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

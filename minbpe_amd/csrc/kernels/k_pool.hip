@@ -30,14 +30,14 @@
 // ahead (st->pool_hint, set when fewer untouched entries than `hint_below` are left) so that the scanning workgroups
 // know at launch whether to stay.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_chain.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 constexpr uint32_t PL_CAP = 128;      // entries the pool holds
 constexpr uint32_t PL_ROWS = 64;      // rows a rebuild hands to the scanning workgroups
@@ -47,10 +47,6 @@ static_assert(PL_GATHER >= 4 * PL_CAP, "maintain: four variants per entry");
 // [0] = rows to scan (0: the scanning workgroups are dismissed), [1 + j] = row j, [1 + PL_ROWS] = theta,
 // [2 + PL_ROWS + w] = workgroup w has gathered its rows
 constexpr uint32_t PL_REQ_WORDS = 2 + PL_ROWS + 256;
-struct PoolEnt {
-    uint32_t xy, c;            // x << 16 | y (training ids are below 65536), the pair's count
-    unsigned long long key;    // epoch << 40 | first-occurrence position; 0 = no order known
-};
 
 // entries ranked by count (descending; equal counts keep their order): out[rank] = in[i].  n <= PL_GATHER, every thread
 // calls.  The order INSIDE a level is made later, from the keys, by a loop over the level alone.
@@ -565,4 +561,5 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     }
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

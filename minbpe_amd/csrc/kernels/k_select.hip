@@ -1,14 +1,13 @@
 // k_select.hip -- K2: arg-max with the reference's first-occurrence tie-break; stream views.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_common.hip"
-#include "k_index.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // stream views, used by the tie-break scans: contiguous (SlotRef, meta == nullptr), slotted
@@ -659,4 +658,5 @@ __global__ void k_set_pair(DevState *st, int32_t a, int32_t b) {
     st->count = 0;
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

@@ -1,14 +1,13 @@
 // k_slots.hip -- K3 in the training loop: slotted merge, re-packing.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_merge.hip"
-#include "k_lookback.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // Slotted merge (the training loop's default for a != b).
@@ -291,4 +290,5 @@ k_slot_compact(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1,
 __global__ void k_set_status(DevState *st, uint32_t status) { st->status = status; }
 __global__ void k_move_n(DevState *st, int from, int to) { st->n[to] = st->n[from]; }
 
+}  // namespace BPE_G
 }  // namespace bpe

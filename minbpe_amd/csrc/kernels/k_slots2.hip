@@ -1,16 +1,14 @@
 // k_slots2.hip -- K3 in the training loop, second form: in-place slotted merge for a != b
 // (dense and sparse passes), the a == b pass, the inverted slot index, re-packing.
 // Part of bpe_kernels.hip, which includes the parts in order.
-#pragma once
+// (no include guard: bpe_kernels.hip includes this part once per geometry, namespace BPE_G)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../bpe_device.h"
-#include "k_index.hip"
-#include "k_merge.hip"
-#include "k_lookback.hip"
 
 namespace bpe {
+namespace BPE_G {
 
 // ---------------------------------------------------------------------------
 // The stream is a sequence of T slots of TILE2 = 1024 words; slot t holds `len` ids at the start
@@ -48,25 +46,6 @@ namespace bpe {
 // turns them into the four vectors of format A (decL = incL = SL, decR = SR + adj at a,
 // incR = SR + adj at Z).
 
-struct AbArgs {
-    uint32_t *b0, *b1;        // the two id buffers
-    const SlotHdr *hdr_in;    // headers as they stand before this pass
-    SlotHdr *hdr_out;         // dense: the other header array; sparse: unused
-    StageRec *stage;          // sparse: staged headers, stage[t] for slot t ...
-    uint32_t *smask;          // ... and [slot / 32]: which slots have one (no shared counter: every
-                              // changed slot would queue up behind it, ~11 ns each)
-    uint32_t T;
-    DevState *st;
-    uint32_t newid;
-    uint32_t *delta;          // [replica][4][vcap]
-    uint32_t vcap;            // row stride | log2(replicas) << 24
-    uint32_t *idx;            // inverted index [IDX_H][istride] (word = slot / 32, bit = slot % 32), or nullptr
-    uint32_t istride;
-    const uint32_t *cand;     // sparse: the slots to visit (st->ncand of them, from k_select)
-    uint32_t *removed;        // [256] ids removed by this pass, spread over counters (t & 255): one
-                              // counter would serialise every changed slot of a dense pass (~11 ns each)
-    uint32_t *dirty_n;        // reset here for the table update that follows
-};
 
 __global__ void __launch_bounds__(256)
 k_slot2_init(SlotHdr *__restrict__ hdr, uint64_t T, DevState *st, int par, uint32_t which,
@@ -260,16 +239,25 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
         kb[j] = ~((mb[j] << 1) | mp) & valid[j] & 0xFu;
         cnt[j] = (uint32_t)__popc(kb[j]);
     }
-    static_assert(MJ == 4, "packed scan below assumes four stripes");
-    const uint32_t i01 = wave_iscan_add(cnt[0] | (cnt[1] << 16));
-    const uint32_t i23 = wave_iscan_add(cnt[2] | (cnt[3] << 16));
-    const uint32_t t01 = lane_last(i01), t23 = lane_last(i23);
-    const uint32_t tot0 = t01 & 0xFFFFu, tot1 = t01 >> 16, tot2 = t23 & 0xFFFFu, tot3 = t23 >> 16;
-    ex[0] = (i01 & 0xFFFFu) - cnt[0];
-    ex[1] = tot0 + (i01 >> 16) - cnt[1];
-    ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
-    ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
-    const uint32_t total = tot0 + tot1 + tot2 + tot3;
+    uint32_t total = 0;
+    if constexpr (MJ == 4) {  // (two stripes' counts per scan)
+        const uint32_t i01 = wave_iscan_add(cnt[0] | (cnt[1] << 16));
+        const uint32_t i23 = wave_iscan_add(cnt[2] | (cnt[3] << 16));
+        const uint32_t t01 = lane_last(i01), t23 = lane_last(i23);
+        const uint32_t tot0 = t01 & 0xFFFFu, tot1 = t01 >> 16, tot2 = t23 & 0xFFFFu, tot3 = t23 >> 16;
+        ex[0] = (i01 & 0xFFFFu) - cnt[0];
+        ex[1] = tot0 + (i01 >> 16) - cnt[1];
+        ex[2] = tot0 + tot1 + (i23 & 0xFFFFu) - cnt[2];
+        ex[3] = tot0 + tot1 + tot2 + (i23 >> 16) - cnt[3];
+        total = tot0 + tot1 + tot2 + tot3;
+    } else {
+#pragma unroll
+        for (int j = 0; j < MJ; j++) {
+            const uint32_t inc = wave_iscan_add(cnt[j]);
+            ex[j] = total + inc - cnt[j];
+            total += lane_last(inc);
+        }
+    }
     // ---- (6) stage the compacted slot in LDS, then 16-byte stores back to its home -------------
     // (everything before the first site keeps its place and value: only the rest is stored)
     uint32_t fstore = 0;  // a dropped first word moves everything
@@ -514,28 +502,6 @@ k_merge_ab_sparse(AbArgs A) {
 // found by walking the run back through the previous slots, out-of-place rewrite, format A delta,
 // every pair charged to its left element) on the 32-byte headers and one-wave slots: the tile
 // helpers of k_merge.hip with a single wave (its span IS the slot).
-struct AaArgs {
-    const uint32_t *b0, *b1;
-    uint32_t *w0, *w1;
-    const SlotHdr *hdr_in;
-    SlotHdr *hdr_out;         // every slot's header is written here ...
-    StageRec *stage;          // ... unless this is set (the a != b kernel of this iteration is the
-                              // sparse one, whose staged headers get committed): changed slots only
-    uint32_t *smask;
-    uint32_t T;
-    DevState *st;
-    uint32_t newid;
-    uint32_t *delta;
-    uint32_t vcap;
-    unsigned long long *sdesc;
-    uint32_t epoch;
-    uint32_t *dirty;          // index live and not kept current by this pass: [slot / 32], set for the slots it rewrites
-    uint32_t *removed;        // [256]
-    const uint32_t *cand;     // the slots to visit (st->ncand of them, from k_select: the slots whose filter admits
-                              // (a,a), the slot before each, the marked ones), or nullptr: every slot
-    uint32_t *idx;            // the index, kept current by this pass (the pairs it creates enter the filters), or nullptr
-    uint32_t istride;
-};
 
 __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A, const uint32_t a) {
     __shared__ int s_wave[MT / 64];
@@ -852,4 +818,5 @@ k_slot2_compact(const uint32_t *__restrict__ b0, const uint32_t *__restrict__ b1
     for (uint32_t i = lane_id(); i < len; i += 64) dst[i] = src[i];
 }
 
+}  // namespace BPE_G
 }  // namespace bpe

@@ -88,7 +88,8 @@ def test_cfg3_shape_gpt4_split_all_merges_equal_oracle(native, engine, big_golde
 # (lean 4: every lean iteration selects, no chained merges; lean 5: a == b passes over every slot + index rebuild;
 # lean 6: no general-path stretches after clustered deferrals -- every tie the lean selection cannot settle is one)
 # lean 7: chain steps (k_chain.hip) forced onto every merge; lean 8: the default engine without chain steps
-FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (2, 7), (1, 8)]
+# lean 9: the default engine with the stream re-packed into 256-id slots at the first index build (option small_slots = 2)
+FULL_VARIANTS = [(1, 1), (2, 1), (1, 0), (2, 0), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (2, 7), (1, 8), (1, 9), (2, 9)]
 
 
 @pytest.mark.parametrize("sparse,lean", FULL_VARIANTS)
@@ -107,7 +108,8 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
         assert hashlib.sha256(np.ascontiguousarray(offs, dtype=np.uint64).tobytes()).hexdigest() == g["offsets_sha256"]
     engine.set_option("sparse", sparse)
     engine.set_option("lean", 2 if lean == 7 else (1 if lean >= 3 else lean))
-    engine.set_option("chain", 1 if lean in (1, 7) else 0)
+    engine.set_option("chain", 1 if lean in (1, 7, 9) else 0)
+    engine.set_option("small_slots", 2 if lean == 9 else 1)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
     engine.set_option("aa_sparse", 0 if lean == 5 else 1)
@@ -122,6 +124,7 @@ def test_whole_vocab_range_all_31744_merges_equal_oracle(native, engine, big_gol
             # path for such stretches instead of deferring merge after merge.
             assert st["lean"] > 1000 and st["deferred"] <= 400, st
     finally:
+        engine.set_option("small_slots", 1)
         engine.set_option("lean_backoff", 1)
         engine.set_option("chain", 1)
         engine.set_option("sparse", 1)

@@ -124,26 +124,30 @@ def test_train_golden_cases(golden, engine, native):
 # but a == b passes visit every slot and mark what they rewrite for an index rebuild (option aa_sparse = 0)
 VARIANTS = [(0, 0, 0, 1, 1), (1, 0, 1, 1, 1), (1, 0, 0, 1, 1), (1, 1, 0, 1, 1), (0, 1, 0, 1, 1), (1, 0, 2, 1, 1),
             (1, 0, 2, 2, 1), (1, 0, 2, 0, 1), (1, 0, 2, 1, 0), (1, 0, 2, 2, 0), (1, 0, 2, 1, 2), (1, 0, 2, 2, 2),
-            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4), (1, 0, 2, 2, 5), (1, 0, 2, 1, 7), (1, 0, 2, 2, 7), (1, 0, 2, 1, 8)]
+            (1, 0, 2, 2, 3), (1, 0, 2, 2, 4), (1, 0, 2, 2, 5), (1, 0, 2, 1, 7), (1, 0, 2, 2, 7), (1, 0, 2, 1, 8),
+            (1, 0, 2, 1, 9), (1, 0, 2, 2, 9), (1, 0, 2, 2, 10)]
 
 
 def set_variant(engine, mode, mimpl, slots, sparse, lean=1):
     """lean: 0 never | 1 the default engine (chain steps, k_chain.hip, wherever lean iterations would run with the
     index live) | 2 lean iterations forced onto every merge, no chain steps | 3, 4, 5 variants of 2 (selection from
     the whole row-maxima array; no chained merges; a == b passes over every slot) | 7 = 2 with chain steps |
-    8 = 1 without chain steps (round 3's default engine)"""
+    8 = 1 without chain steps (round 3's default engine) | 9 = 1 and 10 = 7 with the re-packing into 256-id slots (kernels of
+    namespace bpe_g1) forced onto streams of any size at the first index build (option small_slots = 2; the default does
+    it for streams of more than 16 Ki slots only)"""
     engine.set_option("mode", mode)
     engine.set_option("merge", mimpl)
     engine.set_option("slots", slots)
     engine.set_option("sparse", sparse)
-    engine.set_option("lean", 1 if lean in (1, 8) else (2 if lean >= 2 else 0))
-    engine.set_option("chain", 1 if lean in (1, 7) else 0)
+    engine.set_option("lean", 1 if lean in (1, 8, 9) else (2 if lean >= 2 else 0))
+    engine.set_option("chain", 1 if lean in (1, 7, 9, 10) else 0)
+    engine.set_option("small_slots", 2 if lean in (9, 10) else 1)
     engine.set_option("lean_sum", 0 if lean == 3 else 1)
     engine.set_option("lean_chain", 0 if lean == 4 else 1)
     engine.set_option("aa_sparse", 0 if lean == 5 else 1)
     # lean >= 2 forces the lean iterations onto every merge (coverage of their kernels and of the hand-back):
     # no general-path stretches after clustered deferrals there
-    engine.set_option("lean_backoff", 0 if lean in (2, 3, 4, 5, 7) else 1)
+    engine.set_option("lean_backoff", 0 if lean in (2, 3, 4, 5, 7, 10) else 1)
 
 
 def reset_variant(engine):
@@ -212,6 +216,8 @@ def test_train_synth_2mb_vs_oracle(engine, native, kind, mode, mimpl, slots, spa
                     assert stats["steps"] > 0 and stats["selections"] <= stats["steps"]
             else:
                 assert stats["lean"] > 0
+            if lean in (9, 10) and stats["index_builds"]:
+                assert stats["slot_ids"] == 256, stats  # (the stream was re-packed into 256-id slots when the index was built)
         assert res["pairs"] == exp[0]
         assert res["counts"] == exp[1]
         assert res["lens"] == exp[2]

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 obj = os.path.join(tempfile.gettempdir(), "bpe_api_res.o")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-fPIC",
        f"-I{ROOT}/include", f"-I{ROOT}/minbpe_amd/csrc", f"{ROOT}/minbpe_amd/csrc/bpe_api.hip", "-o", obj,
-       "-Rpass-analysis=kernel-resource-usage"]
+       "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 txt = subprocess.run(cmd, capture_output=True, text=True).stderr
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
 names = [b.split("\n")[0].strip() for b in blocks]
