@@ -19,7 +19,9 @@ tie-break, merge, pair-table update)):
 The headline workload is timed for --steps; the --secondary workloads (default
 basic1g,cfg2,regex1g_dedup,e2e_class,encode at N=1) run --secondary-steps each after it and are reported under
 "secondary".  N > 1: the chunk list of regex1g is sharded (contiguous chunk ranges,
---bytes per GPU = cfg4 shape, weak scaling); `value` is the rate of the ONE sharded job.
+--bytes per GPU = cfg4 shape, weak scaling); `value` = what ALL ranks processed per second
+(N x the job's merges/s: a merge of the one sharded job is applied to every rank's shard --
+the bench contract's whole-job aggregate), `job_merges_per_s` = the rate of the ONE job.
 
 Prints ONE JSON line on rank 0.  `roofline` = the dominant kernel class timed with
 hipEvents on the library's own stream inside the timed steps; `cpu_baseline` = the CPU
@@ -41,7 +43,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
 HBM_COPY_GBPS = 6290.0  # measured float4 copy, same guide
-PROFILE_ROUND = "r4"      # prefix of the committed rocprofv3 summaries under profiles/ this line attaches
+PROFILE_ROUND = "r5"      # prefix of the committed rocprofv3 summaries under profiles/ this line attaches
 
 WORKLOADS = {
     "regex1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=True,
@@ -244,7 +246,7 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode, 
     avg_launch_s = hp["ms"] / launches * 1e-3
     roofline = {
         "bound": "hbm",
-        "kernel": {"merge": "merge pass = k_merge_chain | k_merge_chain_dense | k_merge_chain_dense1 (a chain step: 1..8 "
+        "kernel": {"merge": "merge pass = k_merge_chain | k_merge_chain_dense | k_merge_chain_dense1 (a chain step: 1..15 "
                             "merges + their pair-table deltas in one sweep) | k_merge_ab_* + k_merge_aa (a general iteration)",
                    "pair_count": ("get_stats of every iteration: k_load_count (the first, on bytes) then the general histogram "
                                   "k_pair_count_h32 / k_pair_count_lds (recount mode)" if mode == 0 else
@@ -255,7 +257,7 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode, 
         "alg_bytes_per_launch": hp["alg_bytes"] // launches,
         "equivalent_work_GBps": round(alg_GBps, 1), "equivalent_work_frac": round(alg_GBps / HBM_PEAK_GBPS, 4),
         "note": "achieved / frac = PHYSICAL: HBM bytes per launch (`traffic`: 32 x the size-weighted TCC/EA request counters "
-                "of a rocprofv3 --pmc pass of this same command -- calibrated on known byte counts, profiles/r4_pmc_calibration.json "
+                "of a rocprofv3 --pmc pass of this same command -- calibrated on known byte counts, profiles/r4_pmc_calibration.json (round 4: the counters and the access patterns are the same) "
                 "-- committed profile, attached only when it was measured on these library sources) / the "
                 "hipEvent time of the pass / 8 TB/s.  equivalent_work_* = the SURVEY 8d ALGORITHMIC bytes, 4(2N_i + "
                 "N_{i+1}) per merge (what the reference's get_stats + merge touch), over the same time: the pass does "
@@ -564,6 +566,109 @@ def run_encode_workload(eng, steps, warmup, barrier, pairs=None, tables=("cfg3",
     return first
 
 
+def run_encode_long_workload(eng, pairs=None, n_docs=100_000):
+    """The encode paths the 1 M-document batch does not reach (its synthetic prose holds no chunk above 32 bytes):
+    (1) `long_chunks`: n_docs documents of the same text with URLs, identifiers, whitespace runs and letter noise spliced
+    in -- at least 1 % of the GPT-4-split chunks are 33 .. 4096 bytes (one wave per chunk with the chunk in LDS, k_enc_long)
+    and a few are longer (stream-wide rounds) -- the whole batch against oracle.encode;
+    (2) `basic_100mb`: BasicTokenizer.encode (basic.py:57-74: ONE chunk) of the 100 MB of configs[1] with its own 3840
+    merges.  oracle.encode is O(N x rounds) on one chunk (hours at this size): the answer is checked in full against the
+    stream TRAINING leaves resident for the same text (training applies the merges in order, which is encode of its own
+    input -- and that stream is pinned to the oracle: its length after every merge is in the golden digests of cfg2), and
+    against oracle.encode itself on a 300 kB text."""
+    import numpy as np
+    from minbpe_amd import _native
+    import oracle
+    out = {}
+    if pairs is None:
+        pairs = cfg3_merges(eng)
+    tp = np.asarray(pairs, dtype=np.int32)
+    # ---- (1) documents with long chunks
+    data, doc_offs = encode_docs()
+    doc_offs = doc_offs[:n_docs + 1]
+    text = bytes(data[:int(doc_offs[-1])])
+    rng = np.random.default_rng(7)
+    letters = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz", dtype=np.uint8)
+    urlc = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz/._-", dtype=np.uint8)
+    parts = []
+
+    def long_item(k):
+        if k < 5:
+            return b" https://" + rng.choice(urlc, int(rng.integers(30, 200))).tobytes()
+        if k < 8:
+            return b" " + rng.choice(letters, int(rng.integers(33, 400))).tobytes()
+        return b" " * int(rng.integers(34, 300))
+
+    for d in range(len(doc_offs) - 1):
+        a, b = int(doc_offs[d]), int(doc_offs[d + 1])
+        cuts = []
+        for f in (1, 2):
+            cut = a + (b - a) * f // 3
+            while cut < b and text[cut] != 32:
+                cut += 1
+            cuts.append(cut)
+        parts.append(text[a:cuts[0]])
+        parts.append(long_item(d % 10))
+        parts.append(text[cuts[0]:cuts[1]])
+        parts.append(long_item((d // 3) % 10))
+        if d % 2 == 0:
+            parts.append(long_item(5 + (d // 7) % 5))
+        if d % 2000 == 7:
+            parts.append(b" " + rng.choice(letters, int(rng.integers(1000, 9000))).tobytes())
+        parts.append(text[cuts[1]:b])
+    text2 = b"".join(parts)
+    arr = np.frombuffer(text2, dtype=np.uint8)
+    nl = np.flatnonzero((arr[:-1] == 10) & (arr[1:] == 10)).astype(np.uint64) + 2
+    doc2 = np.unique(np.concatenate([np.zeros(1, np.uint64), nl[nl < len(text2)]]))
+    offs, _first = _native.split_docs(text2, doc2, 4)
+    lens = np.diff(np.append(np.asarray(offs, dtype=np.uint64), np.uint64(len(text2)))).astype(np.int64)
+    eng.encode_batch(tp, None, text2, offs)
+    eng.set_option("profile", 2)
+    eng.prof_reset()
+    t0 = time.perf_counter()
+    ids, out_offs = eng.encode_batch(tp, None, text2, offs)
+    dt = time.perf_counter() - t0
+    dev_ms = eng.prof_read()["encode"]["ms"]
+    eng.set_option("profile", 0)
+    t0 = time.perf_counter()
+    oid, ooff = oracle.encode(tp, text2, offs)
+    ct = time.perf_counter() - t0
+    out["long_chunks"] = {
+        "workload": f"{len(doc2)} documents / {len(text2)} B / {len(offs)} GPT-4-split chunks, the headline's {len(tp)} merges",
+        "chunks_33_to_4096_B": int(((lens > 32) & (lens <= 4096)).sum()), "chunks_over_4096_B": int((lens > 4096).sum()),
+        "share_of_chunks_over_32_B": round(float((lens > 32).mean()), 4),
+        "share_of_bytes_in_chunks_over_32_B": round(float(lens[lens > 32].sum() / max(len(text2), 1)), 4),
+        "device_ms": round(dev_ms, 3), "ms_wall": round(dt * 1e3, 2), "tokens": int(len(ids)),
+        "parity": {"tokens_checked": int(len(oid)), "equal_oracle": bool(
+            len(oid) == len(ids) and np.array_equal(np.asarray(oid, dtype=np.int32), np.asarray(ids, dtype=np.int32))
+            and np.array_equal(np.asarray(ooff, dtype=np.uint64), np.asarray(out_offs, dtype=np.uint64)))},
+        "cpu_oracle_s": round(ct, 2),
+    }
+    del ids, out_offs, oid, ooff
+    # ---- (2) BasicTokenizer.encode of 100 MB
+    wl = dict(WORKLOADS["cfg2"])
+    bdata, _o, _ = make_input(wl)
+    nm = wl["vocab"] - 256
+    eng.load_bytes(bdata)
+    bp = np.asarray(eng.train(nm)["pairs"], dtype=np.int32)
+    trained = eng.read_ids().copy()
+    t0 = time.perf_counter()
+    bids, _boff = eng.encode_batch(bp, None, bdata, None)
+    bdt = time.perf_counter() - t0
+    small = bytes(synth_cached(100_000_000, wl["seed"])[50_000_000:50_300_000])
+    while small and (small[0] & 0xC0) == 0x80:
+        small = small[1:]
+    sid, _so = eng.encode_batch(bp, None, small, None)
+    oid, _oo = oracle.encode(bp, small, None)
+    out["basic_100mb"] = {
+        "workload": f"BasicTokenizer.encode: {len(bdata)} B as ONE chunk, its own {nm} merges (configs[1])",
+        "s_wall": round(bdt, 3), "MB_per_s": round(len(bdata) / bdt / 1e6, 1), "tokens": int(len(bids)),
+        "parity": {"equals_the_stream_training_leaves": bool(np.array_equal(bids, trained)),
+                   "equal_oracle_on_300kB": bool(np.array_equal(np.asarray(oid, dtype=np.int32), sid))},
+    }
+    return out
+
+
 def encode_traffic(tname):
     """HBM bytes of one encode step from the committed PMC pass of this command (profiles/), attached only
     when it was measured on these library sources."""
@@ -638,6 +743,11 @@ def main():
             "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic", "library": minbpe_amd.version(), "source_hash": source_hash()}
 
+    if name == "encode_long":
+        line.update({"metric": "batch encode, long chunks", "unit": "ms", "value": None, "encode_long": run_encode_long_workload(eng)})
+        print(json.dumps(line))
+        eng.close()
+        return
     if name == "encode":
         r = run_encode_workload(eng, args.steps, args.warmup, barrier)
         line.update({"metric": "batch encode docs/sec", "unit": "docs/s", "value": r["docs_per_s_device"],
@@ -675,13 +785,16 @@ def main():
         del data, offs, res
         sec = args.secondary
         if sec is None:
-            sec = ("basic1g,cfg2,regex1g_dedup,e2e_class,encode"
+            sec = ("basic1g,cfg2,regex1g_dedup,e2e_class,encode,encode_long"
                    if (args.workload is None and args.bytes is None and args.vocab is None) else "none")
         secondary = {}
         for sname in [s for s in sec.split(",") if s and s != "none"]:
             try:
                 if sname == "encode":  # BASELINE.json configs[4] (see run_encode_workload)
                     secondary[sname] = run_encode_workload(eng, 2, 1, barrier, plain_ref[0] if plain_ref else None)
+                    continue
+                if sname == "encode_long":  # long chunks and BasicTokenizer.encode (see run_encode_long_workload)
+                    secondary[sname] = run_encode_long_workload(eng, plain_ref[0] if plain_ref else None)
                     continue
                 if sname == "e2e_class":
                     secondary[sname] = run_e2e_class_workload(dict(WORKLOADS["regex1g"]), plain_ref)
@@ -748,7 +861,8 @@ def main():
             if mg["ms"] > 0 and mg["launches"]:
                 ach = alg / (mg["ms"] * 1e-3) / 1e9
                 roofline = {
-                    "bound": "hbm", "kernel": "merge pass of rank 0 (k_merge_ab_* + k_merge_aa) on its shard",
+                    "bound": "hbm", "kernel": "merge pass of rank 0 on its shard: k_merge_chain | k_merge_chain_dense | "
+                                             "k_merge_chain_dense1 (a chain step) | k_merge_ab_* + k_merge_aa (a general iteration)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                     "launches": mg["launches"], "avg_launch_ms": round(mg["ms"] / mg["launches"], 5),

@@ -45,7 +45,7 @@ int bpe_create(int device_id, bpe_ctx **out) {
                                  bpe::bpe_g4::IDX_H * 4)) != hipSuccess)
         return bail("hipFuncSetAttribute(dynamic LDS)", e);
     if ((e = hipMalloc((void **)&c->d_st, sizeof(DevState))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&c->d_scratch, 4 * sizeof(unsigned long long))) != hipSuccess)
+    if ((e = hipMalloc((void **)&c->d_scratch, 8 * sizeof(unsigned long long))) != hipSuccess)
         return bail("hipMalloc", e);
     *out = c;
     return BPE_OK;
@@ -68,7 +68,7 @@ void bpe_destroy(bpe_ctx *c) {
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
                     c->d_slot_off, c->d_slot_bsum, c->d_ids2, c->d_hdr[0], c->d_hdr[1],
                     c->d_dec_blob, c->d_dec_out, c->d_dec_voff, c->d_dec_off, c->d_dec_bsum, c->d_dec_ids,
-                    c->d_dec_len, c->d_wexp, c->d_round_lb, c->d_dp_ckey, c->d_dp_cfold, c->d_hdr2[0], c->d_hdr2[1], c->d_stage, c->d_idx, c->d_idx_tmp, c->d_idx_dirty, c->d_removed, c->d_smask, c->d_cand, c->d_dbits, c->d_lean_res, c->d_lean_sum, c->d_enc_tab, c->d_enc_rep, c->d_enc_mid, c->d_enc_midn, c->d_chain_req, c->d_pool, c->d_pool_gather};
+                    c->d_dec_len, c->d_wexp, c->d_round_lb, c->d_dp_ckey, c->d_dp_cfold, c->d_hdr2[0], c->d_hdr2[1], c->d_stage, c->d_idx, c->d_idx_tmp, c->d_idx_dirty, c->d_removed, c->d_smask, c->d_cand, c->d_dbits, c->d_lean_res, c->d_lean_sum, c->d_enc_tab, c->d_enc_rep, c->d_enc_mid, c->d_enc_midn, c->d_chain_req, c->d_pool, c->d_pool_gather, c->d_enc_huge};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
@@ -163,6 +163,8 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "enc_long")) {
+        c->enc_long = value != 0;
     } else if (!strcmp(name, "small_slots")) {
         if (value < 0 || value > 2) return fail(c, BPE_E_ARG, "small_slots: 0, 1 or 2");
         c->small_slots = (int)value;

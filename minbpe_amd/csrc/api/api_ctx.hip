@@ -128,7 +128,7 @@ struct bpe_ctx {
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
     PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
     uint32_t *d_pool_gather = nullptr;
-    int chain_scan = 31;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
+    int chain_scan = 63;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
                                               // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
     int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
                                               // token-disjoint pairs merged in one pass) instead of lean iterations, wherever those would run with the index live
@@ -164,6 +164,9 @@ struct bpe_ctx {
     uint32_t *d_enc_tmp = nullptr, *d_enc_len = nullptr;
     int32_t *d_enc_out = nullptr;
     unsigned long long *d_enc_off = nullptr, *d_enc_bsum = nullptr, *d_enc_long = nullptr;
+    unsigned long long *d_enc_huge = nullptr;  // chunks of more than ENC_LONG_MAX bytes: the stream-wide rounds' (k_enc_long hands them on)
+    int enc_long = 1;                          // option "enc_long": chunks of ENC_LMAX + 1 .. ENC_LONG_MAX bytes are encoded on the device, one wave
+                                               // per chunk (k_enc_long); 0 = all of them through the stream-wide rounds (round 4's path, a cross-check)
     unsigned long long *d_ht_keys = nullptr;
     uint32_t *d_ht_vals = nullptr;
     int32_t *d_merge_ids = nullptr;

@@ -123,6 +123,7 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
         TRY(dev_realloc(c, c->d_enc_tmp, (size_t)n));
         TRY(dev_realloc(c, c->d_enc_out, (size_t)n));
         TRY(dev_realloc(c, c->d_enc_long, (size_t)(n / (ENC_LMAX + 1) + 2)));
+        TRY(dev_realloc(c, c->d_enc_huge, (size_t)(n / (ENC_LONG_MAX + 1) + 2)));
         c->cap_enc_n = n;
     }
     const uint64_t nb = (n_chunks + SCAN_TILE - 1) / SCAN_TILE;
@@ -153,9 +154,10 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
                            tslots);
         LAUNCHCHK(c, "k_enc_tab_init");
     }
-    unsigned long long *d_nlong = c->d_scratch, *d_total = c->d_scratch + 1;
+    unsigned long long *d_nlong = c->d_scratch, *d_total = c->d_scratch + 1, *d_nhuge = c->d_scratch + 4;
     uint32_t *d_min = (uint32_t *)(c->d_scratch + 2);
     HIPCHK(c, hipMemsetAsync(c->d_scratch, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(d_nhuge, 0, sizeof(unsigned long long), c->stream));
     const uint32_t mask = (uint32_t)(hs - 1);
     // 4. one chunk per lane -- with the cache, one DISTINCT chunk per lane
     TRY(prof_begin(c, BPE_PROF_ENCODE, n));
@@ -180,27 +182,51 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
                            c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
                            c->d_enc_long, d_nlong);
     LAUNCHCHK(c, "k_encode_short");
+    // 5. chunks of more than ENC_LMAX bytes: one wave per chunk with the chunk in LDS (k_enc_long), straight off the list
+    // pass 1 made -- its length stays on the device; what is longer than ENC_LONG_MAX goes on to d_enc_huge
+    if (c->enc_long) {
+        const unsigned glong = (unsigned)std::min<uint64_t>(n / (ENC_LMAX + 1) + 1, (uint64_t)c->num_cus * 16);
+        hipLaunchKernelGGL((k_enc_long<ENC_LONG_MID, 64>), dim3(glong), dim3(64), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
+                           c->d_enc_long, d_nlong, c->d_ht_keys, c->d_ht_vals, mask, d_mids, c->d_enc_tmp, c->d_enc_len,
+                           c->d_enc_huge, d_nhuge, (uint32_t)ENC_LMAX);
+        hipLaunchKernelGGL((k_enc_long<ENC_LONG_MAX, 256>), dim3(std::min(glong, (unsigned)c->num_cus * 2)), dim3(256), 0, c->stream,
+                           c->d_bytes, d_offs, n_chunks, n, c->d_enc_long, d_nlong, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
+                           c->d_enc_tmp, c->d_enc_len, c->d_enc_huge, d_nhuge, (uint32_t)ENC_LONG_MID);
+        LAUNCHCHK(c, "k_enc_long");
+    }
     TRY(prof_end(c));
     unsigned long long n_long = 0;
-    HIPCHK(c, hipMemcpyAsync(&n_long, d_nlong, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n_long, c->enc_long ? d_nhuge : d_nlong, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // 5. the few long chunks: stream-wide rounds (lowest rank present -> merge everywhere)
+    // ... and the chunks beyond that (a BasicTokenizer text is ONE chunk): stream-wide rounds (lowest rank present ->
+    // merge everywhere)
     if (n_long) {
+        const unsigned long long *d_list = c->enc_long ? c->d_enc_huge : c->d_enc_long;
         std::vector<unsigned long long> ids_l(n_long);
-        HIPCHK(c, hipMemcpy(ids_l.data(), c->d_enc_long, n_long * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(ids_l.data(), d_list, n_long * 8, hipMemcpyDeviceToHost));
         std::sort(ids_l.begin(), ids_l.end());
         std::vector<unsigned long long> src(n_long), dst(n_long + 1);
         unsigned long long tot = 0;
-        for (uint64_t k = 0; k < n_long; k++) {
-            const uint64_t ch = ids_l[k];
-            uint64_t se[2] = {0, n};
-            if (resident) {  // (a handful of chunks: two words each from the caller's device array)
-                HIPCHK(c, hipMemcpy(se, chunk_offsets + ch, (ch + 1 < n_chunks ? 2 : 1) * 8, hipMemcpyDeviceToHost));
-            } else {
-                se[0] = chunk_offsets[ch];
-                if (ch + 1 < n_chunks) se[1] = chunk_offsets[ch + 1];
+        std::vector<unsigned long long> range(2 * n_long);
+        if (resident) {  // (the caller's offsets live on the device: the chunks' byte ranges in one kernel and one copy)
+            DevTmp t_list, t_range;
+            HIPCHK(c, t_list.alloc(n_long * 8));
+            HIPCHK(c, t_range.alloc(2 * n_long * 8));
+            HIPCHK(c, hipMemcpyAsync(t_list.as<unsigned long long>(), ids_l.data(), n_long * 8, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_long_ranges, dim3((unsigned)((n_long + 255) / 256)), dim3(256), 0, c->stream, d_offs, n_chunks, n,
+                               t_list.as<unsigned long long>(), (uint64_t)n_long, t_range.as<unsigned long long>());
+            LAUNCHCHK(c, "k_long_ranges");
+            HIPCHK(c, hipMemcpyAsync(range.data(), t_range.as<unsigned long long>(), 2 * n_long * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        } else {
+            for (uint64_t k = 0; k < n_long; k++) {
+                const uint64_t ch = ids_l[k];
+                range[2 * k] = chunk_offsets[ch];
+                range[2 * k + 1] = ch + 1 < n_chunks ? chunk_offsets[ch + 1] : n;
             }
-            const uint64_t s0 = se[0], e0 = se[1];
+        }
+        for (uint64_t k = 0; k < n_long; k++) {
+            const uint64_t s0 = range[2 * k], e0 = range[2 * k + 1];
             src[k] = s0;
             dst[k] = tot;
             tot += e0 - s0;

@@ -37,7 +37,10 @@ constexpr int MT = 256;
     constexpr int IDX_SHIFT = 32 - IDXH_LOG2;                                                                    \
     }
 BPE_GEOMETRY(bpe_g4, 4, 15)
-BPE_GEOMETRY(bpe_g1, 1, 13)
+#ifndef BPE_G1_IDXH_LOG2
+#define BPE_G1_IDXH_LOG2 13
+#endif
+BPE_GEOMETRY(bpe_g1, 1, BPE_G1_IDXH_LOG2)
 constexpr int TILE2_MAX = 1024, TILE2_MIN = 256;
 
 // pair-count kernels: one 1024-thread workgroup per CU using all 128 KiB of dynamic LDS

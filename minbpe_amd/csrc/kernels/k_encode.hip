@@ -671,6 +671,140 @@ k_long_scatter(const uint32_t *__restrict__ ids, const unsigned long long *__res
     if (threadIdx.x == 0) outlen[chunk_id[k]] = (uint32_t)len;
 }
 
+// ---------------------------------------------------------------------------
+// Long chunks on the device (lengths ENC_LMAX + 1 .. ENC_LONG_MAX bytes: URLs, code, whitespace runs): one workgroup
+// per chunk -- ONE WAVE up to ENC_LONG_MID bytes, four waves beyond --, the chunk's tokens and the ranks of its adjacent
+// pairs in LDS.  A round is what one iteration of the reference's loop does (regex.py:92-109 == basic.py:57-74): the
+// lowest rank present (a minimum over the rank array), every occurrence of that pair merged left to right (an a == a
+// run is walked by the thread that owns its start: the greedy pairing of base.py:25-41), the survivors compacted into
+// the other buffer (ballots per 64 positions, one scan over the ballots' counts), and only the ranks next to a new
+// token looked up again -- no stream-wide pass, no host round trip.  Thread t owns positions t, t + NT, ... .  The
+// launch works through the list pass 1 left (its length is read on the device); CAP = the most bytes this
+// instantiation takes, chunks of `lo` bytes or fewer belong to a smaller one, longer ones go on to `huge_list` (the
+// stream-wide rounds of api_encode.hip: a BasicTokenizer text is one such chunk).
+constexpr uint32_t ENC_LONG_MID = 512, ENC_LONG_MAX = 4096;
+template <uint32_t CAP, uint32_t NT>
+__global__ void __launch_bounds__(NT)
+k_enc_long(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
+           const unsigned long long *__restrict__ long_list, const unsigned long long *__restrict__ n_long,
+           const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ vals, uint32_t mask,
+           const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
+           unsigned long long *__restrict__ huge_list, unsigned long long *__restrict__ n_huge, uint32_t lo) {
+    constexpr uint32_t NW = NT / 64, NB = CAP / 64;  // waves; groups of 64 positions (one ballot each)
+    static_assert(NB <= 64 && CAP % NT == 0, "one wave scans the ballots' counts");
+    __shared__ uint32_t s_tok[2][CAP], s_rk[2][CAP];
+    __shared__ uint8_t s_fl[CAP];
+    __shared__ uint32_t s_cnt[NB], s_red[NW], s_len;
+    constexpr uint32_t NONE = 0xFFFFFFFFu, REDO = 0xFFFFFFFEu;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    auto sync = [] {
+        if (NT == 64) {  // (one wave: its LDS operations complete in issue order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
+    const unsigned long long nl = *n_long;
+    for (unsigned long long k = blockIdx.x; k < nl; k += gridDim.x) {
+        const unsigned long long c = long_list[k];
+        const uint64_t s0 = off[c];
+        const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
+        const uint64_t Lb = e0 - s0;
+        if (Lb <= lo || Lb > CAP) {  // (uniform) not this instantiation's
+            if (CAP == ENC_LONG_MAX && Lb > CAP && tid == 0) huge_list[atomicAdd(n_huge, 1ull)] = c;
+            continue;
+        }
+        uint32_t L = (uint32_t)Lb, cur = 0;
+        for (uint32_t i = tid; i < L; i += NT) s_tok[0][i] = bytes[s0 + i];
+        sync();
+        for (uint32_t i = tid; i < L; i += NT)
+            s_rk[0][i] = (i + 1 < L) ? rank_lookup(keys, vals, mask, s_tok[0][i], s_tok[0][i + 1]) : NONE;
+        sync();
+        for (;;) {
+            const uint32_t *tok = s_tok[cur], *rk = s_rk[cur];
+            uint32_t *ntok = s_tok[cur ^ 1], *nrk = s_rk[cur ^ 1];
+            uint32_t m = NONE;
+            for (uint32_t i = tid; i + 1 < L; i += NT) m = min(m, rk[i]);
+            m = wave_umin_dpp(m);
+            if (NW > 1) {
+                if (lane == 0) s_red[wave] = m;
+                sync();
+#pragma unroll
+                for (uint32_t w = 0; w < NW; w++) m = min(m, s_red[w]);
+            }
+            if (m >= REDO) break;  // (uniform) nothing else can be merged
+            const uint32_t Z = merge_ids ? (uint32_t)merge_ids[m] : 256u + m;
+            // bit 0: the pair starts here; bit 1: ... and is merged (a run of overlapping occurrences -- a == a only --
+            // takes every other one, from its left end)
+            for (uint32_t i = tid; i < L; i += NT) s_fl[i] = (i + 1 < L && rk[i] == m) ? 1 : 0;
+            sync();
+            for (uint32_t i = tid; i + 1 < L; i += NT) {
+                if ((s_fl[i] & 1) && (i == 0 || !(s_fl[i - 1] & 1))) {
+                    bool take = true;
+                    for (uint32_t j = i; j + 1 < L && (s_fl[j] & 1); j++) {
+                        if (take) s_fl[j] |= 2;
+                        take = !take;
+                    }
+                }
+            }
+            sync();
+            // survivors: everything but the second token of a merged pair.  One ballot per group of 64 positions, the
+            // counts scanned by wave 0, then every survivor knows its new place
+            const uint32_t ngroups = (L + 63) / 64;
+            for (uint32_t g = wave; g < ngroups; g += NW) {
+                const uint32_t i = g * 64 + lane;
+                const bool kp = i < L && !(i > 0 && (s_fl[i - 1] & 2));
+                const unsigned long long bal = __ballot(kp);
+                if (lane == 0) s_cnt[g] = (uint32_t)__popcll(bal);
+            }
+            sync();
+            if (wave == 0) {
+                const uint32_t v = lane < ngroups ? s_cnt[lane] : 0u;
+                const uint32_t inc = wave_iscan_add(v);
+                if (lane < ngroups) s_cnt[lane] = inc - v;
+                if (lane == 63) s_len = inc;
+            }
+            sync();
+            for (uint32_t g = wave; g < ngroups; g += NW) {
+                const uint32_t i = g * 64 + lane;
+                const bool in = i < L;
+                const bool kp = in && !(i > 0 && (s_fl[i - 1] & 2));
+                const unsigned long long bal = __ballot(kp);
+                if (kp) {
+                    const uint32_t p = s_cnt[g] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    const bool site = (s_fl[i] & 2) != 0;
+                    // the rank to the right of a new token, and of the token before one, is looked up below
+                    const bool next_site = (i + 1 < L) && (s_fl[i + 1] & 2);
+                    ntok[p] = site ? Z : tok[i];
+                    nrk[p] = (site || next_site) ? REDO : rk[i];
+                }
+            }
+            const uint32_t Ln = s_len;
+            sync();
+            L = Ln;
+            cur ^= 1;
+            for (uint32_t i = tid; i < L; i += NT)
+                if (nrk[i] == REDO) nrk[i] = (i + 1 < L) ? rank_lookup(keys, vals, mask, ntok[i], ntok[i + 1]) : NONE;
+            sync();
+        }
+        for (uint32_t i = tid; i < L; i += NT) tmp[s0 + i] = s_tok[cur][i];
+        if (tid == 0) outlen[c] = L;
+        sync();  // (the next chunk overwrites the buffers)
+    }
+}
+// the byte ranges of the chunks the stream-wide rounds take, in one pass (instead of a copy per chunk)
+__global__ void __launch_bounds__(256)
+k_long_ranges(const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n, const unsigned long long *__restrict__ list,
+              uint64_t n_list, unsigned long long *__restrict__ range) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_list) return;
+    const unsigned long long c = list[k];
+    range[2 * k] = off[c];
+    range[2 * k + 1] = (c + 1 < n_chunks) ? off[c + 1] : n;
+}
+
 // exclusive scan of the per-chunk output lengths (u32 -> u64), three small kernels
 __global__ void __launch_bounds__(256)
 k_scan_blocksum(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ bsum) {

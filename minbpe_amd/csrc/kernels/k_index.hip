@@ -36,6 +36,11 @@ __device__ __forceinline__ void index_add(uint32_t *__restrict__ idx, uint32_t s
     atomicOr(&idx[(size_t)h1 * stride + g], bit);
     atomicOr(&idx[(size_t)h2 * stride + g], bit);
     atomicOr(&idx[(size_t)h3 * stride + g], bit);
+#ifdef BPE_DUMMY_ATOMICS  // (experiment: what do the index's atomics cost a pass?  three more that change nothing)
+    atomicOr(&idx[(size_t)(h1 ^ 1u) * stride + g], 0u);
+    atomicOr(&idx[(size_t)(h2 ^ 1u) * stride + g], 0u);
+    atomicOr(&idx[(size_t)(h3 ^ 1u) * stride + g], 0u);
+#endif
 }
 
 // The candidate list of a sparse pass, made by ONE 1024-thread block (the block of k_select

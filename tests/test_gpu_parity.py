@@ -381,6 +381,52 @@ def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits)
     assert np.array_equal(out_off, exp_off)
 
 
+def _long_chunk_text(native, seed):
+    """chunks of 33 .. 6000 bytes among ordinary ones: URLs, identifiers, whitespace runs (a == a merges inside a chunk),
+    a run of one letter, base64-like noise -- what code and logs put behind a GPT-style split"""
+    rng = np.random.default_rng(seed)
+    base = native.synth_text(60_000, seed).decode()
+    words = base.split(" ")
+    parts = []
+    for i, w in enumerate(words):
+        parts.append(w)
+        if i % 17 == 3:
+            parts.append("https://" + "".join(rng.choice(list("abcdefghij/._-0123456789"), int(rng.integers(30, 400)))))
+        if i % 29 == 5:
+            parts.append("x" + "_".join(words[max(0, i - 9):i + 1])[:int(rng.integers(33, 300))])
+        if i % 41 == 7:
+            parts.append("a" * int(rng.integers(33, 700)))
+        if i % 53 == 11:
+            parts.append("".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"),
+                                            int(rng.integers(500, 6000)))))
+        if i % 37 == 9:
+            parts.append(" " * int(rng.integers(34, 900)) + "\n")
+    return " ".join(parts)
+
+
+@pytest.mark.parametrize("enc_long", [1, 0])
+@pytest.mark.parametrize("cache", [1, 0])
+def test_encode_batch_long_chunks_on_the_device(engine, native, cache, enc_long):
+    """Chunks of more than 32 bytes (regex.py:92-109 on URLs, identifiers, whitespace runs): one wave per chunk with
+    the chunk in LDS (k_enc_long, lengths up to 512 and up to 4096 bytes), the stream-wide rounds beyond that -- and
+    option enc_long = 0, every long chunk through the rounds -- all equal to oracle.encode."""
+    pairs = _train_pairs(native, 300_000, 900, 61, "regex")
+    text = _long_chunk_text(native, 62)
+    data, offs = split_chunks(text)
+    lens = np.diff(np.append(offs, len(data)))
+    assert (lens > 32).sum() > 300 and (lens > 512).sum() > 20 and (lens > 4096).sum() >= 3
+    exp_ids, exp_off = oracle.encode(pairs, data, offs)
+    engine.set_option("enc_cache", cache)
+    engine.set_option("enc_long", enc_long)
+    try:
+        ids, out_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+    finally:
+        engine.set_option("enc_cache", 1)
+        engine.set_option("enc_long", 1)
+    assert np.array_equal(out_off, exp_off)
+    assert np.array_equal(ids, exp_ids)
+
+
 _BIG_TABLE = {}
 
 
