@@ -120,8 +120,10 @@ int bpe_train(bpe_ctx *ctx, int32_t num_merges, int32_t *pairs_out,
  * minbpe_amd/dist.py) -- ids and the table never move:
  *
  *   bpe_dp_begin(num_merges, rank, nranks)   widen + local byte-pair counts
- *   [all-reduce SUM   table   (int32 x 65536)]
- *   bpe_dp_table_ready()
+ *   [all-reduce SUM   table   (int32 x 2 x 65536: every count as two 16-bit limbs, low halves then high halves,
+ *                              so that the sum over up to 1024 ranks cannot wrap)]
+ *   bpe_dp_table_ready()                     the GLOBAL counts from the summed limbs; BPE_E_LIMIT on EVERY rank if a
+ *                                            pair occurs 2^32 times or more in the whole job (counts are 32-bit)
  *   for i in range(num_merges):
  *       bpe_dp_select(i)                     arg-max on the replica; local tie-break candidate
  *       [all-reduce MIN   tiekey  (int64 x 3)]   lowest (rank, position) wins the tie (F3/F5);

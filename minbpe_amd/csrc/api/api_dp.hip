@@ -24,15 +24,15 @@ extern "C" int bpe_dp_begin(bpe_ctx *c, int32_t num_merges, int32_t rank, int32_
     c->d_dp_folded = nullptr;
     HIPCHK(c, hipMalloc((void **)&c->d_dp_folded, ((size_t)c->vcap * 4 + 64) * sizeof(uint32_t)));
     HIPCHK(c, hipMemsetAsync(c->d_dp_folded, 0, ((size_t)c->vcap * 4 + 64) * sizeof(uint32_t), c->stream));
-    if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 256 * 256 * sizeof(uint32_t)));
+    if (!c->d_dp_table) HIPCHK(c, hipMalloc((void **)&c->d_dp_table, 2 * 256 * 256 * sizeof(uint32_t)));
     if (!c->d_dp_key) HIPCHK(c, hipMalloc((void **)&c->d_dp_key, 3 * sizeof(long long)));
     HIPCHK(c, hipMemsetAsync(c->d_mat, 0, (size_t)c->vcap * c->vcap * sizeof(uint32_t), c->stream));
     const bool fused_load = load_count_fusable(c);
     TRY(start_from_bytes(c, fused_load));
     if (!fused_load) TRY(launch_pair_count(c, false));
-    // the byte-pair block of the table, packed, is the first all-reduce payload
-    HIPCHK(c, hipMemcpy2DAsync(c->d_dp_table, 256 * 4, c->d_mat, (size_t)c->vcap * 4, 256 * 4, 256,
-                               hipMemcpyDeviceToDevice, c->stream));
+    // the byte-pair block of the table, as 16-bit limbs (the sum over the ranks cannot wrap), is the first all-reduce payload
+    hipLaunchKernelGGL(k_dp_table_split, dim3(256), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_dp_table);
+    LAUNCHCHK(c, "k_dp_table_split");
     c->dp_cur_len = c->n;
     c->dp_enq = c->dp_done = 0;
     c->rep_shift = 5;
@@ -50,7 +50,7 @@ extern "C" int bpe_dp_buffers(bpe_ctx *c, void **table, uint64_t *table_count, v
                               uint64_t *delta_count, void **tiekey) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     if (table) *table = c->d_dp_table;
-    if (table_count) *table_count = 256 * 256;
+    if (table_count) *table_count = 2 * 256 * 256;  // (low limbs, then high limbs)
     if (delta) *delta = c->d_dp_folded;
     if (delta_count) *delta_count = (uint64_t)c->vcap * 4 + 64;  // four vectors + the format-B adj word (padded)
     if (tiekey) *tiekey = c->d_dp_key;
@@ -60,8 +60,17 @@ extern "C" int bpe_dp_buffers(bpe_ctx *c, void **table, uint64_t *table_count, v
 extern "C" int bpe_dp_table_ready(bpe_ctx *c) {
     if (!c || !c->d_dp_folded) return fail(c, BPE_E_STATE, "bpe_dp_begin first");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy2DAsync(c->d_mat, (size_t)c->vcap * 4, c->d_dp_table, 256 * 4, 256 * 4, 256,
-                               hipMemcpyDeviceToDevice, c->stream));
+    // the GLOBAL counts from the summed limbs; a pair that occurs 2^32 times or more in the whole job does not fit the
+    // 32-bit table -- every rank sees the same sums, so every rank fails here, before any further collective
+    HIPCHK(c, hipMemsetAsync(c->d_scratch + 5, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_dp_table_join, dim3(256), dim3(256), 0, c->stream, c->d_dp_table, c->d_mat, c->vcap, c->d_scratch + 5);
+    LAUNCHCHK(c, "k_dp_table_join");
+    unsigned long long over = 0;
+    HIPCHK(c, hipMemcpyAsync(&over, c->d_scratch + 5, sizeof over, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (over)
+        return fail(c, BPE_E_LIMIT, "a byte pair occurs %llu times in the %d shards together: counts are 32-bit "
+                    "(every rank stops here)", over, c->dp_nranks);
     c->vcur = 256;
     hipLaunchKernelGGL(k_rowmax_all, dim3(256), dim3(256), 0, c->stream, c->d_mat, c->vcap, 256u,
                        c->d_rowmax);

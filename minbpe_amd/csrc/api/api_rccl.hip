@@ -14,6 +14,7 @@ struct RcclApi {
     int (*CommInitRank)(void **, int, RcclUid, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;  // (optional)
     const char *(*GetErrorString)(int) = nullptr;
 };
 constexpr int RCCL_INT32 = 2, RCCL_INT64 = 4, RCCL_SUM = 0, RCCL_MIN = 3;  // rccl.h: ncclDataType_t / ncclRedOp_t
@@ -32,6 +33,7 @@ RcclApi *rccl() {
             api.CommInitRank = (int (*)(void **, int, RcclUid, int))dlsym(api.h, "ncclCommInitRank");
             api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.h, "ncclAllReduce");
             api.CommDestroy = (int (*)(void *))dlsym(api.h, "ncclCommDestroy");
+            api.CommAbort = (int (*)(void *))dlsym(api.h, "ncclCommAbort");
             api.GetErrorString = (const char *(*)(int))dlsym(api.h, "ncclGetErrorString");
             if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.h = nullptr;
         }
@@ -100,7 +102,8 @@ extern "C" int bpe_comm_destroy(bpe_ctx *c) {
 // is exchanged.  The host runs `depth` units ahead and waits on records only, as on one GPU; a deferral drains the
 // queue on every rank at the same unit (the step records are replicas).  After a device status every later unit is a
 // no-op whose collectives still pair up.  A host-side failure (a HIP or comm call that returns an error) cannot be
-// recovered from: the stream is lost, the peers are left to their own time-outs.
+// recovered from: the stream is lost; bpe_dp_train then aborts the library's communicator so that the peers fail
+// instead of waiting (ncclCommAbort), a caller's communicator (bpe_dp_train_cb) is left to the caller's time-out.
 namespace {
 int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *pairs_out, uint64_t *counts_out,
                   uint64_t *len_out, int32_t *n_done) {
@@ -122,7 +125,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
     }
     HIPCHK(c, hipMemsetAsync(c->d_dp_cfold, 0, cfold_words * sizeof(uint32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_dp_ckey, 0, DP_KEY_WORDS * sizeof(long long), c->stream));
-    TRY(dp_allreduce(c, c->d_dp_table, 256 * 256, BPE_DT_INT32, BPE_OP_SUM));
+    TRY(dp_allreduce(c, c->d_dp_table, 2 * 256 * 256, BPE_DT_INT32, BPE_OP_SUM));  // (16-bit limbs: bpe_dp_begin)
     TRY(bpe_dp_table_ready(c));
 
     enum { U_GENERAL = 0, U_CHAIN = 2 };
@@ -375,7 +378,17 @@ extern "C" int bpe_dp_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, 
     comm.user = c;
     comm.rank = c->comm_rank;
     comm.nranks = c->comm_nranks;
-    return dp_train_loop(c, num_merges, comm, pairs_out, counts_out, len_out, n_done);
+    const int rc = dp_train_loop(c, num_merges, comm, pairs_out, counts_out, len_out, n_done);
+    // A device status stops every rank at the same merge (it travels with the collectives).  A HOST-side failure on this
+    // rank alone -- a HIP or RCCL call that returned an error, a unit that never reported -- leaves the peers inside a
+    // collective this rank will never join: abort the communicator, so that they fail with an RCCL error instead of
+    // waiting for ever (the communicator is gone afterwards: bpe_comm_init again).  With bpe_dp_train_cb the
+    // collectives are the caller's, and so is their time-out (torch.distributed: the process group's).
+    if ((rc == BPE_E_HIP || rc == BPE_E_INTERNAL) && c->comm && rccl()->CommAbort) {
+        (void)rccl()->CommAbort(c->comm);
+        c->comm = nullptr;
+    }
+    return rc;
 }
 
 // the caller's all-reduce (torch.distributed through a ctypes callback, a test's host-side reduction)

@@ -118,5 +118,25 @@ k_dp_fold(uint32_t *__restrict__ delta, uint32_t vcap, uint32_t Z, uint32_t *__r
     }
 }
 
+// The first all-reduce payload of a sharded job: the 256 x 256 block of byte-pair counts as 16-bit LIMBS -- out[i] = the
+// low half of this shard's count i, out[65536 + i] = its high half -- so that the INT32 sum over up to 1024 ranks cannot
+// wrap (each limb sum stays below 2^26) and every rank sees the exact GLOBAL count: k_dp_table_join writes
+// the replica's table from the summed limbs and raises `over` when a pair occurs 2^32 times or more in the whole job
+// (table entries, and every later count, are 32-bit: every later count is bounded by the largest of these).
+__global__ void __launch_bounds__(256)
+k_dp_table_split(const uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // row blockIdx.x, column threadIdx.x
+    const uint32_t v = mat[(size_t)blockIdx.x * stride + threadIdx.x];
+    out[i] = v & 0xFFFFu;
+    out[65536u + i] = v >> 16;
+}
+__global__ void __launch_bounds__(256)
+k_dp_table_join(const uint32_t *__restrict__ in, uint32_t *__restrict__ mat, uint32_t stride, unsigned long long *__restrict__ over) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const unsigned long long g = ((unsigned long long)in[65536u + i] << 16) + in[i];
+    if (g >> 32) atomicMax(over, g);
+    mat[(size_t)blockIdx.x * stride + threadIdx.x] = (uint32_t)g;
+}
+
 }  // namespace BPE_G
 }  // namespace bpe

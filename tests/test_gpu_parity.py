@@ -651,6 +651,39 @@ def test_dp_lockstep_ties_and_exhaustion(native):
     assert len(exp[0]) < 400  # the table ran empty: every rank stopped at the same merge
 
 
+def test_dp_global_count_guard(native):
+    """table entries are 32-bit, the first all-reduce carries the byte-pair counts as 16-bit limbs, so the
+    sum over the ranks is exact -- and a job in which some pair occurs 2^32 times or more fails on EVERY rank at
+    bpe_dp_table_ready (BPE_E_LIMIT), before any further collective.  A degenerate shard (one letter, 48 M pairs) as
+    rank r of 128: summing 128 identical payloads is what the all-reduce of 128 such shards would deliver."""
+    torch = pytest.importorskip("torch")
+    from minbpe_amd.dist import GpuShard
+    data = b"a" * 48_000_001
+    ok_world, bad_world = 64, 128  # 64 x 48 M < 2^32 <= 128 x 48 M
+    for world, fails in ((ok_world, False), (bad_world, True)):
+        for rank in (0, world - 1):
+            eng = native.Engine(0)
+            try:
+                eng.load_bytes(data)
+                sh = GpuShard(eng, 0)
+                sh.begin(4, rank, world)
+                assert sh.table.numel() == 2 * 65536
+                lo, hi = int(sh.table[97 * 256 + 97]), int(sh.table[65536 + 97 * 256 + 97])
+                assert (hi << 16) + lo == 48_000_000
+                sh.table.mul_(world)  # (the SUM over `world` identical shards: no limb sum reaches 2^31)
+                assert int(sh.table.max()) < 2**31
+                if fails:
+                    with pytest.raises(RuntimeError, match="32-bit"):
+                        sh.table_ready()
+                else:
+                    sh.table_ready()
+                    sh.select(0)
+                    torch.cuda.synchronize()
+                sh.end()
+            finally:
+                eng.close()
+
+
 def _chain_ranks(native, chunks, nm, world, opts=(), dedup=False):
     """bpe_dp_train_cb (the sharded loop of chain steps) on `world` ctxs of the one GPU we have, one thread per rank;
     the all-reduces are done on the host between barriers.  Returns every rank's result dict."""
