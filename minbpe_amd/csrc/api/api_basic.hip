@@ -163,6 +163,10 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "chain_prefetch")) {
+        c->chain_prefetch = value != 0;
+    } else if (!strcmp(name, "count_is_removed")) {
+        c->count_is_removed = value != 0;
     } else if (!strcmp(name, "enc_long")) {
         c->enc_long = value != 0;
     } else if (!strcmp(name, "small_slots")) {

@@ -122,6 +122,9 @@ struct bpe_ctx {
     int small_slots = 1;                      // option "small_slots": re-pack into 256-id slots when the inverted index is first built (a large
                                               // stream going sparse: a merge site then costs 1 KiB of its slot, not 4); 2 = streams of a few thousand
                                               // slots too (tests)
+    int count_is_removed = 1;                 // option "count_is_removed": chain steps of an unweighted stream take the ids a merge removes from the pair's
+                                              // count instead of counting them (0: count, the cross-check)
+    int chain_prefetch = 1;                   // option "chain_prefetch": 256-id slots -- a wave's next candidate slot is loaded while it works on this one
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
                                               // across steps) instead of k_chain_sel (one count level at a time); sharded training keeps k_chain_sel
@@ -1181,7 +1184,10 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     A.idx = c->idx_live ? c->d_idx : nullptr;
     A.istride = (uint32_t)c->idx_cap_words;
     A.cand = nullptr;
-    A.removed = c->d_removed;
+    // (an unweighted stream: a != b merges remove exactly `count` ids -- no removal counters, one atomic less per site;
+    // sharded steps keep them: the count is the GLOBAL one, the ids removed are this shard's)
+    uint32_t *const removed = (c->weighted || dp || !c->count_is_removed) ? c->d_removed : nullptr;
+    A.removed = removed;
     A.dirty_n = c->d_dirty_n;
     const uint32_t nwords = (T + 31) / 32;
     TRY(prof_begin(c, BPE_PROF_MERGE, 0));
@@ -1194,7 +1200,8 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         hipLaunchKernelGGL(GK(c, k_merge_chain_dense1), dim3(g1), dim3(MT), 0, c->stream, A);
     } else {
         const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
-        hipLaunchKernelGGL(GK(c, k_merge_chain), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty, use_index ? 1u : 0u, c->d_dbits);
+        hipLaunchKernelGGL(GK(c, k_merge_chain), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
+                           (use_index ? 1u : 0u) | (c->chain_prefetch ? 2u : 0u), c->d_dbits);
     }
     LAUNCHCHK(c, "k_merge_chain");
     TRY(prof_end(c));
@@ -1210,7 +1217,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     }
     hipLaunchKernelGGL(GK(c, k_apply_chain), dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl, c->d_rowmax,
                        c->d_st, c->d_dbits, c->par, c->h_rec, c->h_srec, step, na, c->d_hdr2[c->mq], c->d_stage,
-                       c->d_removed, c->d_smask, nwords, c->d_lean_sum, dp ? c->d_dp_cfold : (const uint32_t *)nullptr, fS,
+                       removed, c->d_smask, nwords, c->d_lean_sum, dp ? c->d_dp_cfold : (const uint32_t *)nullptr, fS,
                        (const uint32_t *)ftail);
     LAUNCHCHK(c, "k_apply_chain");
     TRY(prof_end(c));

@@ -65,24 +65,27 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
 // ids removed; every id is below LDSD_CAP), flushed by the kernel when its slots are done.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
 // pb1[0] a word that matches nothing, z0: pair p becomes z0 + p.
 constexpr uint32_t CH_SD = 2 * LDSD_CAP + 2;  // words of one pair's LDS delta tables
+// the loads of a slot that depend on nothing but its number: its words (speculatively from buffer 0, where a slot lives
+// unless an a == b pass moved it) and the headers of slots t - 1, t, t + 1 as six 16-byte pieces on lanes 0..5
+__device__ __forceinline__ void chain_slot_load(const AbArgs &A, const uint32_t t, uint4 (&rv)[MJ], uint4 &hv) {
+    const int lane = lane_id();
+    const uint32_t *src = A.b0 + (size_t)t * TILE2;
+#pragma unroll
+    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
+    hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u) : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    const long long hi = 2ll * (long long)t - 2 + lane;
+    if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
+}
+// (rv / hv: the slot's loads, issued by the caller -- k_merge_chain issues the NEXT slot's before it works on this one)
 template <bool DENSE>
 __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t, const AbArgs &A,
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
                                                  const uint32_t K, const uint32_t z0, const uint32_t brep,
+                                                 uint4 (&rv)[MJ], const uint4 hv,
                                                  const uint32_t *ph = nullptr, const uint32_t hm = 0) {
     const int lane = lane_id();
     const uint32_t Tl = min(A.T, A.st->tlive);
-    // ---- (1) every load that does not depend on another one -------------------------------
-    const uint32_t *src = A.b0 + (size_t)t * TILE2;
-    uint4 rv[MJ];
-#pragma unroll
-    for (int j = 0; j < MJ; j++) rv[j] = *reinterpret_cast<const uint4 *>(src + j * 256 + lane * 4);
-    uint4 hv = (lane & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u)
-                          : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
-    {
-        const long long hi = 2ll * (long long)t - 2 + lane;
-        if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
-    }
+    const uint32_t *src;
     const uint32_t meta = bcast(hv.w, 2);
     const uint32_t len = meta & 0x7FFFFFFFu, buf = meta >> 31;
     auto keep_header = [&]() {  // dense: the slot stays as it is (lanes 2 and 3 hold its header)
@@ -337,7 +340,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
             } else {
                 // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
                 // site, CH_RMV counters per pair)
-                atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (t & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], 1u);
+                if (A.removed) atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (t & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], 1u);
                 dl = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u)), vc);
                 dr = dl + vc;
             }
@@ -437,10 +440,15 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
     A1.newid = z0;
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
-        if (K == 1) merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
-        else merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, s_ph, hm);
+        if (K == 1) {
+            merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
+        } else {
+            uint4 rv[MJ], hv;
+            chain_slot_load(A, t, rv, hv);
+            merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+        }
     };
-    if (!use_index || st->gap != 0) {  // short slots about: visit everything
+    if (!(use_index & 1u) || st->gap != 0) {  // short slots about: visit everything
         const uint32_t nw = gridDim.x * NWV;
         for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw) do_slot(t);
         return;
@@ -475,7 +483,25 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
             }
         }
         __syncthreads();
-        for (uint32_t i = wave_id(); i < n; i += NWV) do_slot(s_list[i]);
+        if (K == 1 || MJ > 1 || !(use_index & 2u)) {
+            for (uint32_t i = wave_id(); i < n; i += NWV) do_slot(s_list[i]);
+        } else {
+            // 256-id slots: a slot is 16 bytes per lane and six header pieces -- the wave's NEXT candidate travels while it
+            // works on this one (a wave goes through dozens of candidates in a mid-training sweep, one round trip each)
+            uint32_t i = wave_id();
+            uint4 rv[MJ], hv, nrv[MJ], nhv;
+            if (i < n) chain_slot_load(A, s_list[i], rv, hv);
+            for (; i < n; i += NWV) {
+                const bool more = i + NWV < n;
+                if (more) chain_slot_load(A, s_list[i + NWV], nrv, nhv);
+                merge_chain_wave<false>(s_out[wave_id()], nullptr, s_list[i], A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < MJ; j++) rv[j] = nrv[j];
+                    hv = nhv;
+                }
+            }
+        }
         __syncthreads();  // (the list is rewritten by the next round)
     }
 }
@@ -522,7 +548,11 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
     constexpr uint32_t NWV = LEAN_MT / 64;
     const uint32_t nw = gridDim.x * NWV;
     for (uint32_t t = blockIdx.x * NWV + wave_id(); t < A.T; t += nw)
-        merge_chain_wave<true>(s_out[wave_id()], s_sd, t, A, s_pa, s_pb, s_pb1, K, z0, (uint32_t)CH_RSTRIDE);
+    {
+        uint4 rv[MJ], hv;
+        chain_slot_load(A, t, rv, hv);
+        merge_chain_wave<true>(s_out[wave_id()], s_sd, t, A, s_pa, s_pb, s_pb1, K, z0, (uint32_t)CH_RSTRIDE, rv, hv);
+    }
     __syncthreads();
     // flush: the tables of pair p into one of its CH_RSTRIDE replica blocks
     const uint32_t vc = A.vcap & 0xFFFFFFu;
@@ -539,7 +569,7 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
         if (threadIdx.x == 0) {
             const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
             if (adj) atomicAdd(&st->badj[p], adj);
-            if (rem) atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (blockIdx.x & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], rem);
+            if (rem && A.removed) atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (blockIdx.x & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], rem);
         }
     }
 }
@@ -722,12 +752,16 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     if (blockIdx.x == na && threadIdx.x < 64) {
         // ids removed by the merge pass: CH_RMV counters per pair of the batch, one per 256-byte line (lane l: counters
         // 4l .. 4l + 3, all of pair l / 4)
+        // (removed == nullptr: an unweighted stream -- a merge of a != b removes exactly as many ids as the pair counts, base.py:25-41:
+        // nobody counted, the batch's counts are the answer)
         uint32_t v = 0;
+        if (removed) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
-            if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
-            v += x;
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+                if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
+                v += x;
+            }
         }
         static_assert(CH_RMV == 16, "lanes 4p .. 4p + 3 hold the removals of pair p");
         v += (uint32_t)__shfl_xor((int)v, 1);
@@ -740,6 +774,10 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 #pragma unroll
             for (int p = 0; p < CH_KMAX; p++) tot += rem[p];
             rem[0] = tot;
+        }
+        if (!removed) {
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) rem[p] = st->bcnt[p];
         }
         if (threadIdx.x == 0) {
             const unsigned long long n = st->n[par];

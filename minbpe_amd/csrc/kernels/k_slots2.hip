@@ -312,7 +312,8 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
         if (LDSD) atomicAdd(&sd[2 * LDSD_CAP + 1], len - total);
-        else atomicAdd(&A.removed[(t & 255u) * REMOVED_STRIDE], len - total);
+        else if (A.removed) atomicAdd(&A.removed[(t & 255u) * REMOVED_STRIDE], len - total);  // (nullptr: a chain step of an unweighted
+                                                                                              // stream -- the ids removed ARE the pair's count)
         if (total < 3 && t + 1 < Tl) A.st->gap = 1;
     }
     // ---- (7) pair-table delta of my sites (format B); their new pairs enter the index -----------
@@ -420,7 +421,7 @@ __device__ __forceinline__ void ldsd_flush(const uint32_t *sd, const AbArgs &A) 
     if (threadIdx.x == 0) {
         const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
         if (adj) atomicAdd(&A.st->adj, adj);
-        if (rem) atomicAdd(&A.removed[(blockIdx.x & 255u) * REMOVED_STRIDE], rem);
+        if (rem && A.removed) atomicAdd(&A.removed[(blockIdx.x & 255u) * REMOVED_STRIDE], rem);
     }
 }
 

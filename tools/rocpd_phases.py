@@ -17,7 +17,7 @@ edges = [int(x) for x in sys.argv[2:]] or [0, 10, 100, 300, 1000, 2000, 4000, 80
 
 
 def short(name):
-    s = name.split("(")[0].replace("void ", "").replace("bpe::", "")
+    s = name.split("(")[0].replace("void ", "").replace("bpe::", "").replace("bpe_g1::", "").replace("bpe_g4::", "")
     return s
 
 
