@@ -30,7 +30,7 @@ struct bpe_ctx {
     uint32_t *d_dp_cfold = nullptr;
     uint64_t cap_dp_cfold = 0;
     bool dp_force_comm = false;  // option "dp_force_comm": issue the collectives in a world of one too (tests, launch-cost measurements)
-    int dp_kcap = DP_KCAP_MAX;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
+    int dp_kcap = DP_KCAP_DEFAULT;  // option "dp_kcap": most pairs of a sharded step's batch (the SUM payload, 2 dp_kcap S words, grows with it)
     uint64_t *d_round_lb = nullptr;  // k_load_count: first chunk of every segment of the byte stream
     uint64_t cap_round_lb = 0;
     bool fuse_load = true;  // option "fuse_load": the byte stream's first get_stats rides on the widening pass
@@ -127,7 +127,7 @@ struct bpe_ctx {
     int chain_prefetch = 1;                   // option "chain_prefetch": 256-id slots -- a wave's next candidate slot is loaded while it works on this one
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
-                                              // across steps) instead of k_chain_sel (one count level at a time); sharded training keeps k_chain_sel
+                                              // across steps) instead of k_chain_sel (one count level at a time); in a sharded job in two halves around the MIN all-reduce: k_pool_sel, k_pool_sel_dp
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
     PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
     uint32_t *d_pool_gather = nullptr;
@@ -932,9 +932,10 @@ int plan_pass2(bpe_ctx *c, bool *sparse_out) {
     const bool sparse = can_index && (c->use_sparse == 2 || rare);
     // (an a == b pass only marks the slots it rewrote as "visit always": once the host has seen
     // one go by, the index is rebuilt so that those marks do not pile up)
-    if (sparse && !c->idx_live && c->small_slots && c->ts != TILE2_MIN && (!small || c->small_slots == 2)) {
+    if (sparse && c->small_slots && c->ts != TILE2_MIN && (!small || c->small_slots == 2)) {
         // a large stream goes sparse: from here on a merge site costs the slot it sits in -- re-pack into 256-id slots
-        // (kernels of namespace bpe_g1 from the next launch on; the index is built over the new slots below)
+        // (kernels of namespace bpe_g1 from the next launch on; the index is built over the new slots -- below, or by
+        // slots2_enter itself when the sharded loop had one already, for its ties)
         TRY(slots2_leave(c));
         c->ts = TILE2_MIN;
         TRY(slots2_enter(c));
@@ -1141,9 +1142,9 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         HIPCHK(c, hipMemsetAsync(c->d_chain_req, 0, PL_REQ_WORDS * sizeof(unsigned long long), c->stream));
     }
     if (!c->d_pool) {
-        HIPCHK(c, hipMalloc((void **)&c->d_pool, PL_CAP * sizeof(PoolEnt)));
+        HIPCHK(c, hipMalloc((void **)&c->d_pool, (3 * PL_CAP + 128) * sizeof(PoolEnt)));  // (+ a sharded selection's hand-over: k_pool_sel -> k_pool_sel_dp)
         HIPCHK(c, hipMalloc((void **)&c->d_pool_gather, (2 + 2 * PL_GATHER) * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(c->d_pool, 0, PL_CAP * sizeof(PoolEnt), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_pool, 0, (3 * PL_CAP + 128) * sizeof(PoolEnt), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_pool_gather, 0, (2 + 2 * PL_GATHER) * sizeof(uint32_t), c->stream));
     }
     // sharded training (dp_train_loop, api_rccl.hip): the step's two collectives sit between its launches -- a tie's
@@ -1153,10 +1154,12 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     const DpComm *dp = c->dp_comm;
     uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : std::min(CH_KSWEEP, c->chain_kcap));
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
-    if (c->pool && !dp)
+    const uint32_t hint_below = (uint32_t)(c->pool_hint > 0 ? c->pool_hint : (int)kcap);
+    if (c->pool)
         hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
-                           kcap, c->d_pool, c->d_pool_gather, (uint32_t)(c->pool_hint > 0 ? c->pool_hint : (int)kcap));
+                           kcap, c->d_pool, c->d_pool_gather, hint_below, dp ? c->d_dp_ckey : (long long *)nullptr,
+                           (unsigned long long)(dp ? dp->rank : 0), c->d_pool + PL_CAP);
     else
     hipLaunchKernelGGL(GK(c, k_chain_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
@@ -1165,7 +1168,11 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     LAUNCHCHK(c, "k_chain_sel");
     if (dp) {
         TRY(dp_allreduce(c, c->d_dp_ckey, DP_KEY_WORDS, BPE_DT_INT64, BPE_OP_MIN));
-        hipLaunchKernelGGL(GK(c, k_chain_sel_dp), dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
+        if (c->pool)
+            hipLaunchKernelGGL(GK(c, k_pool_sel_dp), dim3(1), dim3(PL_CAP), 0, c->stream, c->d_st, c->d_dp_ckey, kcap, c->d_pool,
+                               c->d_pool + PL_CAP, hint_below);
+        else
+            hipLaunchKernelGGL(GK(c, k_chain_sel_dp), dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
         LAUNCHCHK(c, "k_chain_sel_dp");
     }
     TRY(prof_end(c));

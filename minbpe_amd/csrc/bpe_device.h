@@ -79,7 +79,8 @@ constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per p
 constexpr uint32_t CH_REP_COUNT = 4096;        // more sites than this (hot tokens queue ~11 ns per same-address atomic) ...
 constexpr int CH_REP = 4;                      // ... this many otherwise (the table update folds every replica it is told to)
 constexpr int CH_RMV = 16;                     // removal counters per pair of a batch (of the 256)
-constexpr int DP_KCAP_MAX = 8;                 // sharded chain steps: most pairs of a batch (the SUM payload's tail keeps word 8 for the status)
+constexpr int DP_KCAP_MAX = CH_KSWEEP;         // sharded chain steps: most pairs of a batch (option dp_kcap; the SUM payload grows with it: 2 K S words)
+constexpr int DP_KCAP_DEFAULT = 8;
 static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must fit the replica blocks");
 static_assert(CH_KMAX * CH_RMV <= 256, "removal counters of a batch");
 static_assert(CH_KSWEEP < 16 && CH_KSWEEP <= CH_KMAX, "pair number + 1 must fit a nibble");

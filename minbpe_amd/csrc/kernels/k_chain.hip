@@ -603,9 +603,9 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
               const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail) {
     // folded != nullptr (sharded training): the batch's delta is the all-reduced payload of k_dp_fold_chain -- pair p's
     // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
-    // (sharded: ftail[8] = the number of ranks whose status was raised when they folded this step's delta -- a
+    // (sharded: ftail[16] = the number of ranks whose status was raised when they folded this step's delta -- a
     // failure inside any rank's merge pass stops every rank at this same merge)
-    const uint32_t remote = (folded && ftail[8] != 0) ? 1u : 0u;
+    const uint32_t remote = (folded && ftail[16] != 0) ? 1u : 0u;
     const uint32_t status = st->status ? st->status : (remote ? ST_INTERNAL : 0u), defer = st->defer;
     const uint32_t K = st->bk, z0 = st->bz0;
     const bool noop = status || defer || K == 0;
@@ -1494,7 +1494,7 @@ k_chain_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap) {
 }
 // k_dp_fold_chain: this rank's delta of the step's batch, folded over its replica blocks into the SUM payload:
 // pair p's SL at folded[2p S ..), its SR at folded[(2p + 1) S ..), S = the payload's vector stride (>= every id in
-// use + 1); tail = folded + 2 kcap S: [p] = format B's adj of pair p, [8] = 1 if this rank's status is raised (the
+// use + 1); tail = folded + 2 kcap S: [p] = format B's adj of pair p (p < 16), [16] = 1 if this rank's status is raised (the
 // sum tells every rank before the table update: all ranks stop at the same merge).
 __global__ void __launch_bounds__(256)
 k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__restrict__ st, uint32_t *__restrict__ folded,
@@ -1502,20 +1502,20 @@ k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__res
     const uint32_t status = st->status, K = st->bk, z0 = st->bz0;
     const bool noop = status || st->defer || K == 0;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t < 16) tail[t] = t == 8 ? (status ? 1u : 0u) : ((!noop && t < K) ? (K == 1 ? st->adj : st->badj[t]) : 0u);
+    if (t < 32) tail[t] = t == 16 ? (status ? 1u : 0u) : ((!noop && t < K && t < 16) ? (K == 1 ? st->adj : st->badj[t]) : 0u);
 #ifdef BPE_DP_DEBUG
-    if (t >= 16 && t < 64) {  // (debug builds: the step's selection state rides in the payload's padding)
+    if (t >= 32 && t < 64) {  // (debug builds: the step's selection state rides in the payload's padding)
         uint32_t v = 0;
-        if (t == 16) v = st->iter;
-        else if (t == 17) v = st->sel_mode;
-        else if (t == 18) v = K;
-        else if (t == 19) v = st->tl_n;
-        else if (t == 20) v = st->tl_M;
-        else if (t == 21) v = st->tl_skip;
-        else if (t == 22) v = st->defer;
-        else if (t == 23) v = st->gap;
-        else if (t < 32) v = (uint32_t)st->ba[t - 24] << 16 | (uint32_t)st->bb[t - 24];
-        else v = (uint32_t)st->chain[2 * (t - 32)] << 16 | (uint32_t)st->chain[2 * (t - 32) + 1];
+        if (t == 32) v = st->iter;
+        else if (t == 33) v = st->sel_mode;
+        else if (t == 34) v = K;
+        else if (t == 35) v = st->tl_n;
+        else if (t == 36) v = st->tl_M;
+        else if (t == 37) v = st->tl_skip;
+        else if (t == 38) v = st->defer;
+        else if (t == 39) v = st->gap;
+        else if (t < 48) v = (uint32_t)st->ba[t - 40] << 16 | (uint32_t)st->bb[t - 24];
+        else v = (uint32_t)st->chain[2 * (t - 48)] << 16 | (uint32_t)st->chain[2 * (t - 48) + 1];
         tail[t] = v;
     }
 #endif

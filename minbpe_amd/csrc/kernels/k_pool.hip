@@ -48,17 +48,17 @@ static_assert(PL_GATHER >= 4 * PL_CAP, "maintain: four variants per entry");
 // [2 + PL_ROWS + w] = workgroup w has gathered its rows
 constexpr uint32_t PL_REQ_WORDS = 2 + PL_ROWS + 256;
 
-// entries ranked by count (descending; equal counts keep their order): out[rank] = in[i].  n <= PL_GATHER, every thread
+// entries ranked by count (descending; equal counts by pair): out[rank] = in[i].  n <= PL_GATHER, every thread
 // calls.  The order INSIDE a level is made later, from the keys, by a loop over the level alone.
 __device__ __forceinline__ void pool_sort(const uint32_t *ixy, const uint32_t *ic, const unsigned long long *ikey,
                                           uint32_t *oxy, uint32_t *oc, unsigned long long *okey, uint32_t n) {
     const uint32_t i = threadIdx.x;
     if (i < n) {
-        const uint32_t c = ic[i];
+        const uint32_t c = ic[i], x = ixy[i];
         uint32_t r = 0;
         for (uint32_t j = 0; j < n; j++) {
             const uint32_t cj = ic[j];
-            r += (cj > c) | ((cj == c) & (j < i));
+            r += (cj > c) | ((cj == c) & (ixy[j] < x));  // (equal counts by pair: the same order on every rank of a sharded job)
         }
         oxy[r] = ixy[i];
         oc[r] = c;
@@ -67,19 +67,133 @@ __device__ __forceinline__ void pool_sort(const uint32_t *ixy, const uint32_t *i
     __syncthreads();
 }
 // a level (entries [lo, hi) of a pool sorted by count) needs an order it does not have: several entries, not all of one epoch
-__device__ __forceinline__ uint32_t pool_level_dirty(const unsigned long long *key, uint32_t lo, uint32_t hi) {
+// (ksh: where the epoch sits in a key -- 40 on one GPU, PL_KSH_DP in a sharded job, whose positions carry the rank)
+constexpr int PL_KSH = 40, PL_KSH_DP = 43, PL_POS_DP = 33;  // sharded: epoch << 43 | rank << 33 | local position (< 2^33)
+__device__ __forceinline__ uint32_t pool_level_dirty(const unsigned long long *key, uint32_t lo, uint32_t hi, int ksh) {
     if (hi - lo <= 1) return 0u;
-    const unsigned long long e0 = key[lo] >> 40;
+    const unsigned long long e0 = key[lo] >> ksh;
     uint32_t d = e0 == 0;
-    for (uint32_t j = lo + 1; j < hi; j++) d |= (key[j] >> 40) != e0;
+    for (uint32_t j = lo + 1; j < hi; j++) d |= (key[j] >> ksh) != e0;
     return d;
+}
+// the bounds of every entry's level in a pool sorted by count (n <= PL_CAP; every thread calls)
+__device__ __forceinline__ void pool_level_bounds(const uint32_t *c, uint32_t n, uint32_t *ls, uint32_t *le) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < n) {
+        const uint32_t ci = c[tid];
+        uint32_t lo = tid, hi = tid + 1;
+        while (lo > 0 && c[lo - 1] == ci) lo--;
+        while (hi < n && c[hi] == ci) hi++;
+        ls[tid] = lo;
+        le[tid] = hi;
+    }
+}
+// The end of a selection, once the keys are what they are going to be (b_*: the pool sorted by count, s_ls / s_le its
+// level bounds): the order inside every level, the batch -- the longest prefix with a != b, no shared token, every level
+// it enters in a known order --, the step's state, and the rest of the entries as the next step's pool.  Every thread of
+// the deciding workgroup calls (blockDim.x >= PL_CAP).
+__device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ pool, const uint32_t *b_xy, const uint32_t *b_c,
+                                            const unsigned long long *b_key, uint32_t *a_xy, uint32_t *a_c,
+                                            unsigned long long *a_key, const uint32_t *s_ls, const uint32_t *s_le,
+                                            uint32_t *s_dirty, uint32_t *s_clash, uint32_t *s_k, uint32_t *s_unt, uint32_t n,
+                                            uint32_t kmax, uint32_t iter, uint32_t theta, unsigned long long epoch, bool rebuilt,
+                                            uint32_t hint_below, int ksh) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nwalk = min(n, kmax);
+    // ---- the order inside every level: by key (a level whose keys are not of one epoch stays without an order) ----------
+    if (tid < n) {
+        const uint32_t lo = s_ls[tid], hi = s_le[tid];
+        const unsigned long long k = b_key[tid];
+        uint32_t r = lo;
+        for (uint32_t j = lo; j < hi; j++) {
+            const unsigned long long kj = b_key[j];
+            r += (kj < k) | ((kj == k) & (j < tid));
+        }
+        a_xy[r] = b_xy[tid];
+        a_c[r] = b_c[tid];
+        a_key[r] = k;
+        s_dirty[r] = pool_level_dirty(b_key, lo, hi, ksh);
+    }
+    if (tid == 0) *s_unt = 0;
+    __syncthreads();
+    if (tid < nwalk) {
+        const uint32_t x = a_xy[tid] >> 16, y = a_xy[tid] & 0xFFFFu;
+        uint32_t bad = (x == y) | s_dirty[tid];
+        for (uint32_t j = 0; j < tid; j++) {
+            const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
+            bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
+        }
+        s_clash[tid] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t k = 0;
+        while (k < nwalk && !s_clash[k]) k++;
+        *s_k = k;
+    }
+    __syncthreads();
+    const uint32_t K = *s_k;
+    if (tid == 0) {
+        st->adj = 0;
+        st->count = a_c[0];
+        st->ntied = s_le[0];
+        st->firstpos = NOPOS;
+        st->sel_tie = 0;
+        st->a = (int32_t)(a_xy[0] >> 16);
+        st->b = (int32_t)(a_xy[0] & 0xFFFFu);
+        st->fin_a = st->a;
+        st->fin_b = st->b;
+        st->bk = K;
+        st->bz0 = 256u + iter;
+        st->tl_n = st->tl_skip = 0;
+        st->dp_wait = 0;
+        st->sel_mode = rebuilt ? CH_FULL : CH_LIST;  // (statistics: what kind of step this was)
+        if (K == 0) {
+            st->found = 0;
+            // a == b at the head: the general path's merge | a level the step cannot order: the general path's selection
+            st->defer = ((a_xy[0] >> 16) == (a_xy[0] & 0xFFFFu) && !s_dirty[0]) ? 1u : 2u;
+            st->pool_n = 0;
+            st->pool_hint = 1;
+        } else {
+            st->found = 1;
+            uint32_t cmax = 0;
+            for (uint32_t i = 0; i < K; i++) {
+                st->ba[i] = (int32_t)(a_xy[i] >> 16);
+                st->bb[i] = (int32_t)(a_xy[i] & 0xFFFFu);
+                st->badj[i] = 0;
+                st->bcnt[i] = a_c[i];
+                cmax = max(cmax, a_c[i]);
+            }
+            st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
+        }
+    }
+    if (K == 0) return;
+    // ---- the rest is the next step's pool ----------------------------------------------------------------------------------
+    if (tid >= K && tid < n) {
+        PoolEnt e;
+        e.xy = a_xy[tid];
+        e.c = a_c[tid];
+        e.key = a_key[tid];
+        pool[tid - K] = e;
+        const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
+        bool touched = false;
+        for (uint32_t p = 0; p < K; p++) touched |= ((a_xy[p] & 0xFFFFu) == x) | ((a_xy[p] >> 16) == y);
+        if (!touched) atomicAdd(s_unt, 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        st->pool_n = n - K;
+        st->pool_theta = theta;
+        st->pool_epoch = epoch;
+        st->pool_hint = *s_unt < hint_below ? 1u : 0u;
+    }
 }
 
 __global__ void __launch_bounds__(1024)
 k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
            CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
            unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
-           uint32_t hint_below) {
+           uint32_t hint_below, long long *__restrict__ dpkey, unsigned long long dprank, PoolEnt *__restrict__ mid) {
     __shared__ unsigned long long s_red[32];
     __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
     __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
@@ -94,6 +208,13 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
     const uint32_t iter = st->iter, nm = st->num_merges, hint = st->pool_hint;
     const uint32_t tid = threadIdx.x;
+    // Sharded training (dpkey != nullptr): the pool is a replica of GLOBAL state, so every rank maintains, gathers and
+    // sorts alike -- but a first occurrence is a rank-local fact.  This launch leaves the MIN all-reduce payload ([0] =
+    // -status, [1] = -1 if this rank cannot order its share (short slots about), [2 + l] = rank << 33 | first local
+    // position of the l-th entry to locate, INT64_MAX = no occurrence here) and the sorted pool in `mid`;
+    // k_pool_sel_dp finishes the selection from the reduced words.  Every word is first written with its neutral value.
+    if (dpkey && blockIdx.x == 0 && tid < (uint32_t)DP_KEY_WORDS)
+        dpkey[tid] = tid == 0 ? -(long long)status : (tid == 1 ? 0ll : 0x7FFFFFFFFFFFFFFFll);
     if (status || defer) return;
     if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
         if (blockIdx.x == 0 && tid == 0) st->bk = 0;
@@ -417,14 +538,11 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     // ---- the levels the walk can reach; the ones that need an order are located through the index ----------------------
     const uint32_t kmax = min(kcap, nm - iter);
     const uint32_t nwalk = min(n, kmax);  // the batch is a prefix of at most this many entries
+    const int ksh = dpkey ? PL_KSH_DP : PL_KSH;
+    pool_level_bounds(b_c, n, s_ls, s_le);
     if (tid < n) {
-        const uint32_t ci = b_c[tid];
-        uint32_t lo = tid, hi = tid + 1;
-        while (lo > 0 && b_c[lo - 1] == ci) lo--;
-        while (hi < n && b_c[hi] == ci) hi++;
-        s_ls[tid] = lo;
-        s_le[tid] = hi;
-        s_dirty[tid] = pool_level_dirty(b_key, lo, hi);
+        const uint32_t lo = s_ls[tid], hi = s_le[tid];
+        s_dirty[tid] = pool_level_dirty(b_key, lo, hi, ksh);
         if (tid < nwalk) {  // does this entry end a batch that reaches its level (a == b, or a token shared with anything above its level's end)?
             const uint32_t x = b_xy[tid] >> 16, y = b_xy[tid] & 0xFFFFu;
             uint32_t cl = x == y;
@@ -445,7 +563,8 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
             }
         const uint32_t reach = s_le[lim];
         uint32_t nl = 0;
-        if (C.T != 0 && gap == 0) {
+        // (sharded: what is located must not depend on this rank's own slots -- a rank with short slots about objects)
+        if (C.T != 0 && (gap == 0 || dpkey)) {
             // every level the walk can reach that lacks an order -- and, while the round of sixteen waves has room, the
             // next ones below (the same latency now, a clean level when the walk gets there)
             const uint32_t scan_end = min(n, reach + 48u);
@@ -466,99 +585,88 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     }
     __syncthreads();
     const uint32_t nl = s_nl;
+    if (dpkey) {
+        // ---- sharded: my first occurrences into the payload, the sorted pool into `mid`; k_pool_sel_dp goes on ----------
+        const bool objection = nl != 0 && gap != 0;
+        if (nl && !objection) (void)tie_by_index(ref, C, s_tied, nl, s_pos);
+        __syncthreads();
+        if (tid == 1 && objection) dpkey[1] = -1ll;
+        if (tid < nl && !objection && s_pos[tid] != NOPOS)
+            dpkey[2 + tid] = (long long)((dprank << PL_POS_DP) | (s_pos[tid] & ((1ull << PL_POS_DP) - 1ull)));
+        if (tid < n) {
+            PoolEnt e;
+            e.xy = b_xy[tid];
+            e.c = b_c[tid];
+            e.key = b_key[tid];
+            mid[1 + tid] = e;
+        }
+        if (tid < nl) mid[1 + PL_CAP + tid].xy = s_lidx[tid];
+        if (tid == 0) {
+            PoolEnt h;  // header: n | nl << 16, theta, epoch | rebuilt << 63
+            h.xy = n | (nl << 16);
+            h.c = theta;
+            h.key = epoch | ((unsigned long long)(rebuilt ? 1u : 0u) << 63);
+            mid[0] = h;
+            st->dp_wait = 1;
+            st->bk = 0;
+            st->found = 0;
+        }
+        return;
+    }
     if (nl) {
         (void)tie_by_index(ref, C, s_tied, nl, s_pos);
         __syncthreads();
         epoch++;
-        if (tid < nl) b_key[s_lidx[tid]] = s_pos[tid] != NOPOS ? (epoch << 40) | s_pos[tid] : 0ull;
+        if (tid < nl) b_key[s_lidx[tid]] = s_pos[tid] != NOPOS ? (epoch << PL_KSH) | s_pos[tid] : 0ull;
         __syncthreads();
     }
-    // ---- the order inside every level: by key (a level whose keys are not of one epoch stays without an order) ----------
+    pool_finish(st, pool, b_xy, b_c, b_key, a_xy, a_c, a_key, s_ls, s_le, s_dirty, s_clash, &s_k, &s_unt, n, kmax, iter, theta,
+                epoch, rebuilt, hint_below, PL_KSH);
+}
+
+// k_pool_sel_dp: the second half of a sharded selection, after the MIN all-reduce of the first occurrences (one workgroup
+// of PL_CAP threads).  The reduced words order the located entries -- lowest (rank, local position) = earliest in the
+// global stream (F3 / F5) -- on every rank alike.
+__global__ void __launch_bounds__(PL_CAP)
+k_pool_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap, PoolEnt *__restrict__ pool,
+              const PoolEnt *__restrict__ mid, uint32_t hint_below) {
+    __shared__ uint32_t a_xy[PL_CAP], a_c[PL_CAP], b_xy[PL_CAP], b_c[PL_CAP];
+    __shared__ unsigned long long a_key[PL_CAP], b_key[PL_CAP];
+    __shared__ uint32_t s_ls[PL_CAP], s_le[PL_CAP], s_dirty[PL_CAP], s_clash[PL_CAP];
+    __shared__ uint32_t s_k, s_unt;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t status = st->status;
+    if (key[0] < 0 && status == 0) {  // some rank failed: every rank stops at this merge
+        if (tid == 0) st->status = ST_INTERNAL;
+        return;
+    }
+    if (status || st->defer || !st->dp_wait) return;
+    const PoolEnt h = mid[0];
+    const uint32_t n = h.xy & 0xFFFFu, nl = h.xy >> 16, theta = h.c;
+    unsigned long long epoch = h.key & 0x7FFFFFFFFFFFFFFFull;
+    const bool rebuilt = (h.key >> 63) != 0;
+    const uint32_t iter = st->iter, nm = st->num_merges;
     if (tid < n) {
-        const uint32_t lo = s_ls[tid], hi = s_le[tid];
-        const unsigned long long k = b_key[tid];
-        uint32_t r = lo;
-        for (uint32_t j = lo; j < hi; j++) {
-            const unsigned long long kj = b_key[j];
-            r += (kj < k) | ((kj == k) & (j < tid));
+        const PoolEnt e = mid[1 + tid];
+        b_xy[tid] = e.xy;
+        b_c[tid] = e.c;
+        b_key[tid] = e.key;
+    }
+    __syncthreads();
+    if (nl) {
+        epoch++;
+        const bool objection = key[1] < 0;  // (some rank has short slots about: nobody orders these levels)
+        if (tid < nl) {
+            const long long p = key[2 + tid];
+            b_key[mid[1 + PL_CAP + tid].xy] =
+                (!objection && p != 0x7FFFFFFFFFFFFFFFll) ? (epoch << PL_KSH_DP) | (unsigned long long)p : 0ull;
         }
-        a_xy[r] = b_xy[tid];
-        a_c[r] = b_c[tid];
-        a_key[r] = k;
-        s_dirty[r] = pool_level_dirty(b_key, lo, hi);
+        __syncthreads();
     }
+    pool_level_bounds(b_c, n, s_ls, s_le);
     __syncthreads();
-    // ---- the batch: the longest prefix with a != b, no shared token, every level it enters in a known order -------------
-    if (tid < nwalk) {
-        const uint32_t x = a_xy[tid] >> 16, y = a_xy[tid] & 0xFFFFu;
-        uint32_t bad = (x == y) | s_dirty[tid];
-        for (uint32_t j = 0; j < tid; j++) {
-            const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
-            bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
-        }
-        s_clash[tid] = bad;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t k = 0;
-        while (k < nwalk && !s_clash[k]) k++;
-        s_k = k;
-    }
-    __syncthreads();
-    const uint32_t K = s_k;
-    if (tid == 0) {
-        st->adj = 0;
-        st->count = a_c[0];
-        st->ntied = s_le[0];
-        st->firstpos = NOPOS;
-        st->sel_tie = 0;
-        st->a = (int32_t)(a_xy[0] >> 16);
-        st->b = (int32_t)(a_xy[0] & 0xFFFFu);
-        st->fin_a = st->a;
-        st->fin_b = st->b;
-        st->bk = K;
-        st->bz0 = 256u + iter;
-        st->tl_n = st->tl_skip = 0;
-        st->sel_mode = rebuilt ? CH_FULL : CH_LIST;  // (statistics: what kind of step this was)
-        if (K == 0) {
-            st->found = 0;
-            // a == b at the head: the general path's merge | a level the step cannot order: the general path's selection
-            st->defer = ((a_xy[0] >> 16) == (a_xy[0] & 0xFFFFu) && !s_dirty[0]) ? 1u : 2u;
-            st->pool_n = 0;
-            st->pool_hint = 1;
-        } else {
-            st->found = 1;
-            uint32_t cmax = 0;
-            for (uint32_t i = 0; i < K; i++) {
-                st->ba[i] = (int32_t)(a_xy[i] >> 16);
-                st->bb[i] = (int32_t)(a_xy[i] & 0xFFFFu);
-                st->badj[i] = 0;
-                st->bcnt[i] = a_c[i];
-                cmax = max(cmax, a_c[i]);
-            }
-            st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
-        }
-    }
-    if (K == 0) return;
-    // ---- the rest is the next step's pool ----------------------------------------------------------------------------------
-    if (tid >= K && tid < n) {
-        PoolEnt e;
-        e.xy = a_xy[tid];
-        e.c = a_c[tid];
-        e.key = a_key[tid];
-        pool[tid - K] = e;
-        const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
-        bool touched = false;
-        for (uint32_t p = 0; p < K; p++) touched |= ((a_xy[p] & 0xFFFFu) == x) | ((a_xy[p] >> 16) == y);
-        if (!touched) atomicAdd(&s_unt, 1u);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        st->pool_n = n - K;
-        st->pool_theta = theta;
-        st->pool_epoch = epoch;
-        st->pool_hint = s_unt < hint_below ? 1u : 0u;
-    }
+    pool_finish(st, pool, b_xy, b_c, b_key, a_xy, a_c, a_key, s_ls, s_le, s_dirty, s_clash, &s_k, &s_unt, n, min(kcap, nm - iter),
+                iter, theta, epoch, rebuilt, hint_below, PL_KSH_DP);
 }
 
 }  // namespace BPE_G

@@ -28,9 +28,9 @@ def ar(ptr, count, dtype, op, stream):
         tl = h[count - 64:].astype(np.uint32)
         pr = lambda v: (int(v) >> 16, int(v) & 0xFFFF)
         K = int(tl[18])
-        log.append(("SUM", dict(iter=int(tl[16]), mode=int(tl[17]), K=K, tl_n=int(tl[19]), M=int(tl[20]), skip=int(tl[21]),
-                                defer=int(tl[22]), gap=int(tl[23]), batch=[pr(v) for v in tl[24:24 + K]],
-                                chain=[pr(v) for v in tl[32:32 + min(int(tl[19]), 32)]])))
+        log.append(("SUM", dict(iter=int(tl[32]), mode=int(tl[33]), K=K, tl_n=int(tl[35]), M=int(tl[36]), skip=int(tl[37]),
+                                defer=int(tl[38]), gap=int(tl[39]), batch=[pr(v) for v in tl[40:40 + min(K, 8)]],
+                                chain=[pr(v) for v in tl[48:48 + min(int(tl[35]), 16)]])))
 try:
     res = eng.dp_train_cb(nm, 0, 1, ar)
 except ValueError:
