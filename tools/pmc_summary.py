@@ -31,6 +31,8 @@ def table(path):
     seen = {}
     for name, cn, v, d in cur.execute("select name, counter_name, counter_value, dispatch_id from pmc_events"):
         key = name.split("(")[0].replace("void ", "").replace("bpe::", "")
+        # (the kernels that know the slot geometry exist twice: bpe_g4 = 1024-id slots, bpe_g1 = 256-id slots, marked "@256")
+        key = key.replace("bpe_g4::", "") if "bpe_g1::" not in key else key.replace("bpe_g1::", "") + "@256"
         e = out.setdefault(key, {"calls": 0, RD: 0.0, WR: 0.0, AT: 0.0})
         if cn in e:
             e[cn] += float(v) * 32.0
