@@ -84,6 +84,41 @@ def test_round4_pmc_profile_matches_the_sources_and_its_own_check():
             assert json.load(f)["source_hash"] == bench.source_hash(), name
 
 
+def test_round5_pmc_profiles_match_the_sources_and_their_own_check():
+    """The committed round-5 profiles (bench.PROFILE_ROUND) are of the library sources in the tree -- so bench.py attaches
+    their traffic --, the headline's and basic1g's self-check holds (k_load_count reads n + 8 B per chunk / n bytes and
+    writes 4n per train), kernels of the 256-id slot geometry are told apart ("@256"), and a train moves less than
+    round 4's 2.04 TB."""
+    assert bench.PROFILE_ROUND == "r5"
+    with open(os.path.join(ROOT, "profiles", "r5_regex1g_pmc.json")) as f:
+        pmc = json.load(f)
+    if pmc["source_hash"] != bench.source_hash():  # (mid-development: bench.py then prints the algorithmic figure, labelled)
+        pytest.skip("device sources changed after the committed PMC pass: tools/gpu_final_r5.sh makes a new one")
+    assert pmc["trains"] == 3 and pmc["merges"] == 3 * 31744 and pmc["launches"] > 0
+    first = pmc["check_on_the_first_pass"]
+    n, chunks = first["n_input_bytes"] * first["calls"], 170_679_779 * first["calls"]
+    assert abs(first["read_bytes"] / (n + 8 * chunks) - 1.0) < 0.03
+    assert abs(first["write_bytes"] / (4 * n) - 1.0) < 0.01
+    assert "k_merge_chain@256" in pmc["merge_kernels"] and "k_merge_chain_dense" in pmc["merge_kernels"]
+    per_train = pmc["all_kernels_hbm_bytes_total"] / pmc["trains"]
+    assert 0.8e12 < per_train < 1.6e12
+    with open(os.path.join(ROOT, "profiles", "r5_basic1g_pmc.json")) as f:
+        b = json.load(f)
+    assert b["source_hash"] == bench.source_hash() and b["trains"] == 3
+    fb = b["check_on_the_first_pass"]
+    assert abs(fb["write_bytes"] / (4 * fb["n_input_bytes"] * fb["calls"]) - 1.0) < 0.01
+    with open(os.path.join(ROOT, "profiles", "r5_encode_pmc.json")) as f:
+        assert json.load(f)["source_hash"] == bench.source_hash()
+    # the committed bench line is of the same sources and carries what the contract asks
+    with open(os.path.join(ROOT, "profiles", "r5_final_bench.json")) as f:
+        line = json.loads(f.readline())
+    assert line["source_hash"] == bench.source_hash() and line["n_gpus"] == 1 and line["unit"] == "merges/s"
+    assert line["roofline"]["traffic_source"].startswith("profiles/r5_regex1g_pmc.json")
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
+    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["python_reference"]["kind"] == "restatement"
+    assert "31744 merges equal the oracle's committed digests: True" in line["config"]["workload"]
+
+
 def test_parity_report_walks_every_committed_golden_without_tripping():
     """The headline's parity check looks at every entry of big_golden.json that could be of its input -- the sharded
     jobs' entries (per-shard digests, no data_sha256) and the 3.9 GB one among them -- and claims nothing for an input
