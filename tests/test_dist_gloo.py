@@ -237,3 +237,118 @@ def test_train_tokenizer_over_ranks_equals_single_process(native, dedup):
         assert status == "ok"
         assert [m[0] for m in merges] == exp[0] and [m[1] for m in merges] == list(range(256, 306))
     assert outs[0][3] == outs[1][3]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The sharded CHAIN STEP (api_rccl.hip: dp_train_loop; k_pool_sel / k_pool_sel_dp, k_dp_fold_chain, k_apply_chain) on the
+# CPU model of tests/cpu_chain_shard.py, which speaks the device's payload layouts: the first exchange as 16-bit limbs,
+# the MIN payload of a selection (rank << 33 | first local position per pool entry to locate), the SUM payload of a batch
+# (format-B vectors per pair, adj words, the status word at tail[16]).
+
+def _worker_chain(rank, world, port, chunks, num_merges, out_q, kcap, capacity, depth, fail_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from minbpe_amd.dist import TorchComm, shard_chunks
+        from cpu_chain_shard import CpuChainShard, train_chain_sharded
+        lo, hi = shard_chunks(len(chunks), rank, world)
+        mine = chunks[lo:hi]
+        data = b"".join(mine)
+        offs = np.cumsum([0] + [len(c) for c in mine[:-1]]).astype(np.uint64) if mine else None
+        shard = CpuChainShard(data, offs, kcap=kcap, capacity=capacity, depth=depth)
+        if fail_rank == rank:  # a rank-local failure inside the third step's merge pass
+            orig, calls = shard.merge_batch, [0]
+
+            def failing(batch):
+                calls[0] += 1
+                if calls[0] == 3:
+                    shard._status = -7
+                orig(batch)
+            shard.merge_batch = failing
+        res = train_chain_sharded(shard, TorchComm(), num_merges)
+        out_q.put((rank, res["status"], res["pairs"], res["counts"], (res["steps"], res["generals"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_chain(chunks, num_merges, world, kcap=8, capacity=24, depth=4, fail_rank=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chain, args=(r, world, port, chunks, num_merges, q, kcap, capacity, depth, fail_rank))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(outs)
+
+
+@pytest.mark.parametrize("world,kcap", [(2, 8), (3, 15), (2, 2)])
+def test_sharded_chain_steps_match_single_process(native, world, kcap):
+    """GPT-like chunks: most merges come off the pool in batches; every rank reports the oracle's merges and counts."""
+    chunks = _chunks(native.synth_text(9000, 45))
+    exp = _oracle(chunks, 90)
+    outs = _run_chain(chunks, 90, world, kcap=kcap)
+    for rank, status, pairs, counts, (steps, generals) in outs:
+        assert status == 0 and pairs == exp[0] and counts == exp[1], f"rank {rank}"
+        assert steps < len(pairs) or kcap == 2  # (batches of several merges)
+    assert len({o[4] for o in outs}) == 1  # every rank ran the same units
+
+
+def test_sharded_chain_steps_ties_across_ranks_and_exhaustion(native):
+    """A three-letter corpus: nearly every level is a tie whose pairs first occur on different ranks (the MIN payload
+    orders them: lowest rank, then position), a == b pairs head the pool again and again (the general path's merges), and
+    the table runs empty before the last merge -- every rank stops at the same one."""
+    rng = np.random.default_rng(9)
+    words = [bytes(97 + rng.integers(0, 3, size=rng.integers(1, 6))) for _ in range(500)]
+    chunks = [b" " + w for w in words]
+    exp = _oracle(chunks, 400)
+    assert len(exp[0]) < 400
+    for world in (2, 3):
+        outs = _run_chain(chunks, 400, world, kcap=8, capacity=12, depth=3)
+        for rank, status, pairs, counts, (steps, generals) in outs:
+            assert pairs == exp[0] and counts == exp[1], f"world {world} rank {rank}"
+            assert generals > 0
+        assert len({(tuple(o[2]), o[4]) for o in outs}) == 1
+
+
+def test_sharded_chain_step_failure_reaches_every_rank_in_the_same_step(native):
+    """tail[16] of the SUM payload: a status raised inside one rank's merge pass is summed into every rank's payload
+    BEFORE the table update of that step -- all ranks stop with the same merges done."""
+    chunks = _chunks(native.synth_text(6000, 46))
+    outs = _run_chain(chunks, 60, 3, fail_rank=1)
+    done = {len(o[2]) for o in outs}
+    assert len(done) == 1 and 0 < done.pop() < 60
+    assert all(o[1] != 0 for o in outs)
+
+
+def test_chain_shard_model_solo_and_the_limb_guard(native):
+    """world of one, no network: the model equals the oracle; and the first exchange's limbs -- summed as 128 identical
+    shards would be -- are refused by table_ready when a global count reaches 2^32 (and joined exactly when it does not)."""
+    from minbpe_amd.dist import SoloComm
+    from cpu_chain_shard import CpuChainShard, train_chain_sharded
+    chunks = _chunks(native.synth_text(5000, 47))
+    data = b"".join(chunks)
+    offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+    exp = _oracle(chunks, 70)
+    res = train_chain_sharded(CpuChainShard(data, offs, kcap=15, capacity=48, depth=8), SoloComm(), 70)
+    assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["steps"] < 40
+    sh = CpuChainShard(b"a" * 4_000, None)
+    for world, fits in ((64, True), (128, False)):  # 64 x 40 M < 2^32 <= 128 x 40 M
+        sh.begin(4, 0, world)
+        assert sh.table.numel() == 2 * 65536
+        i = 97 * 256 + 97
+        assert int(sh.table[i]) == 3_999 and int(sh.table[65536 + i]) == 0
+        sh.table[i], sh.table[65536 + i] = 40_000_000 & 0xFFFF, 40_000_000 >> 16  # (a shard with 40 M pairs (a, a))
+        sh.table.mul_(world)  # the SUM over `world` such shards: every limb sum stays far below 2^31
+        assert int(sh.table.max()) < 2**31
+        if fits:
+            sh.table_ready()
+            assert int(sh.tab[97, 97]) == 64 * 40_000_000
+        else:
+            with pytest.raises(OverflowError):
+                sh.table_ready()
