@@ -1537,14 +1537,23 @@ k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__res
     }
     const uint32_t brep = st->brep;
     for (uint32_t p = 0; p < K; p++) {
+        // (every replica's two words in flight before the first is looked at: the loop with the clearing stores inside
+        // was a chain of round trips, 16 us per step at K = 8)
+        uint32_t x[CH_RSTRIDE][2];
+#pragma unroll
+        for (int r = 0; r < CH_RSTRIDE; r++) {
+            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+            x[r][0] = (uint32_t)r < brep ? delta[o + t] : 0u;
+            x[r][1] = (uint32_t)r < brep ? delta[o + vc + t] : 0u;
+        }
         uint32_t sl = 0, sr = 0;
-        for (uint32_t r = 0; r < brep; r++) {
-            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + r, vc);
-            const uint32_t x = delta[o + t], y = delta[o + vc + t];
-            if (x) delta[o + t] = 0;
-            if (y) delta[o + vc + t] = 0;
-            sl += x;
-            sr += y;
+#pragma unroll
+        for (int r = 0; r < CH_RSTRIDE; r++) {
+            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
+            if (x[r][0]) delta[o + t] = 0;
+            if (x[r][1]) delta[o + vc + t] = 0;
+            sl += x[r][0];
+            sr += x[r][1];
         }
         folded[(size_t)(2 * p) * S + t] = sl;
         folded[(size_t)(2 * p + 1) * S + t] = sr;

@@ -529,7 +529,15 @@ k_enc_place_chained(const uint32_t *__restrict__ tmp, const uint64_t *__restrict
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_tile;
     __shared__ unsigned long long s_excl;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    // chunks of more than ENC_PLACE_BIG tokens that sit in the staging area (long chunks; a BasicTokenizer text is ONE
+    // chunk of millions of tokens): copied by the whole workgroup after the per-thread loop, not by the one thread
+    constexpr uint32_t ENC_PLACE_BIG = 256, ENC_PLACE_NBIG = 32;
+    __shared__ uint32_t s_nbig, s_bl[ENC_PLACE_NBIG];
+    __shared__ unsigned long long s_bd[ENC_PLACE_NBIG], s_bs[ENC_PLACE_NBIG];
+    if (threadIdx.x == 0) {
+        s_tile = atomicAdd(ticket, 1u);
+        s_nbig = 0;
+    }
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint64_t base = (uint64_t)tile * ENC_PLACE_TILE + threadIdx.x;  // element j of this thread: base + 256 j
@@ -614,6 +622,15 @@ k_enc_place_chained(const uint32_t *__restrict__ tmp, const uint64_t *__restrict
         if (L == 0) continue;
         if (sl[j] == ENC_NOSLOT) {
             const uint64_t s0 = off[c];
+            if (L > ENC_PLACE_BIG) {
+                const uint32_t b = atomicAdd(&s_nbig, 1u);
+                if (b < ENC_PLACE_NBIG) {
+                    s_bl[b] = L;
+                    s_bd[b] = d0;
+                    s_bs[b] = s0;
+                    continue;
+                }
+            }
             for (uint32_t k = 0; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
             continue;
         }
@@ -626,6 +643,13 @@ k_enc_place_chained(const uint32_t *__restrict__ tmp, const uint64_t *__restrict
             const uint64_t s0 = off[tab[sl[j]].rep];
             for (uint32_t k = 4; k < L; k++) out[d0 + k] = (int32_t)tmp[s0 + k];
         }
+    }
+    __syncthreads();
+    const uint32_t nbig = min(s_nbig, ENC_PLACE_NBIG);
+    for (uint32_t b = 0; b < nbig; b++) {
+        const uint32_t L = s_bl[b];
+        const unsigned long long d0 = s_bd[b], s0 = s_bs[b];
+        for (uint32_t k = threadIdx.x; k < L; k += 256) out[d0 + k] = (int32_t)tmp[s0 + k];
     }
 }
 
