@@ -381,6 +381,62 @@ def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits)
     assert np.array_equal(out_off, exp_off)
 
 
+CHAIN_OPTIONS = [
+    (("pool", 0),),                                  # round 4's selection: the list of the pairs tied at the maximum
+    (("pool", 0), ("chain_levels", 1)),              # ... walking into tied levels
+    (("pool", 0), ("chain_levels", 1), ("chain_list", 0)),
+    (("chain_kcap", 1),), (("chain_kcap", 4),), (("chain_kcap", 8),),   # batches of one, four, eight (default 15)
+    (("count_is_removed", 0),),                      # the ids a merge removes are counted, not taken from the pair's count
+    (("chain_prefetch", 0),),                        # no register prefetch of the next candidate slot
+    (("small_slots", 0),), (("small_slots", 2),),    # 1024-id slots throughout / 256-id slots from the first index build
+    (("small_slots", 2), ("pool", 0)), (("small_slots", 2), ("chain_kcap", 2), ("pool_hint", 64)),
+    (("chain_scan", 1),), (("chain_scan", 127),),    # one / 127 scanning workgroups in a pool rebuild
+]
+
+
+@pytest.mark.parametrize("opts", CHAIN_OPTIONS)
+@pytest.mark.parametrize("kind", ["regex", "ties"])
+def test_chain_step_options_cross_check(engine, native, kind, opts):
+    """Every option of the chain steps -- the pool against the list it replaced, batch caps, the removal counters, the
+    slot prefetch, both slot geometries, the number of scanning workgroups -- gives the oracle's merges: on a GPT-4-split
+    text with every merge a chain step through the index (sparse = 2, lean = 2), and on a three-letter corpus where nearly
+    every level is a tie, a == b pairs head the pool again and again and the table runs empty."""
+    if kind == "regex":
+        data, offs = split_chunks(native.synth_text(1_500_000, 71).decode())
+        nm = 500
+    else:
+        rng = np.random.default_rng(12)
+        chunks = [b" " + bytes(97 + rng.integers(0, 3, size=rng.integers(1, 6))) for _ in range(4000)]
+        data = b"".join(chunks)
+        offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
+        nm = 400
+    exp = oracle.train(data, nm, offs, raise_on_empty=False)
+    defaults = {"pool": 1, "chain_levels": 0, "chain_list": 1, "chain_kcap": 15, "count_is_removed": 1, "chain_prefetch": 1,
+                "small_slots": 1, "pool_hint": 0, "chain_scan": 63}
+    set_variant(engine, 1, 0, 2, 2, 7)
+    try:
+        for k, v in opts:
+            engine.set_option(k, v)
+        engine.load_bytes(data, offs)
+        if len(exp[0]) < nm:
+            with pytest.raises(ValueError):
+                engine.train(nm)
+            res = engine.last_train
+        else:
+            res = engine.train(nm)
+        st = engine.train_stats()
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], opts
+        assert st["steps"] > 0
+        if ("small_slots", 2) in opts and st["index_builds"]:
+            assert st["slot_ids"] == 256
+        if ("small_slots", 0) in opts:
+            assert st["slot_ids"] == 1024
+    finally:
+        for k, _ in opts:
+            engine.set_option(k, defaults[k])
+        reset_variant(engine)
+
+
 def _long_chunk_text(native, seed):
     """chunks of 33 .. 6000 bytes among ordinary ones: URLs, identifiers, whitespace runs (a == a merges inside a chunk),
     a run of one letter, base64-like noise -- what code and logs put behind a GPT-style split"""
