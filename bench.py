@@ -43,7 +43,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
 HBM_COPY_GBPS = 6290.0  # measured float4 copy, same guide
-PROFILE_ROUND = "r5"      # prefix of the committed rocprofv3 summaries under profiles/ this line attaches
+PROFILE_ROUND = "r6"      # prefix of the committed rocprofv3 summaries under profiles/ this line attaches
+PY_SAMPLE_BYTES = 16_000_000  # cpu_baseline: the pure-Python loop is timed on this much of the input ...
+PY_SAMPLE_MERGES = 4          # ... for this many merges (~10 s of one host core)
 
 WORKLOADS = {
     "regex1g": dict(bytes=1_000_000_000, seed=2, vocab=32000, chunked=True,
@@ -256,10 +258,12 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode, 
         "launches": hp["launches"], "avg_launch_ms": round(avg_launch_s * 1e3, 5),
         "alg_bytes_per_launch": hp["alg_bytes"] // launches,
         "equivalent_work_GBps": round(alg_GBps, 1), "equivalent_work_frac": round(alg_GBps / HBM_PEAK_GBPS, 4),
-        "note": "achieved / frac = PHYSICAL: HBM bytes per launch (`traffic`: 32 x the size-weighted TCC/EA request counters "
-                "of a rocprofv3 --pmc pass of this same command -- calibrated on known byte counts, profiles/r4_pmc_calibration.json (round 4: the counters and the access patterns are the same) "
-                "-- committed profile, attached only when it was measured on these library sources) / the "
-                "hipEvent time of the pass / 8 TB/s.  equivalent_work_* = the SURVEY 8d ALGORITHMIC bytes, 4(2N_i + "
+        "note": "achieved / frac = PHYSICAL, per train on both sides: HBM bytes of the merge-pass kernels per train (32 x the "
+                "size-weighted TCC/EA request counters of a rocprofv3 --pmc pass of this same command -- calibrated on known "
+                "byte counts, profiles/r4_pmc_calibration.json -- committed profile, attached only when it was measured on "
+                "these library sources) / the hipEvent time of the merge passes per train / 8 TB/s; `traffic` = the same "
+                "bytes per launch this run counted.  The pass is NOT bound by HBM bytes once it is sparse: see "
+                "`limited_by`, `dominant_kernel` and the line's `roofline_atomics`.  equivalent_work_* = the SURVEY 8d ALGORITHMIC bytes, 4(2N_i + "
                 "N_{i+1}) per merge (what the reference's get_stats + merge touch), over the same time: the pass does "
                 "not re-read the stream for get_stats and skips slots a merge cannot touch, so that figure exceeds the "
                 "physical one (and 1) -- it measures work avoided, not the kernel.",
@@ -271,19 +275,34 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode, 
     dev_ms = sum(v["ms"] for v in breakdown.values())
     whole["device_ms_per_train"] = round(dev_ms, 3)
     whole["device_ms_per_iteration"] = round(dev_ms / num_merges, 5)
+    roofline_atomics = None
     pmc_file = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}_pmc.json")
     if os.path.exists(pmc_file):
         with open(pmc_file) as f:
             pmc = json.load(f)
-        if pmc.get("source_hash") == source_hash() and pmc.get("launches"):
+        if pmc.get("source_hash") == source_hash() and pmc.get("launches") and pmc.get("trains"):
             src = f"profiles/{PROFILE_ROUND}_{name}_pmc.json (source_hash {pmc['source_hash']})"
             if hot == "merge":
-                per = pmc["hbm_bytes_total"] / pmc["launches"]
-                roofline["traffic"] = int(per)
+                # PER TRAIN on both sides: the profile's bytes of the merge-pass kernels per train over the hipEvent time
+                # of the merge passes per train; the per-launch figures divide both by the launches THIS run counted
+                trains_timed = steps if prof[hot]["launches"] else 1
+                per_train = pmc["hbm_bytes_total"] / pmc["trains"]
+                pass_s_per_train = hp["ms"] * 1e-3 / trains_timed
+                launches_per_train = max(hp["launches"] / trains_timed, 1)
+                roofline["traffic"] = int(per_train / launches_per_train)
+                roofline["traffic_per_train"] = int(per_train)
+                roofline["pass_ms_per_train"] = round(pass_s_per_train * 1e3, 3)
                 roofline["traffic_source"] = src
-                roofline["achieved"] = round(per / avg_launch_s / 1e9, 1)
-                roofline["frac"] = round(per / avg_launch_s / 1e9 / HBM_PEAK_GBPS, 4)
-            if pmc.get("all_kernels_hbm_bytes_total") and pmc.get("trains"):
+                roofline["achieved"] = round(per_train / pass_s_per_train / 1e9, 1)
+                roofline["frac"] = round(per_train / pass_s_per_train / 1e9 / HBM_PEAK_GBPS, 4)
+                # the dominant KERNEL by itself (the class above is eight kernels): its own bytes and atomics per launch
+                # from the PMC pass, its own average duration from the kernel trace of the same command
+                dk = pmc.get("dominant_kernel")
+                if dk:
+                    roofline["dominant_kernel"] = dk
+                    roofline["limited_by"] = dk.get("limited_by")
+                roofline_atomics = pmc.get("roofline_atomics")
+            if pmc.get("all_kernels_hbm_bytes_total"):
                 # per TRAIN on both sides (the profile's per-launch figure is per unit of the loop -- a chain step does
                 # several merges -- and must not be set against a per-merge time)
                 per_train = pmc["all_kernels_hbm_bytes_total"] / pmc["trains"]
@@ -293,6 +312,7 @@ def run_train_workload(name, wl, eng, steps, warmup, barrier, reduce_max, mode, 
                 whole["traffic_source"] = src
         else:
             roofline["traffic_source"] = "committed PMC profile is from other library sources: not attached"
+    out["roofline_atomics"] = roofline_atomics
     out["whole_iteration"] = whole
     roofline["achieved_kind"] = "physical (PMC traffic / hipEvent time)"
     if roofline["achieved"] is None and secondary:
@@ -395,39 +415,47 @@ def cpu_baseline(wl, data, offs, res, cpu_bytes, cpu_iters, total_bytes=None):
     rate = cpu_iters / ct
     total = total_bytes or len(data)  # (a sharded job: the bytes of ALL ranks)
     scale = nb / total
-    out = {
+    c_port = {
         "value": round(rate * scale, 4), "unit": "merges/s", "cores": 1, "kind": "port",
         "sample": f"oracle/bpe_oracle.c (get_stats + max + merge, one thread): first {cpu_iters} merges of the "
                   f"first {nb} bytes of the same input in {ct:.1f} s = {rate:.2f} merges/s, scaled by "
                   f"{scale:.3f} (O(N) per merge) to the full {total} bytes",
-        "sample_merges_per_s": round(rate, 3), **host_info(),
+        "sample_merges_per_s": round(rate, 3),
     }
     if nb == len(data):
-        out["gpu_first_merges_equal"] = bool(cp == res["pairs"][:cpu_iters])
-    # minbpe's pure-Python path, timed HERE on this host's cores: oracle/pyref.py restates base.py:13-41 + basic.py:31-42
-    # statement for statement (the reference tree cannot travel to the GPU box; the restatement is pinned against the
-    # fixtures the reference generated, tests/test_oracle_golden.py) -- one thread, like the reference
+        c_port["gpu_first_merges_equal"] = bool(cp == res["pairs"][:cpu_iters])
+    # THE BASELINE (north_star: "minbpe's pure-Python CPU path timed on the GPU box's own host cores in the same run"):
+    # oracle/pyref.py restates base.py:13-41 + basic.py:31-42 statement for statement (the reference tree cannot travel
+    # to the GPU box; the restatement is pinned against the fixtures the reference generated,
+    # tests/test_oracle_golden.py) -- one thread, like the reference.  The C port above rides along as `c_port`.
+    out = {"value": None, "unit": "merges/s", "cores": 1, "kind": "port", "sample": None, **host_info(), "c_port": c_port}
     try:
         from oracle import pyref
-        py_n = min(4_000_000, nb)
+        py_n = min(PY_SAMPLE_BYTES, nb)
+        while py_n < nb and (sample[py_n] & 0xC0) == 0x80:
+            py_n -= 1
         py_sample = bytes(sample[:py_n])
-        K = 3
+        K = PY_SAMPLE_MERGES
         t0 = time.perf_counter()
         pp, _ = pyref.train(py_sample, K)
-        pt = (time.perf_counter() - t0) / K
-        out["python_reference"] = {
-            "kind": "restatement", "cores": 1, "nproc": os.cpu_count(),
-            "s_per_merge_on_sample": round(pt, 3), "sample_bytes": py_n, "sample_merges": K,
-            "merges_per_s_on_sample": round(1.0 / pt, 4),
-            "extrapolated_merges_per_s_full_size": round(1.0 / (pt * total / py_n), 6),
-            "note": "oracle/pyref.py = get_stats + max + merge of minbpe (base.py:13-41, basic.py:31-42) in pure Python, "
-                    "one thread, as one stream (BasicTokenizer-style), timed in this run on this host; linear "
-                    "extrapolation in N (the loop is O(N) per merge)"}
-        if so is None:
-            out["python_reference"]["equals_c_oracle_first_merges"] = bool(
-                [tuple(p) for p in pp] == [tuple(p) for p in oracle.train(py_sample, K)[0]])
-    except Exception as e:  # the bench line must still come out
-        out["python_reference"] = f"not timed: {type(e).__name__}: {e}"
+        pt_total = time.perf_counter() - t0
+        pt = pt_total / K
+        full = 1.0 / (pt * total / py_n)
+        out["value"] = round(full, 6)
+        out["sample"] = (f"oracle/pyref.py = minbpe's own loop (get_stats + max + merge, base.py:13-41, basic.py:31-42) in pure "
+                         f"Python, one thread, one stream: {K} merges of the first {py_n} bytes of the same input in "
+                         f"{pt_total:.1f} s = {pt:.3f} s per merge, scaled linearly in N (the loop is O(N) per merge) to the "
+                         f"full {total} bytes")
+        out["s_per_merge_on_sample"] = round(pt, 3)
+        out["sample_bytes"] = py_n
+        out["sample_merges"] = K
+        out["merges_per_s_on_sample"] = round(1.0 / pt, 4)
+        c_first = oracle.train(py_sample, K)[0] if so is None else None
+        if c_first is not None:
+            out["equals_c_oracle_first_merges"] = bool([tuple(x) for x in pp] == [tuple(x) for x in c_first])
+    except Exception as e:  # the bench line must still come out: the C port is then the figure, labelled
+        out.update({k: v for k, v in c_port.items() if k in ("value", "sample")})
+        out["python_leg_error"] = f"{type(e).__name__}: {e}"
     return out
 
 
@@ -682,6 +710,24 @@ def encode_traffic(tname):
     return int(pmc["hbm_bytes_per_step"][tname]), f"profiles/{PROFILE_ROUND}_encode_pmc.json (source_hash {pmc['source_hash']})"
 
 
+def parity_failures(obj, path=""):
+    """Every place in the line where a comparison with the oracle / the plain run came out False (None = not checked)."""
+    bad = []
+    keys = ("equal", "equal_oracle", "equals_single_gpu", "ranks_agree", "same_merges_and_counts_as_plain_run",
+            "same_merges_as_headline_run", "equals_the_stream_training_leaves", "equal_oracle_on_300kB", "equals_host_form",
+            "len_drop_equals_count_and_counts_monotone", "split_equals_regex_module", "parity_equal", "invariants_hold")
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k in keys and v is False:
+                bad.append(f"{path}{k}")
+            elif isinstance(v, (dict, list)):
+                bad += parity_failures(v, f"{path}{k}.")
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            bad += parity_failures(v, f"{path}{i}.")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -770,12 +816,22 @@ def main():
         if args.cpu_iters > 0:
             cpu = cpu_baseline(wl, data, offs, res, args.cpu_bytes, args.cpu_iters)
         par = r["parity"]
+        inv_ok = r["invariants"]["len_drop_equals_count_and_counts_monotone"]
+        nm_ = wl["vocab"] - 256
+        # (the driver keeps the first 120 characters of config.workload: the parity verdict comes first)
+        short = (f"parity {par['merges_checked']}/{nm_} merges = oracle: {par['equal']}" if par["golden"]
+                 else "parity: no committed oracle digest") + \
+            f"; {name}: {'Regex' if wl['chunked'] else 'Basic'}Tokenizer.train, {wl['bytes'] / 1e9:g} GB synth seed {wl['seed']}, vocab {wl['vocab']}"
+        headline_ok = (par["equal"] is not False) and inv_ok
         line.update({
-            "value": r["merges_per_s"], "ms_per_step": r["ms_per_step"],
-            "config": {"workload": r["workload"] + "; " + (
+            # a headline whose merges differ from the oracle's is not a measurement
+            "value": r["merges_per_s"] if headline_ok else None, "ms_per_step": r["ms_per_step"],
+            "config": {"workload": short[:119],
+                       "parity_equal": par["equal"], "merges_checked": par["merges_checked"], "invariants_hold": inv_ok,
+                       "workload_detail": r["workload"] + "; " + (
                            f"first {par['merges_checked']} merges equal the oracle's committed digests: {par['equal']}"
                            if par["golden"] else "no committed oracle digest for this input") +
-                       f"; full-length invariants hold: {r['invariants']['len_drop_equals_count_and_counts_monotone']}",
+                       f"; full-length invariants hold: {inv_ok}",
                        "mode": "recount" if args.mode == 0 else ("delta" if args.mode == 1 else "default"),
                        "parallelism": "single"},
             "roofline": r.pop("roofline"), "cpu_baseline": cpu,
@@ -955,6 +1011,9 @@ def main():
             # merge of the job is applied to every rank's 1 GB shard, so N ranks do N x num_merges shard-merges per train;
             # the job's own rate (what a user waits for) is job_merges_per_s
             "value": round(world * num_merges * args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            # (N > 1: `value` counts a merge once per shard it is applied to -- the unit says so, so that nobody reads an
+            # N-fold rise of the job's own rate into it; at N = 1 the two are one and the unit is plain merges/s)
+            "unit": "merges/s" if world == 1 else "shard-merges/s",
             "job_merges_per_s": round(num_merges * args.steps / dt, 2),
             "config": {"workload": f"{wl['desc']} sharded over {world} GPUs by contiguous chunk ranges, "
                                    f"{wl['bytes']} B synthetic UTF-8 per GPU (seed {wl['seed']}+rank), vocab "
@@ -977,11 +1036,17 @@ def main():
             except Exception as e:
                 line["cpu_baseline"] = f"failed: {type(e).__name__}: {e}"
 
+    bad = parity_failures(line)
+    if bad:
+        line["parity_failures"] = bad
     if rank == 0:
         print(json.dumps(line))
     eng.close()
     if sharded:
         dist.destroy_process_group()
+    if bad:  # a fast run whose results differ from the reference's is not done: say so to whoever looks at the exit code
+        print("bench.py: PARITY FAILED: " + "; ".join(bad), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

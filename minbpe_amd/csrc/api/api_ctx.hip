@@ -86,6 +86,7 @@ struct bpe_ctx {
     uint32_t *d_idx_dirty = nullptr;          // [slot / 32]: slots rewritten by a == b passes since the last build
     uint32_t *d_removed = nullptr;            // [256 * REMOVED_STRIDE] removal counters of a merge pass
     uint64_t idx_cap_words = 0;               // index groups allocated
+    uint64_t idx_cap_rows = 0;                // ... and buckets (rows): those of the geometry the index was allocated in
     bool idx_rebuild = false;                 // an a == b merge went by: rebuild before the next pass
     bool last_aa_indexed = false;             // the last general-path iteration enqueued had its a == b pass keep the index current
     bool idx_live = false;                    // the index describes the current slots
@@ -831,17 +832,21 @@ constexpr unsigned SPARSE_GRID = 1024;      // resident workgroups of a sparse p
 
 int index_build(bpe_ctx *c) {
     const uint64_t nwords = (c->slot_T + 31) / 32;
-    if (nwords + 4 > c->idx_cap_words) {
+    // (rows = buckets of the geometry the stream is in: 32 Ki for 1024-id slots, 8 Ki for 256-id slots -- which has four
+    // times the slots, hence four times the words per row: the same bytes either way)
+    if (nwords + 4 > c->idx_cap_words || idx_h(c) > c->idx_cap_rows) {
         if (c->d_idx) HIPCHK(c, hipFree(c->d_idx));
         if (c->d_idx_dirty) HIPCHK(c, hipFree(c->d_idx_dirty));
         c->d_idx = c->d_idx_dirty = nullptr;
         const uint64_t cap = (nwords + 4 + 63) / 64 * 64;  // row stride: 16-byte aligned rows, a padded tail
         if (c->d_idx_tmp) HIPCHK(c, hipFree(c->d_idx_tmp));
         c->d_idx_tmp = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * bpe::bpe_g4::IDX_H * sizeof(uint32_t)));
-        HIPCHK(c, hipMalloc((void **)&c->d_idx_tmp, cap * bpe::bpe_g4::IDX_H * sizeof(uint32_t)));
+        c->idx_cap_words = c->idx_cap_rows = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_idx, cap * idx_h(c) * sizeof(uint32_t)));
+        HIPCHK(c, hipMalloc((void **)&c->d_idx_tmp, cap * idx_h(c) * sizeof(uint32_t)));
         HIPCHK(c, hipMalloc((void **)&c->d_idx_dirty, cap * sizeof(uint32_t)));
         c->idx_cap_words = cap;
+        c->idx_cap_rows = idx_h(c);
     }
     if (nwords) {
         hipLaunchKernelGGL(GK(c, k_index_build), dim3((unsigned)nwords), dim3(1024), (size_t)idx_h(c) * 4, c->stream,
@@ -1155,15 +1160,18 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : std::min(CH_KSWEEP, c->chain_kcap));
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
     const uint32_t hint_below = (uint32_t)(c->pool_hint > 0 ? c->pool_hint : (int)kcap);
+    // (the deciding workgroup and the scanning ones wait for each other: all of them must be resident at once -- one
+    // 1024-thread workgroup per CU at most, like lean_grid)
+    const unsigned nscan = (unsigned)std::max(1, std::min(c->chain_scan, c->num_cus - 1));
     if (c->pool)
-        hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+        hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                            kcap, c->d_pool, c->d_pool_gather, hint_below, dp ? c->d_dp_ckey : (long long *)nullptr,
                            (unsigned long long)(dp ? dp->rank : 0), c->d_pool + PL_CAP);
     else
-    hipLaunchKernelGGL(GK(c, k_chain_sel), dim3(1 + (unsigned)c->chain_scan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
+    hipLaunchKernelGGL(GK(c, k_chain_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                        c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
-                       (uint32_t)((c->chain_extend && c->chain_scan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
+                       (uint32_t)((c->chain_extend && (int)nscan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
                        kcap, dp ? c->d_dp_ckey : (long long *)nullptr, (unsigned long long)(dp ? dp->rank : 0));
     LAUNCHCHK(c, "k_chain_sel");
     if (dp) {

@@ -178,8 +178,11 @@ struct DevState {
     uint32_t dp_wait;             // sharded chain steps: k_chain_sel left a tie for k_chain_sel_dp to order (after the MIN all-reduce)
     // the pool (k_pool.hip): every pair that counts pool_theta or more, pool_n entries in the ctx's pool buffer
     uint32_t pool_n, pool_theta;
-    uint32_t pool_hint;           // the next selection launch may have to rebuild the pool: its row-scanning workgroups stay
-    uint32_t pool_pad_;
+    uint32_t pool_hint;           // the next selection launch may have to rebuild the pool: its row-scanning workgroups stay.
+                                  // Every workgroup of a selection launch reads it at entry, so that launch never writes it:
+    uint32_t pool_hint_next;      // ... the deciding workgroup leaves the next value here, the step's table update (or
+                                  // k_set_iter / k_clear_defer_chain) makes it current -- a workgroup dispatched late must
+                                  // not see a hint that differs from the one its peers acted on
     unsigned long long pool_epoch;  // launches that located entries so far (order keys of one epoch are comparable)
     // k_select: block 0 publishes its decision to the other blocks through this word.  They poll it
     // (hundreds of them): it sits alone in its 128-byte line, so that the polls do not queue up in

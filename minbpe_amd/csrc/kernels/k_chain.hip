@@ -807,6 +807,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             if (status == 0) st->n[par ^ 1] = nn;  // (a step that merged nothing carries the length forward)
             if (remote && st->status == 0) st->status = ST_INTERNAL;
             st->removed = 0;
+            st->pool_hint = st->pool_hint_next;  // (k_pool.hip: what this step's selection announced for the next one)
             StepRec *sr = srec + (step % STEP_RING);
             sr->first_iter = iter;
             sr->k = k_done;
@@ -1514,7 +1515,7 @@ k_dp_fold_chain(uint32_t *__restrict__ delta, uint32_t dl, const DevState *__res
         else if (t == 37) v = st->tl_skip;
         else if (t == 38) v = st->defer;
         else if (t == 39) v = st->gap;
-        else if (t < 48) v = (uint32_t)st->ba[t - 40] << 16 | (uint32_t)st->bb[t - 24];
+        else if (t < 48) v = (uint32_t)st->ba[t - 40] << 16 | (uint32_t)st->bb[t - 40];
         else v = (uint32_t)st->chain[2 * (t - 48)] << 16 | (uint32_t)st->chain[2 * (t - 48) + 1];
         tail[t] = v;
     }
@@ -1576,7 +1577,7 @@ __global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
     st->chain_n = 0;
     st->dp_wait = 0;
     st->pool_n = 0;  // (k_pool.hip: the first selection gathers the pool)
-    st->pool_hint = 1;
+    st->pool_hint = st->pool_hint_next = 1;
     st->pool_epoch = 0;
 }
 // host: a deferred chain step is about to be re-run through the general path
@@ -1588,7 +1589,7 @@ __global__ void k_clear_defer_chain(DevState *st) {
     st->bk = 0;
     st->dp_wait = 0;
     st->pool_n = 0;  // (the general path's merge is not one the pool was maintained for)
-    st->pool_hint = 1;
+    st->pool_hint = st->pool_hint_next = 1;
 }
 
 }  // namespace BPE_G

@@ -39,9 +39,9 @@
 namespace bpe {
 namespace BPE_G {
 
-constexpr uint32_t PL_CAP = 128;      // entries the pool holds
-constexpr uint32_t PL_ROWS = 64;      // rows a rebuild hands to the scanning workgroups
-constexpr uint32_t PL_GATHER = 512;   // pairs a rebuild may gather (and 4 x PL_CAP: what maintain can make of a full pool)
+constexpr uint32_t PL_CAP = 256;      // entries the pool holds
+constexpr uint32_t PL_ROWS = 128;      // rows a rebuild hands to the scanning workgroups
+constexpr uint32_t PL_GATHER = 1024;   // pairs a rebuild may gather (and 4 x PL_CAP: what maintain can make of a full pool)
 static_assert(PL_GATHER >= 4 * PL_CAP, "maintain: four variants per entry");
 // request / answer words of a rebuild (all self-validating: tag << 32 | value, the launch tag never repeats):
 // [0] = rows to scan (0: the scanning workgroups are dismissed), [1 + j] = row j, [1 + PL_ROWS] = theta,
@@ -153,7 +153,7 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
             // a == b at the head: the general path's merge | a level the step cannot order: the general path's selection
             st->defer = ((a_xy[0] >> 16) == (a_xy[0] & 0xFFFFu) && !s_dirty[0]) ? 1u : 2u;
             st->pool_n = 0;
-            st->pool_hint = 1;
+            st->pool_hint_next = 1;
         } else {
             st->found = 1;
             uint32_t cmax = 0;
@@ -185,7 +185,7 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
         st->pool_n = n - K;
         st->pool_theta = theta;
         st->pool_epoch = epoch;
-        st->pool_hint = *s_unt < hint_below ? 1u : 0u;
+        st->pool_hint_next = *s_unt < hint_below ? 1u : 0u;
     }
 }
 
@@ -203,7 +203,7 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     __shared__ int32_t s_tied[2 * TIE_CAP];
     __shared__ unsigned long long s_pos[TIE_CAP];
     __shared__ uint32_t s_lidx[TIE_CAP];
-    __shared__ uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[2];
+    __shared__ uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[PL_CAP / 64];
     __shared__ uint32_t s_fail, s_n, s_theta, s_nrows, s_nl, s_reach, s_k, s_unt, s_x;
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
     const uint32_t iter = st->iter, nm = st->num_merges, hint = st->pool_hint;
@@ -329,10 +329,11 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     {
         const uint32_t no = (uint32_t)__popc(keepm);
         const uint32_t inc = wave_iscan_add(no);
-        if (tid < 128 && lane_id() == 63) s_wtot[wave_id()] = inc;
+        if (tid < PL_CAP && lane_id() == 63) s_wtot[wave_id()] = inc;
         __syncthreads();
-        if (tid < 128) {
-            uint32_t o = inc - no + (wave_id() == 1 ? s_wtot[0] : 0u);
+        if (tid < PL_CAP) {
+            uint32_t o = inc - no;
+            for (int w = 0; w < wave_id(); w++) o += s_wtot[w];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 if ((keepm >> v) & 1u) {
@@ -345,7 +346,8 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
         }
         __syncthreads();
     }
-    uint32_t n1 = n0 ? s_wtot[0] + s_wtot[1] : 0u;
+    uint32_t n1 = 0;
+    if (n0) for (uint32_t w = 0; w < PL_CAP / 64; w++) n1 += s_wtot[w];
     bool rebuilt = false;
     // (a hinted launch -- the scanning workgroups stayed -- whose pool could not fill a batch any more gathers a fresh,
     // deeper one instead of merging the last few entries in small batches: the old entries are in it, without their keys)
@@ -356,7 +358,7 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
                 st->bk = 0;
                 st->found = 0;
                 st->pool_n = 0;
-                st->pool_hint = 1;
+                st->pool_hint_next = 1;
                 st->sel_mode = CH_LIST;
                 st->tl_n = st->tl_skip = 0;
             }
@@ -528,7 +530,7 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
                 st->bk = 0;
                 st->defer = 2;
                 st->pool_n = 0;
-                st->pool_hint = 1;
+                st->pool_hint_next = 1;
             }
             return;
         }
@@ -563,8 +565,10 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
             }
         const uint32_t reach = s_le[lim];
         uint32_t nl = 0;
-        // (sharded: what is located must not depend on this rank's own slots -- a rank with short slots about objects)
-        if (C.T != 0 && (gap == 0 || dpkey)) {
+        // (sharded: what is located must not depend on this rank's own slots -- a rank with short slots about objects, a
+        // rank whose shard is empty or has no index (C.T == 0) finds no occurrence: tie_by_index then looks at nothing --
+        // but it names the same levels, so that the epoch and the keys k_pool_sel_dp makes are the same on every rank)
+        if (dpkey || (C.T != 0 && gap == 0)) {
             // every level the walk can reach that lacks an order -- and, while the round of sixteen waves has room, the
             // next ones below (the same latency now, a clean level when the walk gets there)
             const uint32_t scan_end = min(n, reach + 48u);

@@ -84,39 +84,58 @@ def test_round4_pmc_profile_matches_the_sources_and_its_own_check():
             assert json.load(f)["source_hash"] == bench.source_hash(), name
 
 
-def test_round5_pmc_profiles_match_the_sources_and_their_own_check():
-    """The committed round-5 profiles (bench.PROFILE_ROUND) are of the library sources in the tree -- so bench.py attaches
-    their traffic --, the headline's and basic1g's self-check holds (k_load_count reads n + 8 B per chunk / n bytes and
-    writes 4n per train), kernels of the 256-id slot geometry are told apart ("@256"), and a train moves less than
-    round 4's 2.04 TB."""
-    assert bench.PROFILE_ROUND == "r5"
-    with open(os.path.join(ROOT, "profiles", "r5_regex1g_pmc.json")) as f:
+def test_round6_pmc_profiles_match_the_sources_and_their_own_check():
+    """The committed round-6 profiles (bench.PROFILE_ROUND) are of the library sources in the tree -- so bench.py attaches
+    their traffic --, the headline's self-check holds (k_load_count reads n + 8 B per chunk and writes 4n per train),
+    kernels of the 256-id slot geometry are told apart ("@256"), the profile names its dominant kernel with that kernel's
+    OWN fraction of the HBM peak and its atomics rate against a timed ceiling, and the committed bench line carries
+    the parity verdict where the driver keeps it (the first 120 characters of config.workload)."""
+    assert bench.PROFILE_ROUND == "r6"
+    path = os.path.join(ROOT, "profiles", "r6_regex1g_pmc.json")
+    if not os.path.exists(path):
+        pytest.skip("no round-6 PMC pass committed yet: tools/gpu_final_r6.sh makes one")
+    with open(path) as f:
         pmc = json.load(f)
     if pmc["source_hash"] != bench.source_hash():  # (mid-development: bench.py then prints the algorithmic figure, labelled)
-        pytest.skip("device sources changed after the committed PMC pass: tools/gpu_final_r5.sh makes a new one")
+        pytest.skip("device sources changed after the committed PMC pass: tools/gpu_final_r6.sh makes a new one")
     assert pmc["trains"] == 3 and pmc["merges"] == 3 * 31744 and pmc["launches"] > 0
     first = pmc["check_on_the_first_pass"]
     n, chunks = first["n_input_bytes"] * first["calls"], 170_679_779 * first["calls"]
     assert abs(first["read_bytes"] / (n + 8 * chunks) - 1.0) < 0.03
     assert abs(first["write_bytes"] / (4 * n) - 1.0) < 0.01
-    assert "k_merge_chain@256" in pmc["merge_kernels"] and "k_merge_chain_dense" in pmc["merge_kernels"]
+    assert any(k.endswith("@256") for k in pmc["merge_kernels"])
     per_train = pmc["all_kernels_hbm_bytes_total"] / pmc["trains"]
-    assert 0.8e12 < per_train < 1.6e12
-    with open(os.path.join(ROOT, "profiles", "r5_basic1g_pmc.json")) as f:
-        b = json.load(f)
-    assert b["source_hash"] == bench.source_hash() and b["trains"] == 3
-    fb = b["check_on_the_first_pass"]
-    assert abs(fb["write_bytes"] / (4 * fb["n_input_bytes"] * fb["calls"]) - 1.0) < 0.01
-    with open(os.path.join(ROOT, "profiles", "r5_encode_pmc.json")) as f:
-        assert json.load(f)["source_hash"] == bench.source_hash()
-    # the committed bench line is of the same sources and carries what the contract asks
-    with open(os.path.join(ROOT, "profiles", "r5_final_bench.json")) as f:
+    assert 0.5e12 < per_train < 1.6e12
+    dk = pmc["dominant_kernel"]
+    assert dk["name"] in pmc["kernel_table"] and 0 < dk["frac_of_hbm_peak"] < 1 and dk["avg_us"] > 0
+    ra = pmc["roofline_atomics"]
+    assert ra["peak"] > 0 and ra["achieved"] > 0 and abs(ra["frac"] - ra["achieved"] / ra["peak"]) < 1e-3
+    bl = os.path.join(ROOT, "profiles", "r6_final_bench.json")
+    if not os.path.exists(bl):
+        pytest.skip("no round-6 bench line committed yet")
+    with open(bl) as f:
         line = json.loads(f.readline())
     assert line["source_hash"] == bench.source_hash() and line["n_gpus"] == 1 and line["unit"] == "merges/s"
-    assert line["roofline"]["traffic_source"].startswith("profiles/r5_regex1g_pmc.json")
+    assert line["roofline"]["traffic_source"].startswith("profiles/r6_regex1g_pmc.json")
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
-    assert line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["python_reference"]["kind"] == "restatement"
-    assert "31744 merges equal the oracle's committed digests: True" in line["config"]["workload"]
+    # per train on both sides: bytes per train / pass time per train
+    rf = line["roofline"]
+    assert abs(rf["achieved"] - rf["traffic_per_train"] / (rf["pass_ms_per_train"] * 1e-3) / 1e9) < 0.02 * rf["achieved"]
+    assert line["cpu_baseline"]["cores"] == 1 and "pyref.py" in line["cpu_baseline"]["sample"]
+    assert line["cpu_baseline"]["c_port"]["kind"] == "port"
+    assert len(line["config"]["workload"]) < 120
+    assert line["config"]["workload"].startswith("parity 31744/31744 merges = oracle: True")
+    assert line["config"]["parity_equal"] is True and line["value"] is not None
+    assert line["roofline_atomics"]["peak"] == ra["peak"]
+
+
+def test_parity_failures_finds_every_false_verdict_and_nothing_else():
+    line = {"parity": {"equal": True, "goldens": [{"equal": True}]}, "config": {"parity_equal": True},
+            "secondary": {"cfg2": {"parity": {"equal": None}}, "encode": {"parity": {"equal_oracle": True}}}}
+    assert bench.parity_failures(line) == []
+    line["secondary"]["encode"]["parity"]["equal_oracle"] = False
+    line["parity"]["goldens"][0]["equal"] = False
+    assert sorted(bench.parity_failures(line)) == ["parity.goldens.0.equal", "secondary.encode.parity.equal_oracle"]
 
 
 def test_parity_report_walks_every_committed_golden_without_tripping():
@@ -225,4 +244,8 @@ def test_main_prints_one_conforming_line_at_n1_on_a_test_double(monkeypatch, cap
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
     cpu = line["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] == 1
+    # the figure is minbpe's pure-Python loop (north_star), the C port rides along
+    assert "pyref.py" in cpu["sample"] and cpu["value"] > 0 and cpu["c_port"]["value"] > cpu["value"]
+    assert len(line["config"]["workload"]) < 120 and line["config"]["workload"].startswith("parity")
+    assert line["config"]["parity_equal"] is None and "parity_failures" not in line
     assert line["secondary"] == {}

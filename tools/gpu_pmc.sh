@@ -20,7 +20,8 @@ NB=1000000000; NM=31744; [ "$WL" = "cfg2" ] && NB=100000000 && NM=3840
 if [ "$WL" = "encode" ]; then
 python tools/pmc_encode_summary.py "$R" gpurun_out/${TAG:-r4}_encode_pmc.json; echo "summary rc=$?"
 else
-python tools/pmc_summary.py "$R" $WL gpurun_out/${TAG:-r4}_${WL}_pmc.json $NB $NM; echo "summary rc=$?"
+PEAK=gpurun_out/${TAG:-r4}_atomic_peak.json; [ -f "$PEAK" ] || PEAK=profiles/r6_atomic_peak.json
+python tools/pmc_summary.py "$R" $WL gpurun_out/${TAG:-r4}_${WL}_pmc.json $NB $NM gpurun_out/${TAG:-r4}_${WL}_kernel_stats.csv $PEAK; echo "summary rc=$?"
 fi
 rm -rf gpurun_out/prof_r
 head -8 gpurun_out/${TAG:-r4}_${WL}_kernel_stats.csv 2>/dev/null | cut -c1-150

@@ -9,7 +9,13 @@ bytes = 32 x count.  Calibrated on kernels with known byte counts in this engine
 costs 128, a 4-byte gather 128); writes exact; a device atomic counts as one 32-byte write.  The derived FETCH_SIZE
 tallies a 128-byte request at 64 (x2 for EVERY read pattern, not only wide streams), WRITE_SIZE = writes + atomics.
 
-usage: tools/pmc_summary.py raw.db workload_name out.json [n_bytes_of_the_input]
+usage: tools/pmc_summary.py raw.db workload_name out.json [n_bytes_of_the_input [merges_per_train [kernel_stats.csv [atomic_peak.json]]]]
+
+With the kernel-trace summary of the SAME command (tools/rocpd_stats.py, its own rocprofv3 run: durations under a PMC
+pass are not the kernel's) every kernel gets its own line -- bytes, atomics, average duration, fraction of the 8 TB/s
+HBM peak -- and the one with the most device time is named `dominant_kernel`; with the timed ceiling of
+tools/atomic_peak.hip (device-scope 4-byte atomics per second, addresses over every channel) its atomics rate is set
+against that ceiling: `roofline_atomics`.
 
 A "launch" of the merge pass is one unit of the training loop = the a != b kernel(s) of a general iteration, a lean
 iteration or a chain step plus, in the general path, the a == b kernel; bench.py times exactly that group.  Units =
@@ -43,10 +49,32 @@ def table(path):
     return out
 
 
+def short_name(name):
+    key = name.split("(")[0].replace("void ", "").replace("bpe::", "")
+    return key.replace("bpe_g4::", "") if "bpe_g1::" not in key else key.replace("bpe_g1::", "") + "@256"
+
+
+def durations(csv_path):
+    """kernel -> (calls, total_us) from tools/rocpd_stats.py's table"""
+    import csv
+    out = {}
+    with open(csv_path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            k = short_name(row["Name"])
+            c, t = out.get(k, (0, 0.0))
+            out[k] = (c + int(row["Calls"]), t + float(row["TotalDurationNs"]) / 1e3)
+    return out
+
+
+HBM_PEAK = 8.0e12
+
+
 def main():
     db, workload, outp = sys.argv[1:4]
     n_in = int(sys.argv[4]) if len(sys.argv) > 4 else None
     merges_per_train = int(sys.argv[5]) if len(sys.argv) > 5 else None
+    stats_csv = sys.argv[6] if len(sys.argv) > 6 and os.path.exists(sys.argv[6]) else None
+    peak_json = sys.argv[7] if len(sys.argv) > 7 and os.path.exists(sys.argv[7]) else None
     t = table(db)
     kernels = {k: {"calls": v["calls"], "read_bytes": v[RD], "write_bytes": v[WR], "atomic_bytes": v[AT],
                    "hbm_bytes": v[RD] + v[WR] + v[AT]} for k, v in sorted(t.items())}
@@ -71,6 +99,44 @@ def main():
         "other_kernels": {k: v for k, v in kernels.items() if not k.startswith("k_merge_")
                           and v["hbm_bytes"] > 0.002 * max(total, 1)},
     }
+    if stats_csv:
+        dur = durations(stats_csv)
+        tab = {}
+        for k, v in kernels.items():
+            if k not in dur or not v["calls"]:
+                continue
+            calls_kt, total_us = dur[k]
+            avg_us = total_us / max(calls_kt, 1)
+            per = v["hbm_bytes"] / v["calls"]
+            tab[k] = {"calls_pmc": v["calls"], "calls_trace": calls_kt, "total_us": round(total_us, 1), "avg_us": round(avg_us, 3),
+                      "hbm_bytes_per_launch": round(per), "atomics_per_launch": round(v["atomic_bytes"] / 32.0 / v["calls"]),
+                      "TBps": round(per / (avg_us * 1e-6) / 1e12, 4) if avg_us else None,
+                      "frac_of_hbm_peak": round(per / (avg_us * 1e-6) / HBM_PEAK, 4) if avg_us else None,
+                      "atomics_G_per_s": round(v["atomic_bytes"] / 32.0 / v["calls"] / (avg_us * 1e-6) / 1e9, 3) if avg_us else None}
+        out["kernel_table"] = dict(sorted(tab.items(), key=lambda kv: -kv[1]["total_us"]))
+        out["kernel_table_source"] = os.path.basename(stats_csv) + " (rocprofv3 --kernel-trace of the same command, its own run)"
+        if tab:
+            dk = max(tab, key=lambda k: tab[k]["total_us"])
+            all_us = sum(t for _, t in dur.values())
+            out["dominant_kernel"] = {"name": dk, "share_of_kernel_time": round(tab[dk]["total_us"] / all_us, 4), **tab[dk],
+                                      "limited_by": None}
+            if peak_json:
+                with open(peak_json) as fh:
+                    pk = json.load(fh)
+                peak = pk["add_agent_spread_1GiB"]["G_per_s"]
+                ach = tab[dk]["atomics_G_per_s"] or 0.0
+                out["roofline_atomics"] = {
+                    "kernel": dk, "achieved": ach, "peak": peak, "unit": "G atomics/s", "frac": round(ach / peak, 4) if peak else None,
+                    "atomics_per_launch": tab[dk]["atomics_per_launch"], "avg_us": tab[dk]["avg_us"],
+                    "peak_source": os.path.basename(peak_json) + " (tools/atomic_peak.hip, hipEvent-timed: non-returning device-scope "
+                                   "atomicAdd, 4-byte words spread over 1 GiB, 256 x 1024 threads)",
+                    "note": "atomics = TCC_EA0_WRREQ_WRITE_ATOMIC_32B of the kernel (a device-scope atomic is one 32-byte request at "
+                            "the memory side, profiles/r4_pmc_calibration.json) / its launches / its average duration in the "
+                            "kernel trace"}
+                hbm = tab[dk]["frac_of_hbm_peak"] or 0.0
+                out["dominant_kernel"]["limited_by"] = (
+                    "hbm bytes" if hbm >= max(0.4, ach / peak if peak else 0) else
+                    "memory-side atomics per merge site and dependent round trips per slot (latency), not HBM bytes")
     with open(outp, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: out[k] for k in ("workload", "source_hash", "launches", "trains", "merges", "hbm_bytes_per_launch")}))
