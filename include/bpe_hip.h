@@ -253,8 +253,9 @@ int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
  * that needed no selection of their own (their pair came off the list of tied pairs an earlier selection made:
  * the reference merges those in order of first occurrence while their counts stand), out[7] = chain steps,
  * out[8] = chain steps that selected (gathered the pool of pairs anew; the others took their pairs off it), out[9] = ids
- * per slot the stream ended in (1024; 256 once it was re-packed for sparse passes, option "small_slots").  Writes
- * min(n, 10) values. */
+ * per slot the stream ended in (1024; 256 once it was re-packed for sparse passes, option "small_slots"), out[10] =
+ * chain steps that were ONE launch (selection, merge pass and table update as phases of one resident grid: option
+ * "fuse_step").  Writes min(n, 11) values. */
 int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */

@@ -505,12 +505,13 @@ class Engine:
         """dict(dense, sparse, index_builds, slots, lean, deferred, chained, steps, selections) of the last train()
         (bpe_train_stats_ex): passes by kind, merges done by lean iterations / chain steps, merges handed back to the
         general path, merges that needed no selection of their own, chain steps, chain steps that selected; slot_ids = ids per
-        slot the stream ended in (1024, or 256 once it was re-packed for sparse passes)."""
-        out = np.zeros(10, np.uint64)
-        self._check(_lib.bpe_train_stats_ex(self._h, _ptr(out), 10))
+        slot the stream ended in (1024, or 256 once it was re-packed for sparse passes); fused_steps = chain steps that were
+        one launch (k_step.hip)."""
+        out = np.zeros(11, np.uint64)
+        self._check(_lib.bpe_train_stats_ex(self._h, _ptr(out), 11))
         return dict(dense=int(out[0]), sparse=int(out[1]), index_builds=int(out[2]), slots=int(out[3]),
                     lean=int(out[4]), deferred=int(out[5]), chained=int(out[6]), steps=int(out[7]),
-                    selections=int(out[8]), slot_ids=int(out[9]))
+                    selections=int(out[8]), slot_ids=int(out[9]), fused_steps=int(out[10]))
 
     def prof_read(self):
         k = len(PROF_KINDS)

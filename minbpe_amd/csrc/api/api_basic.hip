@@ -177,6 +177,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_kcap = (int)value;
     } else if (!strcmp(name, "pool")) {
         c->pool = value != 0;
+    } else if (!strcmp(name, "fuse_step")) {
+        if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "fuse_step must be 0 or 1");
+        c->fuse_step = (int)value;
     } else if (!strcmp(name, "pool_hint")) {
         if (value < 0 || value > 128) return fail(c, BPE_E_ARG, "pool_hint must be 0..128");
         c->pool_hint = (int)value;

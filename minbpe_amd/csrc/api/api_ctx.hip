@@ -129,6 +129,12 @@ struct bpe_ctx {
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
                                               // across steps) instead of k_chain_sel (one count level at a time); in a sharded job in two halves around the MIN all-reduce: k_pool_sel, k_pool_sel_dp
+    int fuse_step = 1;                        // option "fuse_step": a sparse chain step of a single-GPU job is ONE launch (k_step.hip:
+                                              // selection -> published batch -> merge pass -> grid barrier -> table update) instead of three
+    unsigned long long *d_step_pub = nullptr; // ... its published line (STEP_PUB_WORDS granules)
+    uint32_t *d_step_bar = nullptr;           // ... its grid-barrier counter (only ever grows; zeroed when a train() begins)
+    uint32_t step_bar_target = 0;             // ... and what it will read once every launch enqueued so far is through its barrier
+    uint64_t n_fused = 0;                     // chain steps of the last train() that were one launch
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
     PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
     uint32_t *d_pool_gather = nullptr;
@@ -1126,7 +1132,9 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
 int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, bool records, bool dense = false) {
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, zhi);
-    TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    // one launch for the whole step (k_step.hip) where there is nothing between its parts: a single-GPU job's sparse steps
+    const bool fused = c->fuse_step && c->pool && !dense && !c->dp_comm && use_index && c->idx_live;
+    if (!fused) TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     CandArgs C;
     C.idx = c->d_idx;
     C.dirty = c->d_idx_dirty;
@@ -1163,6 +1171,92 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     // (the deciding workgroup and the scanning ones wait for each other: all of them must be resident at once -- one
     // 1024-thread workgroup per CU at most, like lean_grid)
     const unsigned nscan = (unsigned)std::max(1, std::min(c->chain_scan, c->num_cus - 1));
+    if (fused) {
+        // ---- the whole step as ONE launch (k_step.hip) ----------------------------------------------------------------
+        if (!c->d_step_pub) {
+            HIPCHK(c, hipMalloc((void **)&c->d_step_pub, 64 * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->d_step_pub, 0, 64 * sizeof(unsigned long long), c->stream));
+        }
+        if (!c->d_step_bar) {
+            HIPCHK(c, hipMalloc((void **)&c->d_step_bar, 256));
+            HIPCHK(c, hipMemsetAsync(c->d_step_bar, 0, 256, c->stream));
+            c->step_bar_target = 0;
+        }
+        const uint32_t nwords = (T + 31) / 32;
+        StepArgs S;
+        S.rowmax = c->d_rowmax;
+        S.mat = c->d_mat;
+        S.stride = c->vcap;
+        S.st = c->d_st;
+        S.ref = stream_ref_h(c);
+        S.C = C;
+        S.dbits = c->d_dbits;
+        S.res = c->d_lean_res;
+        S.tag = ++c->lean_tag;
+        S.req = c->d_chain_req;
+        S.kcap = kcap;
+        S.pool = c->d_pool;
+        S.gather = c->d_pool_gather;
+        S.hint_below = hint_below;
+        AbArgs &A = S.A;
+        A.b0 = c->d_ids[0];
+        A.b1 = c->d_ids[1];
+        A.hdr_in = c->d_hdr2[c->mq];
+        A.hdr_out = nullptr;
+        A.stage = c->d_stage;
+        A.smask = c->d_smask;
+        A.T = T;
+        A.st = c->d_st;
+        A.newid = 0;  // (the device knows: the published line)
+        A.delta = c->d_delta;
+        A.vcap = dl;
+        A.idx = c->d_idx;
+        A.istride = (uint32_t)c->idx_cap_words;
+        A.cand = nullptr;
+        uint32_t *const removed = (c->weighted || !c->count_is_removed) ? c->d_removed : nullptr;
+        A.removed = removed;
+        A.dirty_n = c->d_dirty_n;
+        S.idx_dirty = c->d_idx_dirty;
+        S.use_index = 1u | (c->chain_prefetch ? 2u : 0u);
+        // the grid: what the merge pass wants, what the table update needs (a token per thread), the scanning workgroups --
+        // all of it resident at once: one 1024-thread workgroup per CU at most
+        const unsigned gapply = (zhi + 1 + 1023) / 1024;
+        const unsigned cap = std::min((unsigned)c->num_cus, std::max(std::max((unsigned)c->lean_grid, gapply), 2u));
+        const unsigned gmerge = std::max(1u, std::min(std::min(nwords, (unsigned)c->lean_grid), cap));
+        const unsigned ns = std::min(nscan, cap - 1);
+        const unsigned G = std::min(cap, std::max(std::max(gmerge, gapply), 1 + ns));
+        if (G < gapply) return fail(c, BPE_E_INTERNAL, "fused chain step: %u workgroups cannot hold %u tokens", G, zhi + 1);
+        S.nscan = ns;
+        S.gm = gmerge;
+        S.delta = c->d_delta;
+        S.dl = dl;
+        S.par = c->par;
+        S.rec = c->h_rec;
+        S.srec = c->h_srec;
+        S.step = step;
+        S.hdr_cur = c->d_hdr2[c->mq];
+        S.stage = c->d_stage;
+        S.removed = removed;
+        S.smask = c->d_smask;
+        S.nwords = nwords;
+        S.sums = c->d_lean_sum;
+        S.pub = c->d_step_pub;
+        S.bar = c->d_step_bar;
+        c->step_bar_target += G;
+        S.bar_target = c->step_bar_target;
+        TRY(prof_begin(c, BPE_PROF_MERGE, 0));
+        hipLaunchKernelGGL(GK(c, k_step), dim3(G), dim3(LEAN_MT), 0, c->stream, S);
+        LAUNCHCHK(c, "k_step");
+        TRY(prof_end(c));
+        c->par ^= 1;
+        c->stats_valid = false;
+        c->stream_is_bytes = false;
+        c->rows_pending = true;
+        c->n_steps++;
+        c->n_fused++;
+        c->n_sparse++;
+        return BPE_OK;
+    }
     if (c->pool)
         hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,

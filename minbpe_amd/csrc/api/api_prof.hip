@@ -42,9 +42,9 @@ int bpe_train_stats_ex(bpe_ctx *c, uint64_t *out, int n) {
         TRY(read_state(c, &stt));
         chained = stt.chain_taken;
     }
-    const uint64_t v[10] = {c->n_dense, c->n_sparse, c->n_index_builds, c->slot_T, c->n_lean, c->n_deferred,
-                            chained + c->n_chained, c->n_steps, c->n_full, (uint64_t)c->ts};
-    for (int i = 0; i < n && i < 10; i++) out[i] = v[i];
+    const uint64_t v[11] = {c->n_dense, c->n_sparse, c->n_index_builds, c->slot_T, c->n_lean, c->n_deferred,
+                            chained + c->n_chained, c->n_steps, c->n_full, (uint64_t)c->ts, c->n_fused};
+    for (int i = 0; i < n && i < 11; i++) out[i] = v[i];
     return BPE_OK;
 }
 

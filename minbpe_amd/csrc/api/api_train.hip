@@ -66,6 +66,11 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     c->n_sparse = c->n_dense = c->n_index_builds = 0;
     c->n_lean = c->n_deferred = 0;
     c->n_steps = c->n_full = c->n_chained = 0;
+    c->n_fused = 0;
+    if (c->d_step_bar) {  // (a launch that a device status cut short in an earlier call may have left the count short)
+        HIPCHK(c, hipMemsetAsync(c->d_step_bar, 0, 256, c->stream));
+        c->step_bar_target = 0;
+    }
     c->rows_pending = false;
     c->sum_valid = false;
     // The units of work in flight, oldest first.  GENERAL / LEAN: one iteration whose number the host knows.

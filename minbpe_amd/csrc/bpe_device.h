@@ -270,4 +270,46 @@ struct IterRec {
     unsigned long long seq;  // iteration + 1 once every field above is final
 };
 
+// a sparse chain step as one launch (k_step.hip): the arguments of its three phases -- selection (k_pool_sel's), merge
+// pass (k_merge_chain's), table update (k_apply_chain's) -- and of the hand-overs between them
+struct StepArgs {
+    // selection
+    uint32_t *rowmax, *mat;
+    uint32_t stride;
+    DevState *st;
+    SlotRefH ref;
+    CandArgs C;
+    uint32_t *dbits;
+    unsigned long long *res;   // row maxima on their way to the deciding workgroup
+    uint32_t tag;              // this launch's tag (never repeats): validates res / req / pub words
+    unsigned long long *req;   // a rebuild's request / answer words
+    uint32_t kcap;
+    PoolEnt *pool;
+    uint32_t *gather;
+    uint32_t hint_below;
+    uint32_t nscan;            // workgroups 1 .. nscan do a rebuild's row work
+    // merge pass
+    AbArgs A;
+    const uint32_t *idx_dirty;
+    uint32_t use_index;
+    uint32_t gm;               // workgroups 0 .. gm - 1 take part in the merge pass
+    // table update
+    uint32_t *delta;
+    uint32_t dl;
+    int par;
+    IterRec *rec;
+    StepRec *srec;
+    uint32_t step;
+    SlotHdr *hdr_cur;
+    const StageRec *stage;
+    uint32_t *removed;
+    uint32_t *smask;
+    uint32_t nwords;
+    uint4 *sums;
+    // hand-overs
+    unsigned long long *pub;   // the published line (32 words: the batch itself)
+    uint32_t *bar;             // grid-barrier counter: only ever grows ...
+    uint32_t bar_target;       // ... to this value once every workgroup of this launch has arrived
+};
+
 }  // namespace bpe

@@ -44,6 +44,7 @@
 #include "kernels/k_lean.hip"
 #include "kernels/k_chain.hip"
 #include "kernels/k_pool.hip"
+#include "kernels/k_step.hip"
 #include "kernels/k_dp.hip"
 #undef BPE_G
 #define BPE_G bpe_g1
@@ -56,6 +57,7 @@
 #include "kernels/k_lean.hip"
 #include "kernels/k_chain.hip"
 #include "kernels/k_pool.hip"
+#include "kernels/k_step.hip"
 #include "kernels/k_dp.hip"
 #undef BPE_G
 #include "kernels/k_encode.hip"

@@ -281,10 +281,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = make_uint4(h[4], h[5], 0u, 0u);
         } else {
-            StageRec *r = A.stage + t;
-            r->t = t;
-#pragma unroll
-            for (int i = 0; i < 8; i++) r->h[i] = h[i];
+            stage_put(A.stage + t, t, h);
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
         if (total < 3 && t + 1 < Tl) A.st->gap = 1;
@@ -405,33 +402,29 @@ __device__ __forceinline__ uint32_t chain_hash_build(uint32_t *s_ph, uint32_t *s
 }
 
 // ---------------------------------------------------------------------------
-// merge pass of a chain step: k_merge_ab_lean for the st->bk pairs of the batch (index live)
-__global__ void __launch_bounds__(LEAN_MT)
-k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_out[LEAN_MT / 64][TILE2];
-    __shared__ uint32_t s_list[LEAN_SUB * 32];
-    __shared__ uint32_t s_tot[2];
-    __shared__ uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
-    __shared__ uint32_t s_ph[256], s_hm;
+// merge pass of a chain step: k_merge_ab_lean for the K pairs of the batch (index live).  The body is shared by
+// k_merge_chain (its own launch: the batch comes from st) and k_step (k_step.hip: one launch per step, the batch comes
+// from the deciding workgroup's published line); nblk workgroups take part, this one is number blk.
+struct MergeLds {
+    alignas(16) uint32_t s_out[LEAN_MT / 64][TILE2];
+    uint32_t s_list[LEAN_SUB * 32];
+    uint32_t s_tot[2];
+    uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
+    uint32_t s_ph[256], s_hm;
+};
+// (s_pa / s_pb / s_pb1 are filled and a barrier has passed; every thread of the workgroup calls)
+__device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index,
+                                                 MergeLds &L, const uint32_t K, const uint32_t z0, const uint32_t brep,
+                                                 const uint32_t blk, const uint32_t nblk) {
     DevState *st = A.st;
-    // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
-    const uint32_t ran = st->sel_ran;
-    if (blockIdx.x == 0 && ran) {
-        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
-        __syncthreads();
-        if (threadIdx.x == 0) st->sel_ran = 0;
-    }
-    const uint32_t K = st->bk;
-    if (st->status || st->defer || K == 0) return;
-    const uint32_t z0 = st->bz0, brep = st->brep;
-    if (threadIdx.x < CH_KMAX) {
-        s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
-        s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
-        s_pb1[threadIdx.x + 1] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
-        if (threadIdx.x == 0) s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
-    }
-    __syncthreads();
-    const uint32_t hm = chain_hash_build(s_ph, &s_hm, s_pa, K);
+    auto &s_out = L.s_out;
+    auto &s_list = L.s_list;
+    auto &s_tot = L.s_tot;
+    auto &s_pa = L.s_pa;
+    auto &s_pb = L.s_pb;
+    auto &s_pb1 = L.s_pb1;
+    const uint32_t hm = chain_hash_build(L.s_ph, &L.s_hm, s_pa, K);
+    const uint32_t *s_ph = L.s_ph;
     const uint32_t Tl = min(A.T, st->tlive);
     constexpr uint32_t NWV = LEAN_MT / 64;
     // a batch of one: the single-pair rewrite (merge_ab_wave, k_slots2.hip) -- no per-pair loops, format B's
@@ -449,13 +442,13 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
         }
     };
     if (!(use_index & 1u) || st->gap != 0) {  // short slots about: visit everything
-        const uint32_t nw = gridDim.x * NWV;
-        for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw) do_slot(t);
+        const uint32_t nw = nblk * NWV;
+        for (uint32_t t = blk * NWV + wave_id(); t < Tl; t += nw) do_slot(t);
         return;
     }
     const uint32_t nwords = (Tl + 31) / 32;
-    const uint32_t per = (nwords + gridDim.x - 1) / gridDim.x;  // mask words of one workgroup
-    const uint32_t wlo = blockIdx.x * per, whi = min(nwords, wlo + per);
+    const uint32_t per = (nwords + nblk - 1) / nblk;  // mask words of one workgroup
+    const uint32_t wlo = blk * per, whi = min(nwords, wlo + per);
     for (uint32_t sub = wlo; sub < whi; sub += LEAN_SUB) {
         uint32_t mk = 0;
         const uint32_t w = sub + threadIdx.x;
@@ -504,6 +497,29 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
         }
         __syncthreads();  // (the list is rewritten by the next round)
     }
+}
+__global__ void __launch_bounds__(LEAN_MT)
+k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
+    __shared__ MergeLds L;
+    DevState *st = A.st;
+    // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
+    const uint32_t ran = st->sel_ran;
+    if (blockIdx.x == 0 && ran) {
+        for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) st->sel_ran = 0;
+    }
+    const uint32_t K = st->bk;
+    if (st->status || st->defer || K == 0) return;
+    const uint32_t z0 = st->bz0, brep = st->brep;
+    if (threadIdx.x < CH_KMAX) {
+        L.s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
+        L.s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        L.s_pb1[threadIdx.x + 1] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        if (threadIdx.x == 0) L.s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
+    }
+    __syncthreads();
+    merge_chain_body(A, idx_dirty, use_index, L, K, z0, brep, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -592,51 +608,60 @@ k_merge_chain_dense1(AbArgs A) {
 }
 
 // ---------------------------------------------------------------------------
-// table update of a chain step.  Workgroups [0, na): one token per thread, every pair of the batch.
-// Workgroups [na, grid): commit the staged headers; the first of them also makes the stream length, the
-// iteration records of the step's merges, the step record, and the next step's mode.
-__global__ void __launch_bounds__(256)
-k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
-              const uint32_t *__restrict__ rowmax, DevState *st, uint32_t *__restrict__ dbits, int par, IterRec *rec,
-              StepRec *srec, uint32_t step, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
-              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums,
-              const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail) {
-    // folded != nullptr (sharded training): the batch's delta is the all-reduced payload of k_dp_fold_chain -- pair p's
-    // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
-    // (sharded: ftail[16] = the number of ranks whose status was raised when they folded this step's delta -- a
-    // failure inside any rank's merge pass stops every rank at this same merge)
-    const uint32_t remote = (folded && ftail[16] != 0) ? 1u : 0u;
-    const uint32_t status = st->status ? st->status : (remote ? ST_INTERNAL : 0u), defer = st->defer;
-    const uint32_t K = st->bk, z0 = st->bz0;
-    const bool noop = status || defer || K == 0;
-    if (blockIdx.x < na) {
-        if (noop) return;
-        const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+// table update of a chain step, in three parts shared by k_apply_chain (its own launch) and k_step (k_step.hip: the tail
+// of the step's one launch):
+//   apply_chain_tokens   one token per thread, every pair of the batch;
+//   apply_chain_records  64 threads: the stream length, the iteration records of the step's merges, the step record;
+//   apply_chain_commit   the staged headers.
+// OWNED == false: the flag words (dbits) are shared with whoever set them before -- atomicOr.  OWNED == true (k_step):
+// nobody else touches them during this phase, and the wave that holds tokens [64 k, 64 k + 64) is the only writer of
+// words 2 k and 2 k + 1: it stores them whole -- and starts from zero when the step's selection re-scanned every flagged
+// row (`ran`), which is how k_step clears the flags without a pass of its own.
+// OWNED also means: this is a phase of k_step -- the batch's pairs come from the published line (`pairs`: a << 16 | b, in
+// LDS; brep_line), and what other workgroups wrote earlier in this launch (the delta words and adj counts by device
+// atomics, the row maxima of re-scanned rows) is read with agent-scope loads (k_common.hip).
+template <bool OWNED>
+__device__ __forceinline__ void apply_chain_tokens(const uint32_t t, uint32_t *__restrict__ mat, uint32_t stride,
+                                                   uint32_t *__restrict__ delta, uint32_t vcap, const uint32_t *__restrict__ rowmax,
+                                                   DevState *st, uint32_t *__restrict__ dbits, uint4 *__restrict__ sums,
+                                                   const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail,
+                                                   const uint32_t K, const uint32_t z0, const uint32_t ran,
+                                                   const uint32_t *pairs = nullptr, const uint32_t brep_line = 0) {
+    auto dld = [&](const uint32_t *p) -> uint32_t { return OWNED ? ld_agent(p) : *p; };
+    auto pair_a = [&](uint32_t p) -> uint32_t { return OWNED ? (pairs[p] >> 16) : (uint32_t)st->ba[p]; };
+    auto pair_b = [&](uint32_t p) -> uint32_t { return OWNED ? (pairs[p] & 0xFFFFu) : (uint32_t)st->bb[p]; };
+    {
         const uint32_t Zlast = z0 + K - 1u;
-        if (blockIdx.x * 256u > Zlast) return;  // (the host sized the grid for the most a step can reach)
+        if ((t & ~255u) > Zlast) return;  // (the host sized the grid for the most a step can reach)
         const bool live = t <= Zlast;  // (dead lanes stay for the wave reductions below)
         const uint32_t nrep = 1u << (vcap >> 24);
         const uint32_t vc = vcap & 0xFFFFFFu;
-        const uint32_t M = st->count;
-        (void)M;
         uint2 rm = make_uint2(0u, 0u);
-        uint32_t prevflag = 0;
-        if (live) {
+        uint32_t prevflag = 0, oldword = 0;
+        if (OWNED) {
+            oldword = ran ? 0u : dbits[t >> 5];  // (every lane of the half-wave reads its word: one request)
+            prevflag = (oldword >> (t & 31)) & 1u;
+            if (live) {  // (a row re-scanned by this launch's selection has its maximum from another workgroup)
+                const unsigned long long v = ld_agent64(reinterpret_cast<const unsigned long long *>(rowmax) + t);
+                rm = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+            }
+        } else if (live) {
             prevflag = (dbits[t >> 5] >> (t & 31)) & 1u;  // (flagged by an earlier step of this level, not re-scanned yet)
             rm = reinterpret_cast<const uint2 *>(rowmax)[t];
         }
         bool flagged = false;
         if (K == 1) {
             // ---- one pair: all nrep replicas, (t,a) loaded up front (no returning atomic) ----------------
-            const uint32_t a = (uint32_t)st->ba[0], b = (uint32_t)st->bb[0], Z = z0;
-            const uint32_t adj = folded ? ftail[0] : st->adj;  // (merge_ab_wave's adj)
-            uint32_t x[16][2];
+            const uint32_t a = pair_a(0), b = pair_b(0), Z = z0;
+            const uint32_t adj = folded ? ftail[0] : dld(&st->adj);  // (merge_ab_wave's adj)
+            constexpr int RB = OWNED ? 8 : 16;  // replicas in flight at a time (k_step: 128 registers per lane)
+            uint32_t x[RB][2];
             auto load_batch = [&](uint32_t r0) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < RB; k++) {
                     const uint32_t r = r0 + k;
-                    x[k][0] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + t] : 0u;
-                    x[k][1] = (live && r < nrep) ? delta[delta_rep_off(r, vc) + vc + t] : 0u;
+                    x[k][0] = (live && r < nrep) ? dld(&delta[delta_rep_off(r, vc) + t]) : 0u;
+                    x[k][1] = (live && r < nrep) ? dld(&delta[delta_rep_off(r, vc) + vc + t]) : 0u;
                 }
             };
             if (!folded) load_batch(0);
@@ -648,13 +673,13 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             }
             for (uint32_t r0 = 0; !folded;) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
+                for (int k = 0; k < RB; k++) {
                     if (x[k][0]) delta[delta_rep_off(r0 + k, vc) + t] = 0;
                     if (x[k][1]) delta[delta_rep_off(r0 + k, vc) + vc + t] = 0;
                     sl += x[k][0];
                     sr += x[k][1];
                 }
-                r0 += 16;
+                r0 += RB;
                 if (r0 >= nrep) break;
                 load_batch(r0);
             }
@@ -670,8 +695,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             flagged |= live && ((t == a) | (t == b) | (t == Z));
         } else {
             // ---- a batch: brep replicas per pair, eight pairs' worth of loads in flight at a time -------------------------
-            const uint32_t brep = folded ? 0u : st->brep;
-            constexpr int G = 8;
+            const uint32_t brep = folded ? 0u : (OWNED ? brep_line : st->brep);
+            constexpr int G = OWNED ? 4 : 8;  // (k_step's workgroups are 1024 threads: 128 registers per lane, not 256)
             for (uint32_t g = 0; g < K; g += G) {  // (uniform)
                 uint32_t x[G][CH_REP][2];
                 if (brep == (uint32_t)CH_REP) {
@@ -680,8 +705,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 #pragma unroll
                         for (int r = 0; r < CH_REP; r++) {
                             const size_t o = delta_rep_off((g + (uint32_t)q) * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
-                            x[q][r][0] = (live && g + (uint32_t)q < K) ? delta[o + t] : 0u;
-                            x[q][r][1] = (live && g + (uint32_t)q < K) ? delta[o + vc + t] : 0u;
+                            x[q][r][0] = (live && g + (uint32_t)q < K) ? dld(&delta[o + t]) : 0u;
+                            x[q][r][1] = (live && g + (uint32_t)q < K) ? dld(&delta[o + vc + t]) : 0u;
                         }
                     }
                 }
@@ -689,8 +714,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                 for (int q = 0; q < G; q++) {
                     const uint32_t p = g + (uint32_t)q;
                     if (p >= K) break;  // (uniform)
-                    const uint32_t a = (uint32_t)st->ba[p], b = (uint32_t)st->bb[p], Z = z0 + p;
-                    const uint32_t adj = folded ? ftail[p] : st->badj[p];
+                    const uint32_t a = pair_a(p), b = pair_b(p), Z = z0 + p;
+                    const uint32_t adj = folded ? ftail[p] : dld(&st->badj[p]);
                     uint32_t sl = 0, sr = 0;
                     if (folded) {
                         sl = live ? folded[(size_t)(2 * p) * fS + t] : 0u;
@@ -705,20 +730,24 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                             sr += x[q][r][1];
                         }
                     } else {  // (pairs with thousands of sites: all CH_RSTRIDE replicas, one pair at a time)
-                        uint32_t y[CH_RSTRIDE][2];
+                        constexpr int YB = OWNED ? CH_RSTRIDE / 2 : CH_RSTRIDE;
 #pragma unroll
-                        for (int r = 0; r < CH_RSTRIDE; r++) {
-                            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
-                            y[r][0] = live ? delta[o + t] : 0u;
-                            y[r][1] = live ? delta[o + vc + t] : 0u;
-                        }
+                        for (int r0 = 0; r0 < CH_RSTRIDE; r0 += YB) {
+                            uint32_t y[YB][2];
 #pragma unroll
-                        for (int r = 0; r < CH_RSTRIDE; r++) {
-                            const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)r, vc);
-                            if (y[r][0]) delta[o + t] = 0;
-                            if (y[r][1]) delta[o + vc + t] = 0;
-                            sl += y[r][0];
-                            sr += y[r][1];
+                            for (int r = 0; r < YB; r++) {
+                                const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)(r0 + r), vc);
+                                y[r][0] = live ? dld(&delta[o + t]) : 0u;
+                                y[r][1] = live ? dld(&delta[o + vc + t]) : 0u;
+                            }
+#pragma unroll
+                            for (int r = 0; r < YB; r++) {
+                                const size_t o = delta_rep_off(p * (uint32_t)CH_RSTRIDE + (uint32_t)(r0 + r), vc);
+                                if (y[r][0]) delta[o + t] = 0;
+                                if (y[r][1]) delta[o + vc + t] = 0;
+                                sl += y[r][0];
+                                sr += y[r][1];
+                            }
                         }
                     }
                     const uint32_t dr = sr + (t == a ? adj : 0u), ir = sr + (t == Z ? adj : 0u);
@@ -736,20 +765,33 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
                 }
             }
         }
-        if (flagged && !prevflag) atomicOr(&dbits[t >> 5], 1u << (t & 31));
+        if (OWNED) {
+            const unsigned long long fb = __ballot(flagged);
+            const uint32_t mine = (lane_id() < 32) ? (uint32_t)fb : (uint32_t)(fb >> 32);
+            const uint32_t neww = oldword | mine;
+            if ((lane_id() & 31) == 0 && (ran || neww != oldword)) dbits[t >> 5] = neww;
+        } else if (flagged && !prevflag) {
+            atomicOr(&dbits[t >> 5], 1u << (t & 31));
+        }
         // ---- what the next FULL selection needs: the largest maximum of my wave's 64 rows (flagged rows left
         // out: they are re-scanned), the first row that attains it, that row's arg, how many rows attain it
         const uint32_t vs = (!live || flagged || prevflag) ? 0u : rm.x;
-        const uint32_t gw = blockIdx.x * 4u + wave_id(), base = gw * 64u;
+        const uint32_t gw = t >> 6, base = gw * 64u;
         const int lane = lane_id();
         const uint32_t m = wave_umax_dpp(vs);
         const unsigned long long bal = __ballot(m != 0 && vs == m);
         const int fl = bal ? __ffsll((long long)bal) - 1 : 0;
         const uint32_t arg = (uint32_t)__shfl((int)rm.y, fl);
         if (lane == 0) sums[gw] = make_uint4(m, base + (uint32_t)fl, arg, (uint32_t)__popcll(bal));
-        return;
     }
-    if (blockIdx.x == na && threadIdx.x < 64) {
+}
+// the step's records (the first 64 threads of ONE workgroup call)
+// (k_step: the workgroup that SELECTED calls -- what the selection left in st is then its own workgroup's writes; the
+// removal counters, filled by every workgroup's device atomics earlier in the same launch, are read at agent scope)
+__device__ __forceinline__ void apply_chain_records(DevState *st, int par, IterRec *rec, StepRec *srec, uint32_t step,
+                                                    uint32_t *__restrict__ removed, const uint32_t K, const bool noop,
+                                                    const uint32_t status, const uint32_t defer, const uint32_t remote) {
+    {
         // ids removed by the merge pass: CH_RMV counters per pair of the batch, one per 256-byte line (lane l: counters
         // 4l .. 4l + 3, all of pair l / 4)
         // (removed == nullptr: an unweighted stream -- a merge of a != b removes exactly as many ids as the pair counts, base.py:25-41:
@@ -758,7 +800,7 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
         if (removed) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t x = removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE];
+                const uint32_t x = ld_agent(&removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE]);
                 if (x) removed[(threadIdx.x * 4 + i) * REMOVED_STRIDE] = 0;
                 v += x;
             }
@@ -818,22 +860,52 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
             sr->seq = (unsigned long long)step + 1;
         }
     }
-    if (noop) return;
-    // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]
-    const uint32_t stp = (gridDim.x - na) * blockDim.x;
-    for (uint32_t w = (blockIdx.x - na) * blockDim.x + threadIdx.x; w < nwords; w += stp) {
-        uint32_t m = smask[w];
+}
+// staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]; this thread takes mask words
+// first, first + stp, ...
+__device__ __forceinline__ void apply_chain_commit(uint32_t first, uint32_t stp, uint32_t nwords, uint32_t *__restrict__ smask,
+                                                   const StageRec *__restrict__ stage, SlotHdr *__restrict__ hdr_cur) {
+    for (uint32_t w = first; w < nwords; w += stp) {
+        uint32_t m = ld_agent(&smask[w]);  // (set by device atomics; in k_step by other workgroups of this launch)
         if (!m) continue;
         smask[w] = 0;
         while (m) {
             const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
-            const StageRec r = stage[t];
+            uint32_t h[8];
+            stage_get(stage + t, h);
             uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
-            dst[0] = make_uint4(r.h[0], r.h[1], r.h[2], r.h[3]);
-            dst[1] = make_uint4(r.h[4], r.h[5], r.h[6], r.h[7]);
+            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            dst[1] = make_uint4(h[4], h[5], h[6], h[7]);
         }
     }
+}
+// Workgroups [0, na): one token per thread, every pair of the batch.  Workgroups [na, grid): commit the staged headers;
+// the first of them also makes the stream length, the iteration records of the step's merges, the step record, and the
+// next step's mode.
+__global__ void __launch_bounds__(256)
+k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict__ delta, uint32_t vcap,
+              const uint32_t *__restrict__ rowmax, DevState *st, uint32_t *__restrict__ dbits, int par, IterRec *rec,
+              StepRec *srec, uint32_t step, uint32_t na, SlotHdr *__restrict__ hdr_cur, const StageRec *__restrict__ stage,
+              uint32_t *__restrict__ removed, uint32_t *__restrict__ smask, uint32_t nwords, uint4 *__restrict__ sums,
+              const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail) {
+    // folded != nullptr (sharded training): the batch's delta is the all-reduced payload of k_dp_fold_chain -- pair p's
+    // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
+    // (sharded: ftail[16] = the number of ranks whose status was raised when they folded this step's delta -- a
+    // failure inside any rank's merge pass stops every rank at this same merge)
+    const uint32_t remote = (folded && ftail[16] != 0) ? 1u : 0u;
+    const uint32_t status = st->status ? st->status : (remote ? ST_INTERNAL : 0u), defer = st->defer;
+    const uint32_t K = st->bk, z0 = st->bz0;
+    const bool noop = status || defer || K == 0;
+    if (blockIdx.x < na) {
+        if (noop) return;
+        apply_chain_tokens<false>(blockIdx.x * 256u + threadIdx.x, mat, stride, delta, vcap, rowmax, st, dbits, sums, folded, fS,
+                                  ftail, K, z0, 0u);
+        return;
+    }
+    if (blockIdx.x == na && threadIdx.x < 64) apply_chain_records(st, par, rec, srec, step, removed, K, noop, status, defer, remote);
+    if (noop) return;
+    apply_chain_commit((blockIdx.x - na) * blockDim.x + threadIdx.x, (gridDim.x - na) * blockDim.x, nwords, smask, stage, hdr_cur);
 }
 
 // ---------------------------------------------------------------------------

@@ -85,4 +85,47 @@ __device__ __forceinline__ uint32_t lane_next(uint32_t x, uint32_t fill) {  // v
     return (uint32_t)dpp_mov<0x130>((int)fill, (int)x);
 }
 
+
+// ---------------------------------------------------------------------------
+// Agent-scope accesses for data that crosses workgroups INSIDE one launch (k_step.hip).  The eight XCDs have an L2 each;
+// a plain store may sit dirty in the writer's L2 and a plain load may hit a line the reader's L2 fetched earlier, until
+// a kernel boundary cleans both -- and a fence that cleans them inside a launch (buffer_wbl2 + buffer_inv) costs 14 us
+// per grid barrier with one fencing thread per workgroup, 120 us with all of them (tools/atomic_peak.hip,
+// profiles/r6_atomic_peak.json).  A relaxed agent-scope store is written through to the memory side, a relaxed agent-scope
+// load is served from there: what is handed over this way needs no cache maintenance, only s_waitcnt(0) before the
+// writer signals (grid barrier without fences: 3.8 us).
+typedef unsigned long long __attribute__((address_space(1))) g_u64;
+typedef uint32_t __attribute__((address_space(1))) g_u32;
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+    return __hip_atomic_load((g_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) {
+    return __hip_atomic_load((g_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+    __hip_atomic_store((g_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store((g_u64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a staged slot header (sparse merge passes): written by the wave that rewrote slot t, read by whoever commits it --
+// another workgroup, in k_step in the same launch
+__device__ __forceinline__ void stage_put(StageRec *r, uint32_t t, const uint32_t (&h)[8]) {
+    r->t = t;
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(r->h);
+#pragma unroll
+    for (int i = 0; i < 4; i++) st_agent64(q + i, (unsigned long long)h[2 * i] | ((unsigned long long)h[2 * i + 1] << 32));
+}
+__device__ __forceinline__ void stage_get(const StageRec *r, uint32_t (&h)[8]) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(r->h);
+    unsigned long long v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = ld_agent64(q + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        h[2 * i] = (uint32_t)v[i];
+        h[2 * i + 1] = (uint32_t)(v[i] >> 32);
+    }
+}
+
 }  // namespace bpe

@@ -419,7 +419,8 @@ __device__ __forceinline__ void lean_scan_rows(uint32_t *__restrict__ mat, uint3
         uint32_t m = 0, arg = 0;
         if (x != NOROW) row_scan_wide(mat + (size_t)x * stride, ncols, x == sa ? (int)sb : -1, s_red, m, arg);
         if (threadIdx.x == 0) {
-            if (x != NOROW) reinterpret_cast<uint2 *>(rowmax)[x] = make_uint2(m, arg);
+            // (written through: in k_step the table update of the same launch reads it from another workgroup)
+            if (x != NOROW) st_agent64(reinterpret_cast<unsigned long long *>(rowmax) + x, (unsigned long long)m | ((unsigned long long)arg << 32));
             if (publish) {
                 granule_put(res + 2 * (size_t)(i - lo), tag, m);
                 granule_put(res + 2 * (size_t)(i - lo) + 1, tag, arg);

@@ -134,7 +134,7 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
     __syncthreads();
     const uint32_t K = *s_k;
     if (tid == 0) {
-        st->adj = 0;
+        st_agent(&st->adj, 0u);  // (written through: the merge pass adds to it with device atomics -- in k_step in this very launch)
         st->count = a_c[0];
         st->ntied = s_le[0];
         st->firstpos = NOPOS;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
             for (uint32_t i = 0; i < K; i++) {
                 st->ba[i] = (int32_t)(a_xy[i] >> 16);
                 st->bb[i] = (int32_t)(a_xy[i] & 0xFFFFu);
-                st->badj[i] = 0;
+                st_agent(&st->badj[i], 0u);
                 st->bcnt[i] = a_c[i];
                 cmax = max(cmax, a_c[i]);
             }
@@ -189,22 +189,53 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(1024)
-k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
-           CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-           unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
-           uint32_t hint_below, long long *__restrict__ dpkey, unsigned long long dprank, PoolEnt *__restrict__ mid) {
-    __shared__ unsigned long long s_red[32];
-    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
-    __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
-    __shared__ uint32_t a_xy[PL_GATHER], a_c[PL_GATHER], b_xy[PL_GATHER], b_c[PL_GATHER];
-    __shared__ unsigned long long a_key[PL_GATHER], b_key[PL_GATHER];
-    __shared__ uint32_t s_ls[PL_CAP], s_le[PL_CAP], s_dirty[PL_CAP], s_clash[PL_CAP];
-    __shared__ int32_t s_tied[2 * TIE_CAP];
-    __shared__ unsigned long long s_pos[TIE_CAP];
-    __shared__ uint32_t s_lidx[TIE_CAP];
-    __shared__ uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[PL_CAP / 64];
-    __shared__ uint32_t s_fail, s_n, s_theta, s_nrows, s_nl, s_reach, s_k, s_unt, s_x;
+// The LDS of a selection (one struct, so that k_step can overlay it with its merge pass's).
+struct PoolLds {
+    unsigned long long s_red[32];
+    uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
+    uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
+    uint32_t a_xy[PL_GATHER], a_c[PL_GATHER], b_xy[PL_GATHER], b_c[PL_GATHER];
+    unsigned long long a_key[PL_GATHER], b_key[PL_GATHER];
+    uint32_t s_ls[PL_CAP], s_le[PL_CAP], s_dirty[PL_CAP], s_clash[PL_CAP];
+    int32_t s_tied[2 * TIE_CAP];
+    unsigned long long s_pos[TIE_CAP];
+    uint32_t s_lidx[TIE_CAP];
+    uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[PL_CAP / 64];
+    uint32_t s_fail, s_n, s_theta, s_nrows, s_nl, s_reach, s_k, s_unt, s_x;
+};
+// The selection: workgroup `blk` of `nblk` (0 decides, 1 .. nblk - 1 do a rebuild's row work); every thread calls.  Shared
+// by k_pool_sel (its own launch) and k_step (k_step.hip: the head of the step's one launch).
+__device__ __forceinline__ void
+pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, const SlotRefH &ref,
+              const CandArgs &C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+              unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
+              uint32_t hint_below, long long *__restrict__ dpkey, unsigned long long dprank, PoolEnt *__restrict__ mid,
+              PoolLds &L, const uint32_t blk, const uint32_t nblk) {
+    auto &s_red = L.s_red;
+    auto &s_words = L.s_words;
+    auto &s_pref = L.s_pref;
+    auto &s_exrow = L.s_exrow;
+    auto &s_exm = L.s_exm;
+    auto &s_exarg = L.s_exarg;
+    auto &a_xy = L.a_xy;
+    auto &a_c = L.a_c;
+    auto &b_xy = L.b_xy;
+    auto &b_c = L.b_c;
+    auto &a_key = L.a_key;
+    auto &b_key = L.b_key;
+    auto &s_ls = L.s_ls;
+    auto &s_le = L.s_le;
+    auto &s_dirty = L.s_dirty;
+    auto &s_clash = L.s_clash;
+    auto &s_tied = L.s_tied;
+    auto &s_pos = L.s_pos;
+    auto &s_lidx = L.s_lidx;
+    auto &s_rows = L.s_rows;
+    auto &s_cnt = L.s_cnt;
+    auto &s_r16 = L.s_r16;
+    auto &s_wtot = L.s_wtot;
+    uint32_t &s_fail = L.s_fail, &s_n = L.s_n, &s_theta = L.s_theta, &s_nrows = L.s_nrows, &s_nl = L.s_nl, &s_k = L.s_k,
+             &s_unt = L.s_unt, &s_x = L.s_x;
     const uint32_t status = st->status, defer = st->defer, gap = st->gap;
     const uint32_t iter = st->iter, nm = st->num_merges, hint = st->pool_hint;
     const uint32_t tid = threadIdx.x;
@@ -213,20 +244,20 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     // -status, [1] = -1 if this rank cannot order its share (short slots about), [2 + l] = rank << 33 | first local
     // position of the l-th entry to locate, INT64_MAX = no occurrence here) and the sorted pool in `mid`;
     // k_pool_sel_dp finishes the selection from the reduced words.  Every word is first written with its neutral value.
-    if (dpkey && blockIdx.x == 0 && tid < (uint32_t)DP_KEY_WORDS)
+    if (dpkey && blk == 0 && tid < (uint32_t)DP_KEY_WORDS)
         dpkey[tid] = tid == 0 ? -(long long)status : (tid == 1 ? 0ll : 0x7FFFFFFFFFFFFFFFll);
     if (status || defer) return;
     if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
-        if (blockIdx.x == 0 && tid == 0) st->bk = 0;
+        if (blk == 0 && tid == 0) st->bk = 0;
         return;
     }
     const uint32_t vcur = 256u + iter;
     const DirtyView D{s_words, s_pref};
     // ================= workgroups 1..: a rebuild's row work (only in a launch that was told to expect one) ===========
-    if (blockIdx.x != 0) {
+    if (blk != 0) {
         if (!hint) return;
         const uint32_t nd = dirty_view_build(dbits, D);
-        if (nd) lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
+        if (nd) lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blk - 1, nblk - 1, res, tag,
                                true, s_red, 3);
         if (tid == 0) {
             uint32_t n = 0, th = 0;
@@ -237,8 +268,8 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
         }
         __syncthreads();
         const uint32_t n = s_n, theta = s_theta;
-        if (blockIdx.x - 1 >= n) return;
-        for (uint32_t j = blockIdx.x - 1; j < n; j += gridDim.x - 1) {
+        if (blk - 1 >= n) return;
+        for (uint32_t j = blk - 1; j < n; j += nblk - 1) {
             if (tid == 0) {
                 uint32_t x = 0;
                 s_x = granule_get(req + 1 + j, tag, x) ? x : 0xFFFFFFFFu;
@@ -277,7 +308,7 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
         }
         __threadfence();
         __syncthreads();
-        if (tid == 0) granule_put(req + 2 + PL_ROWS + blockIdx.x, tag, 1u);
+        if (tid == 0) granule_put(req + 2 + PL_ROWS + blk, tag, 1u);
         return;
     }
     // ================= the deciding workgroup ========================================================================
@@ -481,7 +512,7 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
             granule_put(req + 1 + PL_ROWS, tag, theta);
             granule_put(req, tag, nrows);
         }
-        const uint32_t nh = min(gridDim.x - 1, nrows);
+        const uint32_t nh = min(nblk - 1, nrows);
         if (tid < nh) {
             uint32_t d = 0;
             if (!granule_get(req + 2 + PL_ROWS + (tid + 1), tag, d)) s_fail = 1;
@@ -626,6 +657,16 @@ k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t s
     }
     pool_finish(st, pool, b_xy, b_c, b_key, a_xy, a_c, a_key, s_ls, s_le, s_dirty, s_clash, &s_k, &s_unt, n, kmax, iter, theta,
                 epoch, rebuilt, hint_below, PL_KSH);
+}
+
+__global__ void __launch_bounds__(1024)
+k_pool_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
+           CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
+           unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
+           uint32_t hint_below, long long *__restrict__ dpkey, unsigned long long dprank, PoolEnt *__restrict__ mid) {
+    __shared__ PoolLds L;
+    pool_sel_body(rowmax, mat, stride, st, ref, C, dbits, res, tag, req, kcap, pool, gather, hint_below, dpkey, dprank, mid, L,
+                  blockIdx.x, gridDim.x);
 }
 
 // k_pool_sel_dp: the second half of a sharded selection, after the MIN all-reduce of the first occurrences (one workgroup

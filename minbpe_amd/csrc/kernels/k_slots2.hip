@@ -305,10 +305,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = make_uint4(h[4], h[5], 0u, 0u);
         } else {
-            StageRec *r = A.stage + t;
-            r->t = t;
-#pragma unroll
-            for (int i = 0; i < 8; i++) r->h[i] = h[i];
+            stage_put(A.stage + t, t, h);
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
         if (LDSD) atomicAdd(&sd[2 * LDSD_CAP + 1], len - total);

@@ -62,23 +62,32 @@ __global__ void k_empty(uint32_t *p) {
 __global__ void __launch_bounds__(1024) k_empty_big(uint32_t *p) {
     if (p == nullptr) return;
 }
-// a chain of dependent hand-overs inside ONE launch: `rounds` grid barriers (monotone counter, bounded spin)
+// a chain of dependent hand-overs inside ONE launch: `rounds` grid barriers (monotone counter, bounded spin).
+// FENCE 0: every thread __threadfence() before and after (L2 write-back + invalidate by all 16 waves of every workgroup)
+//       1: one thread per workgroup fences (release before its arrival, acquire after the wait)
+//       2: no cache maintenance at all: s_waitcnt(0) + relaxed agent-scope atomics (what crosses workgroups then has to be
+//          written and read with agent-scope accesses itself)
+template <int FENCE>
 __global__ void __launch_bounds__(1024) k_barriers(uint32_t *ctr, uint32_t rounds, uint32_t base, uint32_t *fail) {
     for (uint32_t r = 0; r < rounds; r++) {
-        __threadfence();
+        if (FENCE == 0) __threadfence();
+        if (FENCE == 2) __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t target = base + (r + 1u) * gridDim.x;
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (FENCE == 1) __threadfence();
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t spins = 0;
-            while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                 if (++spins > (1u << 22)) {
                     *fail = 1;
                     break;
                 }
             }
+            if (FENCE == 1) __threadfence();
         }
         __syncthreads();
+        if (FENCE == 0) __threadfence();
     }
 }
 
@@ -144,20 +153,24 @@ int main() {
     };
     launches("empty_launch_1x64_back_to_back", false, 2000);
     launches("empty_launch_256x1024_back_to_back", true, 2000);
-    {
+    uint32_t base = 0;
+    auto barriers = [&](const char *name, auto kern) {
         const uint32_t rounds = 200;
-        uint32_t base = 0;
-        hipLaunchKernelGGL(k_barriers, dim3(grid), dim3(1024), 0, 0, ctr, rounds, base, fail);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, 0, ctr, rounds, base, fail);
         base += rounds * grid;
         CHK(hipDeviceSynchronize());
         CHK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_barriers, dim3(grid), dim3(1024), 0, 0, ctr, rounds, base, fail);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, 0, ctr, rounds, base, fail);
+        base += rounds * grid;
         CHK(hipEventRecord(e1, 0));
         const float ms = time_ms(e0, e1);
         uint32_t f = 0;
         CHK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
-        printf(", \"grid_barrier_256x1024\": {\"rounds\": %u, \"us_per_barrier\": %.3f, \"timed_out\": %u}", rounds, ms * 1e3 / rounds, f);
-    }
+        printf(", \"%s\": {\"rounds\": %u, \"us_per_barrier\": %.3f, \"timed_out\": %u}", name, rounds, ms * 1e3 / rounds, f);
+    };
+    barriers("grid_barrier_256x1024_every_thread_fences", k_barriers<0>);
+    barriers("grid_barrier_256x1024_one_thread_fences", k_barriers<1>);
+    barriers("grid_barrier_256x1024_no_cache_maintenance", k_barriers<2>);
     printf("}\n");
     return 0;
 }
