@@ -129,12 +129,15 @@ struct bpe_ctx {
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
                                               // across steps) instead of k_chain_sel (one count level at a time); in a sharded job in two halves around the MIN all-reduce: k_pool_sel, k_pool_sel_dp
-    int fuse_step = 1;                        // option "fuse_step": a sparse chain step of a single-GPU job is ONE launch (k_step.hip:
-                                              // selection -> published batch -> merge pass -> grid barrier -> table update) instead of three
+    int fuse_step = 0;                        // option "fuse_step": 1 = a sparse chain step of a single-GPU job is ONE launch (k_step.hip:
+                                              // selection -> published batch -> merge pass -> grid barrier -> table update) instead of three.
+                                              // Measured SLOWER than the three launches (this part overlaps a dependent launch's
+                                              // ramp with its predecessor's tail -- median gap 0.0 us -- and a fence-free grid barrier is 3.8 us): off
     unsigned long long *d_step_pub = nullptr; // ... its published line (STEP_PUB_WORDS granules)
     uint32_t *d_step_bar = nullptr;           // ... its grid-barrier counter (only ever grows; zeroed when a train() begins)
     uint32_t step_bar_target = 0;             // ... and what it will read once every launch enqueued so far is through its barrier
     uint64_t n_fused = 0;                     // chain steps of the last train() that were one launch
+    unsigned long long *d_step_stamps = nullptr;  // debug (env BPE_STEP_STAMPS=file): clock stamps of its phases, dumped when train() ends
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
     PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
     uint32_t *d_pool_gather = nullptr;
@@ -1244,6 +1247,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         S.bar = c->d_step_bar;
         c->step_bar_target += G;
         S.bar_target = c->step_bar_target;
+        S.stamps = c->d_step_stamps;
         TRY(prof_begin(c, BPE_PROF_MERGE, 0));
         hipLaunchKernelGGL(GK(c, k_step), dim3(G), dim3(LEAN_MT), 0, c->stream, S);
         LAUNCHCHK(c, "k_step");

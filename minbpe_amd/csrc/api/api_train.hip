@@ -67,6 +67,12 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
     c->n_lean = c->n_deferred = 0;
     c->n_steps = c->n_full = c->n_chained = 0;
     c->n_fused = 0;
+    static const char *stamp_path = getenv("BPE_STEP_STAMPS");
+    const size_t stamp_bytes = (size_t)STEP_STAMP_RING * (3 * 16 + 256 * 2) * sizeof(unsigned long long);
+    if (stamp_path) {
+        if (!c->d_step_stamps) HIPCHK(c, hipMalloc((void **)&c->d_step_stamps, stamp_bytes));
+        HIPCHK(c, hipMemsetAsync(c->d_step_stamps, 0, stamp_bytes, c->stream));
+    }
     if (c->d_step_bar) {  // (a launch that a device status cut short in an earlier call may have left the count short)
         HIPCHK(c, hipMemsetAsync(c->d_step_bar, 0, 256, c->stream));
         c->step_bar_target = 0;
@@ -426,6 +432,14 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         }
     }
     TRY(prof_drain(c));
+    if (stamp_path && c->d_step_stamps) {  // (debug: [step % STEP_STAMP_RING][workgroup 0 | gm / 2 | last][16 stamps of the 100 MHz clock])
+        std::vector<unsigned long long> h(stamp_bytes / sizeof(unsigned long long));
+        HIPCHK(c, hipMemcpy(h.data(), c->d_step_stamps, stamp_bytes, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(stamp_path, "wb")) {
+            fwrite(h.data(), 1, stamp_bytes, f);
+            fclose(f);
+        }
+    }
     if (timing) {
         auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "[bpe_train] %d merges: setup+enqueue of the first pass %.2f ms, loop %.2f ms, drain %.2f ms, "

@@ -175,6 +175,8 @@ struct DevState {
     uint32_t badj[CH_KMAX];       // delta format B, per pair of the batch: sites whose right neighbour starts a site of the SAME pair
     uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum: k_chain_sel)
     uint32_t brep;                // delta replicas per pair of this batch (CH_REP or CH_RSTRIDE)
+    uint32_t bhm, bhm_key;        // the multiplier of the batch's first-token look-up table (merge_chain_wave), found once by the selection
+                                  // instead of by every workgroup of the merge pass; valid iff bhm_key == bz0 << 8 | bk
     uint32_t dp_wait;             // sharded chain steps: k_chain_sel left a tie for k_chain_sel_dp to order (after the MIN all-reduce)
     // the pool (k_pool.hip): every pair that counts pool_theta or more, pool_n entries in the ctx's pool buffer
     uint32_t pool_n, pool_theta;
@@ -310,6 +312,8 @@ struct StepArgs {
     unsigned long long *pub;   // the published line (32 words: the batch itself)
     uint32_t *bar;             // grid-barrier counter: only ever grows ...
     uint32_t bar_target;       // ... to this value once every workgroup of this launch has arrived
+    unsigned long long *stamps;  // nullptr, or [STEP_STAMP_RING][3 workgroups][16] clock stamps of the phases (BPE_STEP_STAMPS: where a step's time goes)
 };
+constexpr uint32_t STEP_STAMP_RING = 8192;
 
 }  // namespace bpe

@@ -380,22 +380,35 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
 // and takes the first under which no two of the K tokens fall into the same of the 256 buckets (K <= 15: two in three
 // multipliers do); returns it to every thread (0: none found, or a batch too small to pay -- the pass compares).
 // s_ph: 256 words, s_hm: one word.  Every thread calls.
-__device__ __forceinline__ uint32_t chain_hash_build(uint32_t *s_ph, uint32_t *s_hm, const uint32_t *s_pa, uint32_t K) {
-    if (threadIdx.x < 256) s_ph[threadIdx.x] = 0xFFFFFFFFu;
-    if (threadIdx.x == 0) *s_hm = 0;
-    __syncthreads();
-    if (K >= 5 && wave_id() == 0) {
-        const uint32_t m = 129u + 2u * (uint32_t)lane_id();
-        bool ok = true;
-        for (uint32_t i = 1; i < K; i++) {
-            const uint32_t hi = (__umul24(s_pa[i], m) >> 8) & 255u;
-            for (uint32_t j = 0; j < i; j++) ok &= hi != ((__umul24(s_pa[j], m) >> 8) & 255u);
-        }
-        const unsigned long long bal = __ballot(ok);
-        if (lane_id() == 0 && bal) *s_hm = 129u + 2u * (uint32_t)(__ffsll((long long)bal) - 1);
+// the multiplier itself (one wave; returns it to lane 0 .. 63 alike): 0 = none found, or a batch too small to pay
+__device__ __forceinline__ uint32_t chain_hash_find(const uint32_t *pa, uint32_t K) {
+    if (K < 5) return 0u;
+    const uint32_t m = 129u + 2u * (uint32_t)lane_id();
+    bool ok = true;
+    for (uint32_t i = 1; i < K; i++) {
+        const uint32_t hi = (__umul24(pa[i], m) >> 8) & 255u;
+        for (uint32_t j = 0; j < i; j++) ok &= hi != ((__umul24(pa[j], m) >> 8) & 255u);
     }
-    __syncthreads();
-    const uint32_t hm = *s_hm;
+    const unsigned long long bal = __ballot(ok);
+    return bal ? 129u + 2u * (uint32_t)(__ffsll((long long)bal) - 1) : 0u;
+}
+// (pre_ok: the selection already found the multiplier, pre_hm -- k_pool.hip: pool_finish; DevState::bhm)
+__device__ __forceinline__ uint32_t chain_hash_build(uint32_t *s_ph, uint32_t *s_hm, const uint32_t *s_pa, uint32_t K,
+                                                     bool pre_ok = false, uint32_t pre_hm = 0) {
+    if (threadIdx.x < 256) s_ph[threadIdx.x] = 0xFFFFFFFFu;
+    uint32_t hm = pre_hm;
+    if (!pre_ok) {  // (uniform)
+        if (threadIdx.x == 0) *s_hm = 0;
+        __syncthreads();
+        if (wave_id() == 0) {
+            const uint32_t f = chain_hash_find(s_pa, K);
+            if (lane_id() == 0) *s_hm = f;
+        }
+        __syncthreads();
+        hm = *s_hm;
+    } else {
+        __syncthreads();
+    }
     if (hm && threadIdx.x < K) s_ph[(__umul24(s_pa[threadIdx.x], hm) >> 8) & 255u] = (s_pa[threadIdx.x] << 8) | (threadIdx.x + 1u);
     __syncthreads();
     return hm;
@@ -415,7 +428,12 @@ struct MergeLds {
 // (s_pa / s_pb / s_pb1 are filled and a barrier has passed; every thread of the workgroup calls)
 __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index,
                                                  MergeLds &L, const uint32_t K, const uint32_t z0, const uint32_t brep,
-                                                 const uint32_t blk, const uint32_t nblk) {
+                                                 const uint32_t blk, const uint32_t nblk, unsigned long long *dbg = nullptr,
+                                                 const bool have_st = false, const uint32_t tlive_in = 0, const uint32_t gap_in = 0,
+                                                 const bool pre_ok = false, const uint32_t pre_hm = 0) {
+    auto dstamp = [&](int i) {  // (debug, BPE_STEP_STAMPS)
+        if (dbg && threadIdx.x == 0) dbg[i] = wall_clock64();
+    };
     DevState *st = A.st;
     auto &s_out = L.s_out;
     auto &s_list = L.s_list;
@@ -423,9 +441,11 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
     auto &s_pa = L.s_pa;
     auto &s_pb = L.s_pb;
     auto &s_pb1 = L.s_pb1;
-    const uint32_t hm = chain_hash_build(L.s_ph, &L.s_hm, s_pa, K);
+    const uint32_t hm = chain_hash_build(L.s_ph, &L.s_hm, s_pa, K, pre_ok, pre_hm);
     const uint32_t *s_ph = L.s_ph;
-    const uint32_t Tl = min(A.T, st->tlive);
+    // (have_st: the caller fetched the state words this pass needs in one round trip with the batch)
+    const uint32_t Tl = min(A.T, have_st ? tlive_in : st->tlive);
+    const uint32_t gap = have_st ? gap_in : st->gap;
     constexpr uint32_t NWV = LEAN_MT / 64;
     // a batch of one: the single-pair rewrite (merge_ab_wave, k_slots2.hip) -- no per-pair loops, format B's
     // adj in st->adj, all 256 removal counters
@@ -441,11 +461,12 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
             merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
         }
     };
-    if (!(use_index & 1u) || st->gap != 0) {  // short slots about: visit everything
+    if (!(use_index & 1u) || gap != 0) {  // short slots about: visit everything
         const uint32_t nw = nblk * NWV;
         for (uint32_t t = blk * NWV + wave_id(); t < Tl; t += nw) do_slot(t);
         return;
     }
+    dstamp(8);
     const uint32_t nwords = (Tl + 31) / 32;
     const uint32_t per = (nwords + nblk - 1) / nblk;  // mask words of one workgroup
     const uint32_t wlo = blk * per, whi = min(nwords, wlo + per);
@@ -476,6 +497,7 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
             }
         }
         __syncthreads();
+        if (sub == wlo) dstamp(9);
         if (K == 1 || MJ > 1 || !(use_index & 2u)) {
             for (uint32_t i = wave_id(); i < n; i += NWV) do_slot(s_list[i]);
         } else {
@@ -498,28 +520,58 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
         __syncthreads();  // (the list is rewritten by the next round)
     }
 }
+// The words of DevState a chain step's merge pass / table update needs, fetched by 64 lanes at once (ONE round trip: the
+// fields used to be read where the code came to them -- status, then the batch, then tlive / gap: three dependent round
+// trips, ~4.5 us at the head of every launch): [p] = ba[p], [16 + p] = bb[p], [32 + p] = badj[p], then the scalars below.
+enum { SW_BK = 48, SW_BZ0, SW_BREP, SW_STATUS, SW_DEFER, SW_SEL_RAN, SW_TLIVE, SW_GAP, SW_BHM, SW_BHM_KEY, SW_ADJ, SW_N };
+static_assert(SW_N <= 64, "one wave fetches the state words");
+__device__ __forceinline__ void step_words_fetch(const DevState *st, uint32_t *s_w) {
+    const uint32_t i = threadIdx.x;
+    if (i < (uint32_t)SW_N) {
+        const uint32_t *base = reinterpret_cast<const uint32_t *>(st);
+        uint32_t off;
+        if (i < 16) off = (uint32_t)offsetof(DevState, ba) / 4 + i;
+        else if (i < 32) off = (uint32_t)offsetof(DevState, bb) / 4 + (i - 16);
+        else if (i < 48) off = (uint32_t)offsetof(DevState, badj) / 4 + (i - 32);
+        else {
+            constexpr uint32_t o[SW_N - 48] = {
+                (uint32_t)offsetof(DevState, bk) / 4,      (uint32_t)offsetof(DevState, bz0) / 4,     (uint32_t)offsetof(DevState, brep) / 4,
+                (uint32_t)offsetof(DevState, status) / 4,  (uint32_t)offsetof(DevState, defer) / 4,   (uint32_t)offsetof(DevState, sel_ran) / 4,
+                (uint32_t)offsetof(DevState, tlive) / 4,   (uint32_t)offsetof(DevState, gap) / 4,     (uint32_t)offsetof(DevState, bhm) / 4,
+                (uint32_t)offsetof(DevState, bhm_key) / 4, (uint32_t)offsetof(DevState, adj) / 4};
+            off = o[0];
+#pragma unroll
+            for (int k = 1; k < SW_N - 48; k++) off = (i == 48u + (uint32_t)k) ? o[k] : off;
+        }
+        s_w[i] = base[off];
+    }
+    __syncthreads();
+}
 __global__ void __launch_bounds__(LEAN_MT)
 k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
     __shared__ MergeLds L;
+    __shared__ uint32_t s_w[64];
     DevState *st = A.st;
+    step_words_fetch(st, s_w);
     // (the flagged rows were re-scanned by the selection launch before this one if that was a FULL one)
-    const uint32_t ran = st->sel_ran;
+    const uint32_t ran = s_w[SW_SEL_RAN];
     if (blockIdx.x == 0 && ran) {
         for (uint32_t i = threadIdx.x; i < DBITS_WORDS; i += LEAN_MT) dbits[i] = 0;
         __syncthreads();
         if (threadIdx.x == 0) st->sel_ran = 0;
     }
-    const uint32_t K = st->bk;
-    if (st->status || st->defer || K == 0) return;
-    const uint32_t z0 = st->bz0, brep = st->brep;
+    const uint32_t K = s_w[SW_BK];
+    if (s_w[SW_STATUS] || s_w[SW_DEFER] || K == 0) return;
+    const uint32_t z0 = s_w[SW_BZ0], brep = s_w[SW_BREP];
     if (threadIdx.x < CH_KMAX) {
-        L.s_pa[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->ba[threadIdx.x] : 0xFFFFFFFFu;
-        L.s_pb[threadIdx.x] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
-        L.s_pb1[threadIdx.x + 1] = threadIdx.x < K ? (uint32_t)st->bb[threadIdx.x] : 0xFFFFFFFFu;
+        L.s_pa[threadIdx.x] = threadIdx.x < K ? s_w[threadIdx.x] : 0xFFFFFFFFu;
+        L.s_pb[threadIdx.x] = threadIdx.x < K ? s_w[16 + threadIdx.x] : 0xFFFFFFFFu;
+        L.s_pb1[threadIdx.x + 1] = threadIdx.x < K ? s_w[16 + threadIdx.x] : 0xFFFFFFFFu;
         if (threadIdx.x == 0) L.s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
     }
     __syncthreads();
-    merge_chain_body(A, idx_dirty, use_index, L, K, z0, brep, blockIdx.x, gridDim.x);
+    merge_chain_body(A, idx_dirty, use_index, L, K, z0, brep, blockIdx.x, gridDim.x, nullptr, true, s_w[SW_TLIVE], s_w[SW_GAP],
+                     s_w[SW_BHM_KEY] == ((z0 << 8) | K), s_w[SW_BHM]);
 }
 
 // ---------------------------------------------------------------------------
@@ -617,19 +669,20 @@ k_merge_chain_dense1(AbArgs A) {
 // nobody else touches them during this phase, and the wave that holds tokens [64 k, 64 k + 64) is the only writer of
 // words 2 k and 2 k + 1: it stores them whole -- and starts from zero when the step's selection re-scanned every flagged
 // row (`ran`), which is how k_step clears the flags without a pass of its own.
-// OWNED also means: this is a phase of k_step -- the batch's pairs come from the published line (`pairs`: a << 16 | b, in
-// LDS; brep_line), and what other workgroups wrote earlier in this launch (the delta words and adj counts by device
-// atomics, the row maxima of re-scanned rows) is read with agent-scope loads (k_common.hip).
+// The batch comes from the caller, in LDS: pairs[p] = a << 16 | b, adjs[p] = format B's adj of pair p (adjs[0] for a batch of
+// one: merge_ab_wave's st->adj), brep_in.  OWNED also means: this is a phase of k_step -- what other workgroups wrote
+// earlier in this launch (the delta words by device atomics, the row maxima of re-scanned rows) is read with agent-scope
+// loads (k_common.hip).
 template <bool OWNED>
 __device__ __forceinline__ void apply_chain_tokens(const uint32_t t, uint32_t *__restrict__ mat, uint32_t stride,
                                                    uint32_t *__restrict__ delta, uint32_t vcap, const uint32_t *__restrict__ rowmax,
-                                                   DevState *st, uint32_t *__restrict__ dbits, uint4 *__restrict__ sums,
+                                                   uint32_t *__restrict__ dbits, uint4 *__restrict__ sums,
                                                    const uint32_t *__restrict__ folded, uint32_t fS, const uint32_t *__restrict__ ftail,
                                                    const uint32_t K, const uint32_t z0, const uint32_t ran,
-                                                   const uint32_t *pairs = nullptr, const uint32_t brep_line = 0) {
+                                                   const uint32_t *pairs, const uint32_t *adjs, const uint32_t brep_in) {
     auto dld = [&](const uint32_t *p) -> uint32_t { return OWNED ? ld_agent(p) : *p; };
-    auto pair_a = [&](uint32_t p) -> uint32_t { return OWNED ? (pairs[p] >> 16) : (uint32_t)st->ba[p]; };
-    auto pair_b = [&](uint32_t p) -> uint32_t { return OWNED ? (pairs[p] & 0xFFFFu) : (uint32_t)st->bb[p]; };
+    auto pair_a = [&](uint32_t p) -> uint32_t { return pairs[p] >> 16; };
+    auto pair_b = [&](uint32_t p) -> uint32_t { return pairs[p] & 0xFFFFu; };
     {
         const uint32_t Zlast = z0 + K - 1u;
         if ((t & ~255u) > Zlast) return;  // (the host sized the grid for the most a step can reach)
@@ -653,7 +706,7 @@ __device__ __forceinline__ void apply_chain_tokens(const uint32_t t, uint32_t *_
         if (K == 1) {
             // ---- one pair: all nrep replicas, (t,a) loaded up front (no returning atomic) ----------------
             const uint32_t a = pair_a(0), b = pair_b(0), Z = z0;
-            const uint32_t adj = folded ? ftail[0] : dld(&st->adj);  // (merge_ab_wave's adj)
+            const uint32_t adj = folded ? ftail[0] : adjs[0];  // (merge_ab_wave's adj)
             constexpr int RB = OWNED ? 8 : 16;  // replicas in flight at a time (k_step: 128 registers per lane)
             uint32_t x[RB][2];
             auto load_batch = [&](uint32_t r0) {
@@ -695,7 +748,7 @@ __device__ __forceinline__ void apply_chain_tokens(const uint32_t t, uint32_t *_
             flagged |= live && ((t == a) | (t == b) | (t == Z));
         } else {
             // ---- a batch: brep replicas per pair, eight pairs' worth of loads in flight at a time -------------------------
-            const uint32_t brep = folded ? 0u : (OWNED ? brep_line : st->brep);
+            const uint32_t brep = folded ? 0u : brep_in;
             constexpr int G = OWNED ? 4 : 8;  // (k_step's workgroups are 1024 threads: 128 registers per lane, not 256)
             for (uint32_t g = 0; g < K; g += G) {  // (uniform)
                 uint32_t x[G][CH_REP][2];
@@ -715,7 +768,7 @@ __device__ __forceinline__ void apply_chain_tokens(const uint32_t t, uint32_t *_
                     const uint32_t p = g + (uint32_t)q;
                     if (p >= K) break;  // (uniform)
                     const uint32_t a = pair_a(p), b = pair_b(p), Z = z0 + p;
-                    const uint32_t adj = folded ? ftail[p] : dld(&st->badj[p]);
+                    const uint32_t adj = folded ? ftail[p] : adjs[p];
                     uint32_t sl = 0, sr = 0;
                     if (folded) {
                         sl = live ? folded[(size_t)(2 * p) * fS + t] : 0u;
@@ -830,15 +883,8 @@ __device__ __forceinline__ void apply_chain_records(DevState *st, int par, IterR
             if (!noop) {
                 for (uint32_t p = 0; p < K; p++) {
                     nn -= rem[p];
-                    IterRec *r = rec + iter + p;
-                    r->a = st->ba[p];
-                    r->b = st->bb[p];
-                    r->count = st->bcnt[p];
-                    r->status = ST_OK;
-                    r->new_len = nn;
+                    iter_rec_put(rec + iter + p, st->ba[p], st->bb[p], st->bcnt[p], ST_OK, nn);
                 }
-                __threadfence_system();
-                for (uint32_t p = 0; p < K; p++) rec[iter + p].seq = (unsigned long long)(iter + p) + 1;
                 k_done = K;
                 st->iter = iter + K;
                 // the list minus the batch: anything left -> the next step takes its pairs off it
@@ -851,13 +897,13 @@ __device__ __forceinline__ void apply_chain_records(DevState *st, int par, IterR
             st->removed = 0;
             st->pool_hint = st->pool_hint_next;  // (k_pool.hip: what this step's selection announced for the next one)
             StepRec *sr = srec + (step % STEP_RING);
-            sr->first_iter = iter;
-            sr->k = k_done;
-            sr->status = (status == 0 && defer) ? ST_DEFER : status;
-            sr->pad = mode_used | (defer << 8);  // (defer: 1 = a == b heads the list, 2 = a tie the step could not settle)
-            sr->new_len = nn;
-            __threadfence_system();
-            sr->seq = (unsigned long long)step + 1;
+            // (pad: defer 1 = a == b heads the list, 2 = a tie the step could not settle)
+            step_rec_put(sr, iter, k_done, (status == 0 && defer) ? (uint32_t)ST_DEFER : status, mode_used | (defer << 8), nn);
+            // ONE wait for everything above to be acknowledged, then the sequence words (the host waits on the step's, then on
+            // each merge's: every record it reads is final once its own sequence word shows)
+            __builtin_amdgcn_s_waitcnt(0);
+            for (uint32_t p = 0; p < k_done; p++) iter_rec_seal(rec + iter + p, (unsigned long long)(iter + p) + 1);
+            step_rec_seal(sr, (unsigned long long)step + 1);
         }
     }
 }
@@ -893,14 +939,19 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
     // SL at folded[2p fS ..), SR at folded[(2p + 1) fS ..), its adj in ftail[p] -- instead of this rank's replica blocks
     // (sharded: ftail[16] = the number of ranks whose status was raised when they folded this step's delta -- a
     // failure inside any rank's merge pass stops every rank at this same merge)
+    __shared__ uint32_t s_w[64], s_pairs[CH_KMAX];
+    step_words_fetch(st, s_w);
     const uint32_t remote = (folded && ftail[16] != 0) ? 1u : 0u;
-    const uint32_t status = st->status ? st->status : (remote ? ST_INTERNAL : 0u), defer = st->defer;
-    const uint32_t K = st->bk, z0 = st->bz0;
+    const uint32_t status = s_w[SW_STATUS] ? s_w[SW_STATUS] : (remote ? ST_INTERNAL : 0u), defer = s_w[SW_DEFER];
+    const uint32_t K = s_w[SW_BK], z0 = s_w[SW_BZ0];
     const bool noop = status || defer || K == 0;
     if (blockIdx.x < na) {
         if (noop) return;
-        apply_chain_tokens<false>(blockIdx.x * 256u + threadIdx.x, mat, stride, delta, vcap, rowmax, st, dbits, sums, folded, fS,
-                                  ftail, K, z0, 0u);
+        if (threadIdx.x < CH_KMAX) s_pairs[threadIdx.x] = (s_w[threadIdx.x] << 16) | (s_w[16 + threadIdx.x] & 0xFFFFu);
+        if (threadIdx.x == 0 && K == 1) s_w[32] = s_w[SW_ADJ];  // (a batch of one: merge_ab_wave's adj word)
+        __syncthreads();
+        apply_chain_tokens<false>(blockIdx.x * 256u + threadIdx.x, mat, stride, delta, vcap, rowmax, dbits, sums, folded, fS,
+                                  ftail, K, z0, 0u, s_pairs, s_w + 32, s_w[SW_BREP]);
         return;
     }
     if (blockIdx.x == na && threadIdx.x < 64) apply_chain_records(st, par, rec, srec, step, removed, K, noop, status, defer, remote);

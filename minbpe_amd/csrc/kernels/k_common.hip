@@ -108,6 +108,34 @@ __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
 __device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store((g_u64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The records a chain step leaves in pinned HOST memory (IterRec per merge, StepRec per step): every field written through
+// with system-scope stores, the sequence word after the others have been acknowledged.  No __threadfence_system(): that
+// fence writes back every dirty line of the L2 first -- in k_step the whole merge pass's slots -- to publish 32 bytes.
+typedef unsigned long long __attribute__((address_space(1))) g_u64s;
+__device__ __forceinline__ void st_system64(void *p, unsigned long long v) {
+    __hip_atomic_store((g_u64s *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void iter_rec_put(IterRec *r, int32_t a, int32_t b, uint32_t count, uint32_t status, unsigned long long new_len) {
+    static_assert(sizeof(IterRec) == 32, "IterRec: {a, b}, {count, status}, new_len, seq");
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(r);
+    st_system64(q + 0, (unsigned long long)(uint32_t)a | ((unsigned long long)(uint32_t)b << 32));
+    st_system64(q + 1, (unsigned long long)count | ((unsigned long long)status << 32));
+    st_system64(q + 2, new_len);
+}
+__device__ __forceinline__ void iter_rec_seal(IterRec *r, unsigned long long seq) {  // (after s_waitcnt(0))
+    st_system64(reinterpret_cast<unsigned long long *>(r) + 3, seq);
+}
+__device__ __forceinline__ void step_rec_put(StepRec *r, uint32_t first_iter, uint32_t k, uint32_t status, uint32_t pad, unsigned long long new_len) {
+    static_assert(sizeof(StepRec) == 32, "StepRec: {first_iter, k}, {status, pad}, new_len, seq");
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(r);
+    st_system64(q + 0, (unsigned long long)first_iter | ((unsigned long long)k << 32));
+    st_system64(q + 1, (unsigned long long)status | ((unsigned long long)pad << 32));
+    st_system64(q + 2, new_len);
+}
+__device__ __forceinline__ void step_rec_seal(StepRec *r, unsigned long long seq) {
+    st_system64(reinterpret_cast<unsigned long long *>(r) + 3, seq);
+}
+
 // a staged slot header (sparse merge passes): written by the wave that rewrote slot t, read by whoever commits it --
 // another workgroup, in k_step in the same launch
 __device__ __forceinline__ void stage_put(StageRec *r, uint32_t t, const uint32_t (&h)[8]) {

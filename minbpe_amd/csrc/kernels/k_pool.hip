@@ -48,45 +48,103 @@ static_assert(PL_GATHER >= 4 * PL_CAP, "maintain: four variants per entry");
 // [2 + PL_ROWS + w] = workgroup w has gathered its rows
 constexpr uint32_t PL_REQ_WORDS = 2 + PL_ROWS + 256;
 
+// Scratch of the helpers below.  They are written for LATENCY: a selection is one workgroup's serial work in the middle of
+// every step (20 of a late step's 58 us while its loops ran one entry per thread over a level or over the whole pool, each
+// iteration waiting for its LDS read, and thread 0 walked the levels alone: profiles/r6_step_stamps_*.json) -- so every
+// "count the entries that rank before mine" is split over several threads per entry, and what thread 0 did in loops is a
+// ballot or a prefix sum.
+struct PoolScratch {
+    uint32_t dl[PL_CAP];       // [level start] the level lacks an order
+    uint32_t rank[PL_GATHER];  // partial ranks, summed by LDS atomics
+    uint32_t w[8];             // per wave: last / first level start
+    uint32_t wtot[PL_CAP / 64];
+    uint32_t fv, nl, k;
+};
 // entries ranked by count (descending; equal counts by pair): out[rank] = in[i].  n <= PL_GATHER, every thread
 // calls.  The order INSIDE a level is made later, from the keys, by a loop over the level alone.
 __device__ __forceinline__ void pool_sort(const uint32_t *ixy, const uint32_t *ic, const unsigned long long *ikey,
-                                          uint32_t *oxy, uint32_t *oc, unsigned long long *okey, uint32_t n) {
-    const uint32_t i = threadIdx.x;
-    if (i < n) {
-        const uint32_t c = ic[i], x = ixy[i];
+                                          uint32_t *oxy, uint32_t *oc, unsigned long long *okey, uint32_t n, PoolScratch &X) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t sh = 0;  // log2(threads per entry)
+    while (sh < 4 && (n << (sh + 1)) <= blockDim.x) sh++;
+    const uint32_t tpe = 1u << sh, e = tid >> sh, q = tid & (tpe - 1u);
+    if (tid < n) X.rank[tid] = 0;
+    __syncthreads();
+    if (e < n) {
+        const uint32_t c = ic[e], x = ixy[e];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n; j++) {
+#pragma unroll 4
+        for (uint32_t j = q; j < n; j += tpe) {
             const uint32_t cj = ic[j];
             r += (cj > c) | ((cj == c) & (ixy[j] < x));  // (equal counts by pair: the same order on every rank of a sharded job)
         }
-        oxy[r] = ixy[i];
-        oc[r] = c;
-        okey[r] = ikey[i];
+        if (r) atomicAdd(&X.rank[e], r);
+    }
+    __syncthreads();
+    if (tid < n) {
+        const uint32_t r = X.rank[tid];
+        oxy[r] = ixy[tid];
+        oc[r] = ic[tid];
+        okey[r] = ikey[tid];
     }
     __syncthreads();
 }
-// a level (entries [lo, hi) of a pool sorted by count) needs an order it does not have: several entries, not all of one epoch
 // (ksh: where the epoch sits in a key -- 40 on one GPU, PL_KSH_DP in a sharded job, whose positions carry the rank)
 constexpr int PL_KSH = 40, PL_KSH_DP = 43, PL_POS_DP = 33;  // sharded: epoch << 43 | rank << 33 | local position (< 2^33)
-__device__ __forceinline__ uint32_t pool_level_dirty(const unsigned long long *key, uint32_t lo, uint32_t hi, int ksh) {
-    if (hi - lo <= 1) return 0u;
-    const unsigned long long e0 = key[lo] >> ksh;
-    uint32_t d = e0 == 0;
-    for (uint32_t j = lo + 1; j < hi; j++) d |= (key[j] >> ksh) != e0;
-    return d;
-}
-// the bounds of every entry's level in a pool sorted by count (n <= PL_CAP; every thread calls)
-__device__ __forceinline__ void pool_level_bounds(const uint32_t *c, uint32_t n, uint32_t *ls, uint32_t *le) {
-    const uint32_t tid = threadIdx.x;
-    if (tid < n) {
-        const uint32_t ci = c[tid];
-        uint32_t lo = tid, hi = tid + 1;
-        while (lo > 0 && c[lo - 1] == ci) lo--;
-        while (hi < n && c[hi] == ci) hi++;
+// the bounds of every entry's level in a pool sorted by count (n <= PL_CAP; every thread calls; ends with a barrier): a
+// level starts where the count changes -- one ballot per wave, the nearest start below / above a lane from its bits
+__device__ __forceinline__ void pool_level_bounds(const uint32_t *c, uint32_t n, uint32_t *ls, uint32_t *le, PoolScratch &X) {
+    const uint32_t tid = threadIdx.x, w = (uint32_t)wave_id(), lane = (uint32_t)lane_id();
+    const bool in = tid < n;
+    const bool start = in && (tid == 0 || c[tid - 1] != c[tid]);
+    const unsigned long long bal = __ballot(start);
+    if (tid < PL_CAP && lane == 0) {
+        X.w[w] = bal ? w * 64u + 63u - (uint32_t)__clzll((long long)bal) : 0xFFFFFFFFu;        // the wave's last start
+        X.w[4 + w] = bal ? w * 64u + (uint32_t)__ffsll((long long)bal) - 1u : 0xFFFFFFFFu;     // ... and its first
+    }
+    __syncthreads();
+    if (in) {
+        const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const unsigned long long below = bal & upto, above = bal & ~upto;
+        uint32_t lo = 0, hi = n;
+        if (below) {
+            lo = w * 64u + 63u - (uint32_t)__clzll((long long)below);
+        } else {
+            for (int v = (int)w - 1; v >= 0; v--)
+                if (X.w[v] != 0xFFFFFFFFu) {
+                    lo = X.w[v];
+                    break;
+                }
+        }
+        if (above) {
+            hi = w * 64u + (uint32_t)__ffsll((long long)above) - 1u;
+        } else {
+            for (uint32_t v = w + 1; v < PL_CAP / 64; v++)
+                if (X.w[4 + v] != 0xFFFFFFFFu) {
+                    hi = X.w[4 + v];
+                    break;
+                }
+        }
         ls[tid] = lo;
         le[tid] = hi;
     }
+    __syncthreads();
+}
+// dirty[i] = the level of entry i (bounds ls / le) needs an order it does not have: several entries, not all of one epoch.
+// Every thread calls; ends with a barrier.
+__device__ __forceinline__ void pool_levels_dirty(const unsigned long long *key, uint32_t n, const uint32_t *ls, const uint32_t *le,
+                                                  uint32_t *dirty, int ksh, PoolScratch &X) {
+    const uint32_t tid = threadIdx.x;
+    if (tid < n) X.dl[tid] = 0;
+    __syncthreads();
+    if (tid < n) {
+        const uint32_t lo = ls[tid], hi = le[tid];
+        const unsigned long long e0 = key[lo] >> ksh;
+        if (hi - lo > 1 && (e0 == 0 || (key[tid] >> ksh) != e0)) X.dl[lo] = 1;  // (everybody who writes writes 1)
+    }
+    __syncthreads();
+    if (tid < n) dirty[tid] = X.dl[ls[tid]];
+    __syncthreads();
 }
 // The end of a selection, once the keys are what they are going to be (b_*: the pool sorted by count, s_ls / s_le its
 // level bounds): the order inside every level, the batch -- the longest prefix with a != b, no shared token, every level
@@ -97,39 +155,59 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
                                             unsigned long long *a_key, const uint32_t *s_ls, const uint32_t *s_le,
                                             uint32_t *s_dirty, uint32_t *s_clash, uint32_t *s_k, uint32_t *s_unt, uint32_t n,
                                             uint32_t kmax, uint32_t iter, uint32_t theta, unsigned long long epoch, bool rebuilt,
-                                            uint32_t hint_below, int ksh) {
+                                            uint32_t hint_below, int ksh, PoolScratch &X) {
     const uint32_t tid = threadIdx.x;
     const uint32_t nwalk = min(n, kmax);
     // ---- the order inside every level: by key (a level whose keys are not of one epoch stays without an order) ----------
+    const uint32_t sh = blockDim.x >= 4 * PL_CAP ? 2u : 0u;  // (threads per entry: four in the 1024-thread selection)
+    const uint32_t tpe = 1u << sh, e = tid >> sh, q = tid & (tpe - 1u);
     if (tid < n) {
-        const uint32_t lo = s_ls[tid], hi = s_le[tid];
-        const unsigned long long k = b_key[tid];
-        uint32_t r = lo;
-        for (uint32_t j = lo; j < hi; j++) {
-            const unsigned long long kj = b_key[j];
-            r += (kj < k) | ((kj == k) & (j < tid));
-        }
-        a_xy[r] = b_xy[tid];
-        a_c[r] = b_c[tid];
-        a_key[r] = k;
-        s_dirty[r] = pool_level_dirty(b_key, lo, hi, ksh);
+        X.rank[tid] = 0;
+        X.dl[tid] = 0;
     }
     if (tid == 0) *s_unt = 0;
     __syncthreads();
-    if (tid < nwalk) {
-        const uint32_t x = a_xy[tid] >> 16, y = a_xy[tid] & 0xFFFFu;
-        uint32_t bad = (x == y) | s_dirty[tid];
-        for (uint32_t j = 0; j < tid; j++) {
-            const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
-            bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
+    if (e < n) {
+        const uint32_t lo = s_ls[e], hi = s_le[e];
+        const unsigned long long k = b_key[e];
+        uint32_t r = 0;
+#pragma unroll 4
+        for (uint32_t j = lo + q; j < hi; j += tpe) {
+            const unsigned long long kj = b_key[j];
+            r += (kj < k) | ((kj == k) & (j < e));
         }
-        s_clash[tid] = bad;
+        if (r) atomicAdd(&X.rank[e], r);
+        if (q == 0) {
+            const unsigned long long e0 = b_key[lo] >> ksh;
+            if (hi - lo > 1 && (e0 == 0 || (k >> ksh) != e0)) X.dl[lo] = 1;
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t k = 0;
-        while (k < nwalk && !s_clash[k]) k++;
-        *s_k = k;
+    if (tid < n) {
+        const uint32_t lo = s_ls[tid];
+        const uint32_t r = lo + X.rank[tid];
+        a_xy[r] = b_xy[tid];
+        a_c[r] = b_c[tid];
+        a_key[r] = b_key[tid];
+        s_dirty[r] = X.dl[lo];
+    }
+    __syncthreads();
+    // ---- the batch: the longest prefix with a != b, no shared token, every level entered in a known order -----------------
+    if (tid < 64) {  // (nwalk <= CH_KSWEEP < 64: one wave)
+        uint32_t bad = 0;
+        if (tid < nwalk) {
+            const uint32_t x = a_xy[tid] >> 16, y = a_xy[tid] & 0xFFFFu;
+            bad = (x == y) | s_dirty[tid];
+#pragma unroll
+            for (uint32_t j = 0; j < (uint32_t)CH_KSWEEP - 1u; j++) {
+                if (j < tid) {
+                    const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
+                    bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
+                }
+            }
+        }
+        const unsigned long long bb = __ballot(bad != 0);
+        if (tid == 0) *s_k = bb ? min(nwalk, (uint32_t)__ffsll((long long)bb) - 1u) : nwalk;
     }
     __syncthreads();
     const uint32_t K = *s_k;
@@ -141,8 +219,8 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
         st->sel_tie = 0;
         st->a = (int32_t)(a_xy[0] >> 16);
         st->b = (int32_t)(a_xy[0] & 0xFFFFu);
-        st->fin_a = st->a;
-        st->fin_b = st->b;
+        st->fin_a = (int32_t)(a_xy[0] >> 16);
+        st->fin_b = (int32_t)(a_xy[0] & 0xFFFFu);
         st->bk = K;
         st->bz0 = 256u + iter;
         st->tl_n = st->tl_skip = 0;
@@ -156,29 +234,48 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
             st->pool_hint_next = 1;
         } else {
             st->found = 1;
-            uint32_t cmax = 0;
-            for (uint32_t i = 0; i < K; i++) {
-                st->ba[i] = (int32_t)(a_xy[i] >> 16);
-                st->bb[i] = (int32_t)(a_xy[i] & 0xFFFFu);
-                st_agent(&st->badj[i], 0u);
-                st->bcnt[i] = a_c[i];
-                cmax = max(cmax, a_c[i]);
-            }
-            st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
         }
     }
     if (K == 0) return;
+    if (tid < K) X.rank[tid] = a_xy[tid] >> 16;  // (the batch's first tokens, for chain_hash_find below)
+    __syncthreads();
+    if (tid < 64) {  // the batch itself, a pair per lane
+        uint32_t c = 0;
+        if (tid < K) {
+            c = a_c[tid];
+            st->ba[tid] = (int32_t)(a_xy[tid] >> 16);
+            st->bb[tid] = (int32_t)(a_xy[tid] & 0xFFFFu);
+            st_agent(&st->badj[tid], 0u);
+            st->bcnt[tid] = c;
+        }
+        const uint32_t cmax = wave_umax_dpp(c);
+        // the multiplier of the merge pass's first-token look-up table, found here once (chain_hash_find, k_chain.hip)
+        // instead of by every workgroup of the pass; the key says which batch it belongs to
+        const uint32_t hm = chain_hash_find(reinterpret_cast<const uint32_t *>(X.rank), K);
+        if (tid == 0) {
+            st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
+            st->bhm = hm;
+            st->bhm_key = ((256u + iter) << 8) | K;
+        }
+    }
     // ---- the rest is the next step's pool ----------------------------------------------------------------------------------
+    bool unt = false;
     if (tid >= K && tid < n) {
-        PoolEnt e;
-        e.xy = a_xy[tid];
-        e.c = a_c[tid];
-        e.key = a_key[tid];
-        pool[tid - K] = e;
-        const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
+        PoolEnt e2;
+        e2.xy = a_xy[tid];
+        e2.c = a_c[tid];
+        e2.key = a_key[tid];
+        pool[tid - K] = e2;
+        const uint32_t x = e2.xy >> 16, y = e2.xy & 0xFFFFu;
         bool touched = false;
-        for (uint32_t p = 0; p < K; p++) touched |= ((a_xy[p] & 0xFFFFu) == x) | ((a_xy[p] >> 16) == y);
-        if (!touched) atomicAdd(s_unt, 1u);
+#pragma unroll
+        for (uint32_t p = 0; p < (uint32_t)CH_KSWEEP; p++)
+            if (p < K) touched |= ((a_xy[p] & 0xFFFFu) == x) | ((a_xy[p] >> 16) == y);
+        unt = !touched;
+    }
+    if (tid < PL_CAP) {
+        const unsigned long long ub = __ballot(unt);
+        if (lane_id() == 0 && ub) atomicAdd(s_unt, (uint32_t)__popcll(ub));
     }
     __syncthreads();
     if (tid == 0) {
@@ -202,6 +299,8 @@ struct PoolLds {
     uint32_t s_lidx[TIE_CAP];
     uint32_t s_rows[PL_ROWS], s_cnt[8], s_r16[16], s_wtot[PL_CAP / 64];
     uint32_t s_fail, s_n, s_theta, s_nrows, s_nl, s_reach, s_k, s_unt, s_x;
+    PoolScratch X;
+    uint32_t s_sw[64];  // the words of st a selection needs (fetched at once)
 };
 // The selection: workgroup `blk` of `nblk` (0 decides, 1 .. nblk - 1 do a rebuild's row work); every thread calls.  Shared
 // by k_pool_sel (its own launch) and k_step (k_step.hip: the head of the step's one launch).
@@ -210,7 +309,10 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
               const CandArgs &C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
               unsigned long long *__restrict__ req, uint32_t kcap, PoolEnt *__restrict__ pool, uint32_t *__restrict__ gather,
               uint32_t hint_below, long long *__restrict__ dpkey, unsigned long long dprank, PoolEnt *__restrict__ mid,
-              PoolLds &L, const uint32_t blk, const uint32_t nblk) {
+              PoolLds &L, const uint32_t blk, const uint32_t nblk, unsigned long long *dbg = nullptr) {
+    auto dstamp = [&](int i) {  // (debug, BPE_STEP_STAMPS: where a selection's time goes)
+        if (dbg && threadIdx.x == 0 && blk == 0) dbg[i] = wall_clock64();
+    };
     auto &s_red = L.s_red;
     auto &s_words = L.s_words;
     auto &s_pref = L.s_pref;
@@ -234,11 +336,37 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     auto &s_cnt = L.s_cnt;
     auto &s_r16 = L.s_r16;
     auto &s_wtot = L.s_wtot;
-    uint32_t &s_fail = L.s_fail, &s_n = L.s_n, &s_theta = L.s_theta, &s_nrows = L.s_nrows, &s_nl = L.s_nl, &s_k = L.s_k,
+    uint32_t &s_fail = L.s_fail, &s_n = L.s_n, &s_theta = L.s_theta, &s_nrows = L.s_nrows, &s_nl = L.s_nl, &s_k = L.s_k, &s_reach = L.s_reach,
              &s_unt = L.s_unt, &s_x = L.s_x;
-    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
-    const uint32_t iter = st->iter, nm = st->num_merges, hint = st->pool_hint;
     const uint32_t tid = threadIdx.x;
+    // everything the selection needs from st, and its own pool entry, in ONE round trip (the fields used to be read where
+    // the code came to them: three dependent round trips before the first table word was asked for)
+    enum { PW_STATUS = 32, PW_DEFER, PW_GAP, PW_ITER, PW_NM, PW_HINT, PW_THETA, PW_POOLN, PW_BK, PW_BZ0, PW_EPOCH_LO, PW_EPOCH_HI, PW_N };
+    PoolEnt my_ent;
+    my_ent.xy = my_ent.c = 0;
+    my_ent.key = 0;
+    if (blk == 0 && tid < PL_CAP) my_ent = pool[tid];
+    if (tid < (uint32_t)PW_N) {
+        const uint32_t *base = reinterpret_cast<const uint32_t *>(st);
+        uint32_t off;
+        if (tid < 16) off = (uint32_t)offsetof(DevState, ba) / 4 + tid;
+        else if (tid < 32) off = (uint32_t)offsetof(DevState, bb) / 4 + (tid - 16);
+        else {
+            constexpr uint32_t o[PW_N - 32] = {
+                (uint32_t)offsetof(DevState, status) / 4,     (uint32_t)offsetof(DevState, defer) / 4,      (uint32_t)offsetof(DevState, gap) / 4,
+                (uint32_t)offsetof(DevState, iter) / 4,       (uint32_t)offsetof(DevState, num_merges) / 4, (uint32_t)offsetof(DevState, pool_hint) / 4,
+                (uint32_t)offsetof(DevState, pool_theta) / 4, (uint32_t)offsetof(DevState, pool_n) / 4,     (uint32_t)offsetof(DevState, bk) / 4,
+                (uint32_t)offsetof(DevState, bz0) / 4,        (uint32_t)offsetof(DevState, pool_epoch) / 4, (uint32_t)offsetof(DevState, pool_epoch) / 4 + 1};
+            off = o[0];
+#pragma unroll
+            for (int k = 1; k < PW_N - 32; k++) off = (tid == 32u + (uint32_t)k) ? o[k] : off;
+        }
+        L.s_sw[tid] = base[off];
+    }
+    __syncthreads();
+    const uint32_t *s_sw = L.s_sw;
+    const uint32_t status = s_sw[PW_STATUS], defer = s_sw[PW_DEFER], gap = s_sw[PW_GAP];
+    const uint32_t iter = s_sw[PW_ITER], nm = s_sw[PW_NM], hint = s_sw[PW_HINT];
     // Sharded training (dpkey != nullptr): the pool is a replica of GLOBAL state, so every rank maintains, gathers and
     // sorts alike -- but a first occurrence is a rank-local fact.  This launch leaves the MIN all-reduce payload ([0] =
     // -status, [1] = -1 if this rank cannot order its share (short slots about), [2 + l] = rank << 33 | first local
@@ -317,9 +445,9 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     };
     uint32_t rm[SEL_RPT];
     if (hint) select_load(rowmax, vcur, rm);  // (a rebuild is likely: the row maxima travel while the pool is looked at)
-    uint32_t theta = st->pool_theta;
-    unsigned long long epoch = st->pool_epoch;
-    const uint32_t n0 = min(st->pool_n, PL_CAP);
+    uint32_t theta = s_sw[PW_THETA];
+    unsigned long long epoch = (unsigned long long)s_sw[PW_EPOCH_LO] | ((unsigned long long)s_sw[PW_EPOCH_HI] << 32);
+    const uint32_t n0 = min(s_sw[PW_POOLN], PL_CAP);
     if (tid == 0) {
         s_fail = 0;
         s_nrows = 0;
@@ -327,19 +455,20 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         s_unt = 0;
     }
     if (tid < 8) s_cnt[tid] = 0;
+    dstamp(8);
     // ---- maintain: what the last batch made of my entry ------------------------------------------------------------
     uint32_t vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0}, keepm = 0, ec = 0;
     unsigned long long ekey = 0;
     if (tid < n0) {
-        const uint32_t Kp = st->bk, zp = st->bz0;
-        const PoolEnt e = pool[tid];
+        const uint32_t Kp = min(s_sw[PW_BK], (uint32_t)CH_KMAX), zp = s_sw[PW_BZ0];
+        const PoolEnt e = my_ent;
         const uint32_t x = e.xy >> 16, y = e.xy & 0xFFFFu;
         ec = e.c;
         ekey = e.key;
         int32_t zx = -1, zy = -1;
         for (uint32_t p = 0; p < Kp; p++) {
-            if ((uint32_t)st->bb[p] == x) zx = (int32_t)(zp + p);
-            if ((uint32_t)st->ba[p] == y) zy = (int32_t)(zp + p);
+            if (s_sw[16 + p] == x) zx = (int32_t)(zp + p);
+            if (s_sw[p] == y) zy = (int32_t)(zp + p);
         }
         vx[0] = vx[2] = x;
         vx[1] = vx[3] = zx >= 0 ? (uint32_t)zx : x;
@@ -377,6 +506,7 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         }
         __syncthreads();
     }
+    dstamp(9);
     uint32_t n1 = 0;
     if (n0) for (uint32_t w = 0; w < PL_CAP / 64; w++) n1 += s_wtot[w];
     bool rebuilt = false;
@@ -544,7 +674,9 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         if (hint && tid == 0) st->sel_ran = 1;  // (... but workgroups 1.. do re-scan every flagged row)
     }
     // ---- sort by count; more entries than the pool holds: whole levels leave from the bottom, theta rises above them ----
-    pool_sort(a_xy, a_c, a_key, b_xy, b_c, b_key, n1);
+    dstamp(10);
+    pool_sort(a_xy, a_c, a_key, b_xy, b_c, b_key, n1, L.X);
+    dstamp(11);
     uint32_t n = n1;
     if (n1 > PL_CAP) {
         if (tid == 0) {
@@ -572,54 +704,76 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     const uint32_t kmax = min(kcap, nm - iter);
     const uint32_t nwalk = min(n, kmax);  // the batch is a prefix of at most this many entries
     const int ksh = dpkey ? PL_KSH_DP : PL_KSH;
-    pool_level_bounds(b_c, n, s_ls, s_le);
-    if (tid < n) {
-        const uint32_t lo = s_ls[tid], hi = s_le[tid];
-        s_dirty[tid] = pool_level_dirty(b_key, lo, hi, ksh);
-        if (tid < nwalk) {  // does this entry end a batch that reaches its level (a == b, or a token shared with anything above its level's end)?
-            const uint32_t x = b_xy[tid] >> 16, y = b_xy[tid] & 0xFFFFu;
-            uint32_t cl = x == y;
-            for (uint32_t j = 0; j < hi; j++) {
-                const uint32_t xj = b_xy[j] >> 16, yj = b_xy[j] & 0xFFFFu;
-                cl |= (j != tid) & ((xj == x) | (xj == y) | (yj == x) | (yj == y));
-            }
-            s_clash[tid] = cl;
-        }
+    PoolScratch &X = L.X;
+    pool_level_bounds(b_c, n, s_ls, s_le, X);
+    pool_levels_dirty(b_key, n, s_ls, s_le, s_dirty, ksh, X);
+    // does entry i < nwalk end a batch that reaches its level (a == b, or a token shared with anything above its level's
+    // end)?  Entry j looks at every such i (nwalk <= 15 broadcast reads) instead of entry i looking at every j.
+    if (tid < 64) s_clash[tid] = 0;
+    if (tid == 0) {
+        X.fv = 0xFFFFFFFFu;
+        X.nl = 0;
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t lim = nwalk - 1u;
-        for (uint32_t i = 0; i <= lim; i++)
-            if (s_clash[i]) {
-                lim = i;
-                break;
+    if (tid < n) {
+        const uint32_t x = b_xy[tid] >> 16, y = b_xy[tid] & 0xFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < (uint32_t)CH_KSWEEP; i++) {
+            if (i < nwalk) {
+                const uint32_t xi = b_xy[i] >> 16, yi = b_xy[i] & 0xFFFFu;
+                if (tid != i && tid < s_le[i] && ((xi == x) | (xi == y) | (yi == x) | (yi == y))) s_clash[i] = 1;
             }
-        const uint32_t reach = s_le[lim];
-        uint32_t nl = 0;
+        }
+        if (tid < nwalk && x == y) s_clash[tid] = 1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned long long cb = __ballot(tid < nwalk && s_clash[tid] != 0);
+        const uint32_t lim = cb ? (uint32_t)__ffsll((long long)cb) - 1u : nwalk - 1u;
+        if (tid == 0) s_reach = s_le[lim];
+    }
+    __syncthreads();
+    {
+        const uint32_t reach = s_reach;
         // (sharded: what is located must not depend on this rank's own slots -- a rank with short slots about objects, a
         // rank whose shard is empty or has no index (C.T == 0) finds no occurrence: tie_by_index then looks at nothing --
         // but it names the same levels, so that the epoch and the keys k_pool_sel_dp makes are the same on every rank)
-        if (dpkey || (C.T != 0 && gap == 0)) {
-            // every level the walk can reach that lacks an order -- and, while the round of sixteen waves has room, the
-            // next ones below (the same latency now, a clean level when the walk gets there)
-            const uint32_t scan_end = min(n, reach + 48u);
-            for (uint32_t i = 0; i < scan_end; i = s_le[i]) {
-                if (!s_dirty[i]) continue;
-                const uint32_t size = s_le[i] - i;
-                if (i >= reach && nl + size > 16u) break;
-                if (nl + size > (uint32_t)TIE_CAP) break;  // (this level does not fit: the walk stops before it)
-                for (uint32_t j = i; j < i + size; j++) {
-                    s_tied[2 * nl] = (int32_t)(b_xy[j] >> 16);
-                    s_tied[2 * nl + 1] = (int32_t)(b_xy[j] & 0xFFFFu);
-                    s_lidx[nl] = j;
-                    nl++;
-                }
-            }
+        const bool locate = dpkey || (C.T != 0 && gap == 0);
+        // every level the walk can reach that lacks an order -- and, while the round of sixteen waves has room, the next
+        // ones below (the same latency now, a clean level when the walk gets there).  Going down the levels that start
+        // before scan_end: a level that lacks an order is taken whole, until one does not fit -- below `reach` the round
+        // of sixteen, anywhere TIE_CAP -- and nothing after that one.  With P = the entries of such levels before a level,
+        // the first level that does not fit is the first with P + size over its limit: a prefix sum, no walk.
+        const uint32_t scan_end = min(n, reach + 48u);
+        const bool cons = locate && tid < n && s_ls[tid] < scan_end && s_dirty[tid] != 0;
+        const uint32_t one = cons ? 1u : 0u;
+        const uint32_t inc = wave_iscan_add(one);
+        if (tid < PL_CAP && lane_id() == 63) X.wtot[wave_id()] = inc;
+        __syncthreads();
+        uint32_t P = inc - one;
+        if (tid < PL_CAP)
+            for (int v = 0; v < wave_id(); v++) P += X.wtot[v];
+        if (cons && s_ls[tid] == tid) {  // (a level's first entry: P = the entries taken before this level)
+            const uint32_t size = s_le[tid] - tid;
+            if ((tid >= reach && P + size > 16u) || P + size > (uint32_t)TIE_CAP) atomicMin(&X.fv, tid);
         }
-        s_nl = nl;
+        __syncthreads();
+        const bool take = cons && s_ls[tid] < X.fv;
+        if (take) {
+            s_tied[2 * P] = (int32_t)(b_xy[tid] >> 16);
+            s_tied[2 * P + 1] = (int32_t)(b_xy[tid] & 0xFFFFu);
+            s_lidx[P] = tid;
+        }
+        if (tid < PL_CAP) {
+            const unsigned long long tb = __ballot(take);
+            if (lane_id() == 0 && tb) atomicAdd(&X.nl, (uint32_t)__popcll(tb));
+        }
+        __syncthreads();
+        if (tid == 0) s_nl = X.nl;
+        __syncthreads();
     }
-    __syncthreads();
     const uint32_t nl = s_nl;
+    dstamp(12);
     if (dpkey) {
         // ---- sharded: my first occurrences into the payload, the sorted pool into `mid`; k_pool_sel_dp goes on ----------
         const bool objection = nl != 0 && gap != 0;
@@ -655,8 +809,10 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         if (tid < nl) b_key[s_lidx[tid]] = s_pos[tid] != NOPOS ? (epoch << PL_KSH) | s_pos[tid] : 0ull;
         __syncthreads();
     }
+    dstamp(13);
     pool_finish(st, pool, b_xy, b_c, b_key, a_xy, a_c, a_key, s_ls, s_le, s_dirty, s_clash, &s_k, &s_unt, n, kmax, iter, theta,
-                epoch, rebuilt, hint_below, PL_KSH);
+                epoch, rebuilt, hint_below, PL_KSH, X);
+    dstamp(14);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -679,6 +835,7 @@ k_pool_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap, Po
     __shared__ unsigned long long a_key[PL_CAP], b_key[PL_CAP];
     __shared__ uint32_t s_ls[PL_CAP], s_le[PL_CAP], s_dirty[PL_CAP], s_clash[PL_CAP];
     __shared__ uint32_t s_k, s_unt;
+    __shared__ PoolScratch X;
     const uint32_t tid = threadIdx.x;
     const uint32_t status = st->status;
     if (key[0] < 0 && status == 0) {  // some rank failed: every rank stops at this merge
@@ -708,10 +865,9 @@ k_pool_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap, Po
         }
         __syncthreads();
     }
-    pool_level_bounds(b_c, n, s_ls, s_le);
-    __syncthreads();
+    pool_level_bounds(b_c, n, s_ls, s_le, X);
     pool_finish(st, pool, b_xy, b_c, b_key, a_xy, a_c, a_key, s_ls, s_le, s_dirty, s_clash, &s_k, &s_unt, n, min(kcap, nm - iter),
-                iter, theta, epoch, rebuilt, hint_below, PL_KSH_DP);
+                iter, theta, epoch, rebuilt, hint_below, PL_KSH_DP, X);
 }
 
 }  // namespace BPE_G

@@ -36,7 +36,10 @@
 namespace bpe {
 namespace BPE_G {
 
-constexpr uint32_t STEP_PUB_WORDS = 32;  // the published line: [0] = K | brep << 8 | ran << 16 | noop << 17, [1] = z0, [2 + p] = a_p << 16 | b_p
+// the published line: [0] = K | brep << 8 | ran << 16 | noop << 17 | next hint << 18 | defer << 19 | mode << 21, [1] = 256 + merges done so far
+// (= the batch's first new id), [2 + p] = a_p << 16 | b_p, [17 + p] = the count of pair p
+constexpr uint32_t STEP_PUB_WORDS = 32;
+static_assert(2 + 2 * CH_KSWEEP == STEP_PUB_WORDS, "the line holds the pairs and their counts");
 
 union StepLds {
     PoolLds p;
@@ -71,25 +74,36 @@ __device__ __forceinline__ bool step_grid_barrier(uint32_t *ctr, uint32_t target
 __global__ void __launch_bounds__(LEAN_MT)
 k_step(StepArgs S) {
     __shared__ StepLds U;
-    __shared__ uint32_t s_b[STEP_PUB_WORDS];
+    __shared__ uint32_t s_b[STEP_PUB_WORDS], s_adj[CH_KMAX];
     __shared__ uint32_t s_flag;
     DevState *st = S.st;
     const uint32_t tid = threadIdx.x;
+    // (debug, BPE_STEP_STAMPS: the 100 MHz clock at the phase boundaries of workgroups 0, gm / 2 and the last one)
+    const int swho = blockIdx.x == 0 ? 0 : (blockIdx.x == S.gm / 2 ? 1 : (blockIdx.x == gridDim.x - 1 ? 2 : -1));
+    auto stamp = [&](int i) {
+        if (S.stamps && tid == 0 && swho >= 0) S.stamps[(((size_t)(S.step % STEP_STAMP_RING)) * 3 + (size_t)swho) * 16 + (size_t)i] = wall_clock64();
+    };
+    unsigned long long *const dbg = (S.stamps && swho >= 0) ? S.stamps + (((size_t)(S.step % STEP_STAMP_RING)) * 3 + (size_t)swho) * 16 : nullptr;
+    stamp(0);
     // ================= S: the selection (workgroup 0 decides, 1 .. nscan scan rows when told to) ==========================
     if (blockIdx.x == 0) {
         pool_sel_body(S.rowmax, S.mat, S.stride, st, S.ref, S.C, S.dbits, S.res, S.tag, S.req, S.kcap, S.pool, S.gather,
-                      S.hint_below, nullptr, 0ull, S.pool + PL_CAP, U.p, 0u, 1u + S.nscan);
+                      S.hint_below, nullptr, 0ull, S.pool + PL_CAP, U.p, 0u, 1u + S.nscan, dbg);
         __builtin_amdgcn_s_waitcnt(0);  // (the adj words it zeroed are in memory before anybody is told to add to them)
         __syncthreads();
+        stamp(1);
         if (tid < STEP_PUB_WORDS) {
             // (what thread 0 of this workgroup left in st: the same addresses read back through the same L2)
             const uint32_t status = st->status, defer = st->defer;
             const uint32_t noop = (status || defer) ? 1u : 0u;
             const uint32_t K = noop ? 0u : min(st->bk, (uint32_t)CH_KSWEEP);
             uint32_t v = 0;
-            if (tid == 0) v = K | (st->brep << 8) | ((st->sel_ran ? 1u : 0u) << 16) | (noop << 17);
-            else if (tid == 1) v = st->bz0;
+            if (tid == 0)
+                v = K | (st->brep << 8) | ((st->sel_ran ? 1u : 0u) << 16) | (noop << 17) | ((st->pool_hint_next ? 1u : 0u) << 18) |
+                    ((defer & 3u) << 19) | ((st->sel_mode & 1u) << 21);
+            else if (tid == 1) v = 256u + st->iter;
             else if (tid - 2 < K) v = ((uint32_t)st->ba[tid - 2] << 16) | ((uint32_t)st->bb[tid - 2] & 0xFFFFu);
+            else if (tid >= 2 + CH_KSWEEP && tid - (2 + CH_KSWEEP) < K) v = st->bcnt[tid - (2 + CH_KSWEEP)];
             s_b[tid] = v;
             granule_put(S.pub + tid, S.tag, v);
         }
@@ -113,6 +127,9 @@ k_step(StepArgs S) {
         if (tid < STEP_PUB_WORDS) s_b[tid] = tid == 0 ? (1u << 17) : 0u;
     }
     __syncthreads();
+    stamp(2);
+    if (S.stamps && tid == 0 && blockIdx.x < 256)
+        S.stamps[(size_t)STEP_STAMP_RING * 3 * 16 + ((size_t)(S.step % STEP_STAMP_RING) * 256 + blockIdx.x) * 2] = wall_clock64();
     const uint32_t K = s_b[0] & 0xFFu, brep = (s_b[0] >> 8) & 0xFFu, ran = (s_b[0] >> 16) & 1u, z0 = s_b[1];
     const bool sel_noop = ((s_b[0] >> 17) & 1u) != 0 || K == 0;
     // ================= M: the merge pass =======================================================================================
@@ -126,27 +143,106 @@ k_step(StepArgs S) {
             if (tid == 0) L.s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
         }
         __syncthreads();
-        merge_chain_body(S.A, S.idx_dirty, S.use_index, L, K, z0, brep, blockIdx.x, S.gm);
+        merge_chain_body(S.A, S.idx_dirty, S.use_index, L, K, z0, brep, blockIdx.x, S.gm, blockIdx.x == 0 ? nullptr : dbg);
     }
     // ================= B: every delta word, staged header and flag of this step is in memory ==================================
+    stamp(3);
+    // (debug: when every workgroup got the line and when it reached the barrier -- who is the last one?)
+    if (S.stamps && tid == 0 && blockIdx.x < 256) {
+        unsigned long long *all = S.stamps + (size_t)STEP_STAMP_RING * 3 * 16 + ((size_t)(S.step % STEP_STAMP_RING) * 256 + blockIdx.x) * 2;
+        all[1] = wall_clock64();
+    }
     const bool arrived = step_grid_barrier(S.bar, S.bar_target, &s_flag);
+    stamp(4);
     if (!arrived && tid == 0) atomicExch(&st->status, ST_LOOKBACK);
     // ================= A: the table update ====================================================================================
-    const uint32_t status = arrived ? ld_agent(&st->status) : (uint32_t)ST_LOOKBACK, defer = st->defer;
-    const bool noop = status || defer || K == 0;
+    const uint32_t status = arrived ? ld_agent(&st->status) : (uint32_t)ST_LOOKBACK;
+    const bool noop = status || ((s_b[0] >> 19) & 3u) || K == 0;  // (defer: from the line)
     if (!noop) {
-        apply_chain_tokens<true>(blockIdx.x * (uint32_t)LEAN_MT + tid, S.mat, S.stride, S.delta, S.dl, S.rowmax, st, S.dbits, S.sums,
-                                 nullptr, 0u, nullptr, K, z0, ran, s_b + 2, brep);
+        // a token per thread, 64 tokens per wave, dealt over ALL workgroups (a wave or two each: the update is a chain of
+        // round trips per wave, not a matter of bandwidth)
+        const uint32_t nwv4 = (((z0 + K - 1u) >> 8) + 1u) * 4u;  // waves of tokens, in blocks of 256 tokens
+        const uint32_t wpw = (nwv4 + gridDim.x - 1u) / gridDim.x;
+        const uint32_t tw = blockIdx.x * wpw + (uint32_t)wave_id();
+        // (the adj counts: device atomics of this launch's merge pass -- agent-scope loads, into LDS for everybody)
+        if (tid < CH_KMAX) s_adj[tid] = K == 1 ? (tid == 0 ? ld_agent(&st->adj) : 0u) : (tid < K ? ld_agent(&st->badj[tid]) : 0u);
+        __syncthreads();
+        if ((uint32_t)wave_id() < wpw && tw < nwv4)
+            apply_chain_tokens<true>(tw * 64u + (uint32_t)lane_id(), S.mat, S.stride, S.delta, S.dl, S.rowmax, S.dbits, S.sums,
+                                     nullptr, 0u, nullptr, K, z0, ran, s_b + 2, s_adj, brep);
     } else if (ran && arrived) {  // (nothing merged, but the selection did re-scan the flagged rows: nobody sets a flag in this phase)
         for (uint32_t i = blockIdx.x * (uint32_t)LEAN_MT + tid; i < (uint32_t)DBITS_WORDS; i += gridDim.x * (uint32_t)LEAN_MT) S.dbits[i] = 0;
     }
-    // (the records by the workgroup that selected: the batch, its counts, the next hint are its own writes)
-    if (blockIdx.x == 0 && tid < 64) {
-        apply_chain_records(st, S.par, S.rec, S.srec, S.step, S.removed, K, noop, status, defer, 0u);
-        if (tid == 0 && arrived) st->sel_ran = 0;
+    stamp(5);
+    // ---- the step's records.  To the HOST (pinned memory, PCIe round trips: ~5 us) by the last workgroup, which has no
+    // tokens to update in a full-size grid -- everything it writes it has from the line.  The state words in st by workgroup
+    // 0 alone: it wrote their neighbours during the selection, and one line of st must not sit dirty in two L2s.
+    if ((blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && wave_id() == 0) {
+        const uint32_t lane = (uint32_t)lane_id();
+        const uint32_t defer2 = (s_b[0] >> 19) & 3u, mode_used = (s_b[0] >> 21) & 1u, hint_next = (s_b[0] >> 18) & 1u;
+        // ids removed by the merge pass: CH_RMV counters per pair (lane l: counters 4l .. 4l + 3, all of pair l / 4), read at
+        // agent scope (device atomics of this launch) -- or, an unweighted stream, nobody counted: a merge of a != b removes
+        // exactly as many ids as the pair counts (base.py:25-41)
+        uint32_t v = 0;
+        if (S.removed) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) v += ld_agent(&S.removed[(lane * 4 + i) * REMOVED_STRIDE]);
+        }
+        static_assert(CH_RMV == 16, "lanes 4p .. 4p + 3 hold the removals of pair p");
+        v += (uint32_t)__shfl_xor((int)v, 1);
+        v += (uint32_t)__shfl_xor((int)v, 2);
+        uint32_t rem[CH_KMAX];
+#pragma unroll
+        for (int p = 0; p < CH_KMAX; p++) rem[p] = (uint32_t)__shfl((int)v, 4 * p);
+        if (K == 1) {  // (a pair merged alone spreads over all the counters)
+            uint32_t tot = 0;
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) tot += rem[p];
+            rem[0] = tot;
+        }
+        if (!S.removed) {
+#pragma unroll
+            for (int p = 0; p < CH_KMAX; p++) rem[p] = p < CH_KSWEEP ? s_b[2 + CH_KSWEEP + p] : 0u;
+        }
+        const uint32_t iter = z0 - 256u;
+        unsigned long long nn = st->n[S.par];  // (an earlier launch's: workgroup 0 writes the OTHER parity below)
+        if (!noop)
+            for (uint32_t p = 0; p < K; p++) nn -= rem[p];
+        if (blockIdx.x == 0) {
+            if (S.removed && lane < 64) {  // (only now: the last workgroup reads the counters from memory, where they still stand)
+#pragma unroll
+                for (int i = 0; i < 4; i++) S.removed[(lane * 4 + i) * REMOVED_STRIDE] = 0;
+            }
+            if (lane == 0) {
+                if (!noop) st->iter = iter + K;
+                if (status == 0) st->n[S.par ^ 1] = nn;  // (a step that merged nothing carries the length forward)
+                st->removed = 0;
+                st->pool_hint = hint_next;  // (k_pool.hip: what this step's selection announced for the next one)
+                if (arrived) st->sel_ran = 0;
+            }
+        }
+        if (blockIdx.x == gridDim.x - 1 && lane == 0) {
+            if (!noop) {
+                unsigned long long m = st->n[S.par];
+                for (uint32_t p = 0; p < K; p++) {
+                    m -= rem[p];
+                    iter_rec_put(S.rec + iter + p, (int32_t)(s_b[2 + p] >> 16), (int32_t)(s_b[2 + p] & 0xFFFFu), s_b[2 + CH_KSWEEP + p], ST_OK, m);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                for (uint32_t p = 0; p < K; p++) iter_rec_seal(S.rec + iter + p, (unsigned long long)(iter + p) + 1);
+                __builtin_amdgcn_s_waitcnt(0);  // (the step record below tells the host that these are final)
+            }
+            StepRec *sr = S.srec + (S.step % STEP_RING);
+            // (pad: the step's mode | defer << 8 -- 1 = a == b heads the pool, 2 = a tie the step could not settle)
+            step_rec_put(sr, iter, noop ? 0u : K, (status == 0 && defer2) ? (uint32_t)ST_DEFER : status, mode_used | (defer2 << 8), nn);
+            __builtin_amdgcn_s_waitcnt(0);
+            step_rec_seal(sr, (unsigned long long)S.step + 1);
+        }
     }
+    stamp(6);
     if (noop) return;
     apply_chain_commit(blockIdx.x * (uint32_t)LEAN_MT + tid, gridDim.x * (uint32_t)LEAN_MT, S.nwords, S.smask, S.stage, S.hdr_cur);
+    stamp(7);
 }
 
 }  // namespace BPE_G

@@ -391,8 +391,11 @@ CHAIN_OPTIONS = [
     (("small_slots", 0),), (("small_slots", 2),),    # 1024-id slots throughout / 256-id slots from the first index build
     (("small_slots", 2), ("pool", 0)), (("small_slots", 2), ("chain_kcap", 2), ("pool_hint", 64)),
     (("chain_scan", 1),), (("chain_scan", 127),),    # one / 127 scanning workgroups in a pool rebuild
-    (("fuse_step", 0),), (("fuse_step", 0), ("chain_kcap", 4)),   # a step as three launches (k_pool_sel, k_merge_chain, k_apply_chain) instead of one (k_step)
-    (("lean_grid", 8),), (("lean_grid", 70),),       # the one-launch step on a grid of 8 / 70 workgroups (its phases deal the work by the grid)
+    # a step as ONE launch (k_step: selection -> published batch -> merge pass -> grid barrier -> table update) instead of three
+    (("fuse_step", 1),), (("fuse_step", 1), ("chain_kcap", 4)), (("fuse_step", 1), ("count_is_removed", 0)),
+    (("fuse_step", 1), ("small_slots", 2)), (("fuse_step", 1), ("small_slots", 0)),
+    (("fuse_step", 1), ("lean_grid", 8)), (("fuse_step", 1), ("lean_grid", 70)),   # ... on a grid of 8 / 70 workgroups (its phases deal the work by the grid)
+    (("lean_grid", 8),),
 ]
 
 
@@ -414,7 +417,7 @@ def test_chain_step_options_cross_check(engine, native, kind, opts):
         nm = 400
     exp = oracle.train(data, nm, offs, raise_on_empty=False)
     defaults = {"pool": 1, "chain_levels": 0, "chain_list": 1, "chain_kcap": 15, "count_is_removed": 1, "chain_prefetch": 1,
-                "small_slots": 1, "pool_hint": 0, "chain_scan": 63, "fuse_step": 1, "lean_grid": 256}
+                "small_slots": 1, "pool_hint": 0, "chain_scan": 63, "fuse_step": 0, "lean_grid": 256}
     set_variant(engine, 1, 0, 2, 2, 7)
     try:
         for k, v in opts:
@@ -430,10 +433,10 @@ def test_chain_step_options_cross_check(engine, native, kind, opts):
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2], opts
         assert st["steps"] > 0
         # the step is ONE launch (k_step.hip) wherever its selection is the pool and the option stands
-        if ("pool", 0) in opts or ("fuse_step", 0) in opts:
-            assert st["fused_steps"] == 0
-        else:
+        if ("fuse_step", 1) in opts:
             assert st["fused_steps"] > 0
+        else:
+            assert st["fused_steps"] == 0
         if ("small_slots", 2) in opts and st["index_builds"]:
             assert st["slot_ids"] == 256
         if ("small_slots", 0) in opts:
