@@ -73,6 +73,11 @@ void bpe_destroy(bpe_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_srec) (void)hipHostFree(c->h_srec);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (hipEvent_t ev : c->ev_stage)
+        if (ev) (void)hipEventDestroy(ev);
+    for (void *p : {(void *)c->d_step_pub, (void *)c->d_step_bar, (void *)c->d_step_stamps})
+        if (p) (void)hipFree(p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -177,6 +182,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_kcap = (int)value;
     } else if (!strcmp(name, "pool")) {
         c->pool = value != 0;
+    } else if (!strcmp(name, "pinned_upload")) {
+        if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "pinned_upload must be 0 or 1");
+        c->pinned_upload = (int)value;
     } else if (!strcmp(name, "fuse_step")) {
         if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "fuse_step must be 0 or 1");
         c->fuse_step = (int)value;
@@ -248,7 +256,7 @@ static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const u
         TRY(dev_realloc(c, c->d_bytes, (size_t)n + 16));
         c->cap_bytes = n + 16;
     }
-    if (n) HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, hipMemcpyHostToDevice, c->stream));
+    if (n) TRY(upload_h2d(c, c->d_bytes, bytes, n));
     static const uint64_t zero = 0;
     if (!chunk_offsets) {
         chunk_offsets = &zero;
@@ -258,16 +266,14 @@ static int load_bytes_impl(bpe_ctx *c, const uint8_t *bytes, uint64_t n, const u
         TRY(dev_realloc(c, c->d_offsets, (size_t)n_chunks));
         c->cap_offsets = n_chunks;
     }
-    if (n_chunks)
-        HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
-                                 hipMemcpyHostToDevice, c->stream));
+    if (n_chunks) TRY(upload_h2d(c, c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t)));
     c->weighted = false;
     if (wexp && n_chunks) {
         if (n_chunks > c->cap_wexp) {
             TRY(dev_realloc(c, c->d_wexp, (size_t)n_chunks));
             c->cap_wexp = n_chunks;
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_wexp, wexp, n_chunks, hipMemcpyHostToDevice, c->stream));
+        TRY(upload_h2d(c, c->d_wexp, wexp, n_chunks));
         c->weighted = true;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may free its buffers on return

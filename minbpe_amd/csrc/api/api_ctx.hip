@@ -136,6 +136,11 @@ struct bpe_ctx {
     unsigned long long *d_step_pub = nullptr; // ... its published line (STEP_PUB_WORDS granules)
     uint32_t *d_step_bar = nullptr;           // ... its grid-barrier counter (only ever grows; zeroed when a train() begins)
     uint32_t step_bar_target = 0;             // ... and what it will read once every launch enqueued so far is through its barrier
+    // host -> device uploads of large caller buffers (upload_h2d below): a ring of pinned staging buffers filled by several
+    // host threads while the copy engine drains the ones before (option "pinned_upload": 0 = plain hipMemcpyAsync)
+    int pinned_upload = 1;
+    uint8_t *h_stage = nullptr;
+    hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
     uint64_t n_fused = 0;                     // chain steps of the last train() that were one launch
     unsigned long long *d_step_stamps = nullptr;  // debug (env BPE_STEP_STAMPS=file): clock stamps of its phases, dumped when train() ends
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
@@ -1341,6 +1346,123 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     c->rows_pending = true;
     c->n_steps++;
     if (use_index) c->n_sparse++; else c->n_dense++;
+    return BPE_OK;
+}
+
+// A large buffer of the caller's (pageable memory) to the device.  hipMemcpy from pageable memory stages through the
+// runtime's own pinned buffer with ONE host thread: 0.07 - 0.57 s per GB depending on the box (profiles/r5_notes.md) --
+// for the 1 GB headline input (1 GB of text + 1.4 GB of chunk offsets) a fifth of a train() call.  Here STAGE_T host
+// threads copy piece i into pinned buffer i % STAGE_R (each its slice) while the copy engine drains the pieces before:
+// the upload runs at min(host memory bandwidth, PCIe).  The copy is complete on the stream when the call returns
+// BPE_OK only in the sense of hipMemcpyAsync: the caller synchronises the stream (load_bytes_impl does).
+constexpr size_t STAGE_PIECE = 32u << 20;
+constexpr int STAGE_R = 4, STAGE_T_MAX = 16;
+int upload_h2d(bpe_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return BPE_OK;
+    if (!c->pinned_upload || bytes < 2 * STAGE_PIECE) {
+        HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return BPE_OK;
+    }
+    if (!c->h_stage) {
+        if (hipHostMalloc((void **)&c->h_stage, STAGE_PIECE * STAGE_R, hipHostMallocDefault) != hipSuccess) {
+            c->h_stage = nullptr;
+            (void)hipGetLastError();
+            HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));  // (no pinned memory to be had: the plain path)
+            return BPE_OK;
+        }
+        for (int r = 0; r < STAGE_R; r++) HIPCHK(c, hipEventCreateWithFlags(&c->ev_stage[r], hipEventDisableTiming));
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int T = (int)std::max(1u, std::min((unsigned)STAGE_T_MAX, hw / 2));
+    const size_t pieces = (bytes + STAGE_PIECE - 1) / STAGE_PIECE;
+    std::atomic<long long> go{-1};
+    std::atomic<unsigned long long> done{0};
+    const uint8_t *s8 = static_cast<const uint8_t *>(src);
+    uint8_t *stage = c->h_stage;
+    auto worker = [&](int w) {
+        for (size_t i = 0; i < pieces; i++) {
+            while (go.load(std::memory_order_acquire) < (long long)i) std::this_thread::yield();
+            const size_t len = std::min(STAGE_PIECE, bytes - i * STAGE_PIECE);
+            const size_t per = (len + (size_t)T - 1) / (size_t)T, lo = std::min(len, per * (size_t)w), hi = std::min(len, lo + per);
+            if (hi > lo) memcpy(stage + (i % STAGE_R) * STAGE_PIECE + lo, s8 + i * STAGE_PIECE + lo, hi - lo);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T);
+    for (int w = 1; w < T; w++) pool.emplace_back(worker, w);
+    int rc = BPE_OK;
+    hipError_t err = hipSuccess;
+    for (size_t i = 0; i < pieces; i++) {
+        // (the buffer's previous piece has left it; on an error the workers are still let through every piece, so that they end)
+        if (i >= (size_t)STAGE_R && err == hipSuccess) err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);
+        go.store((long long)i, std::memory_order_release);
+        {   // the calling thread is worker 0
+            const size_t len = std::min(STAGE_PIECE, bytes - i * STAGE_PIECE);
+            const size_t per = (len + (size_t)T - 1) / (size_t)T, hi = std::min(len, per);
+            if (hi) memcpy(stage + (i % STAGE_R) * STAGE_PIECE, s8 + i * STAGE_PIECE, hi);
+            done.fetch_add(1, std::memory_order_release);
+        }
+        while (done.load(std::memory_order_acquire) < (unsigned long long)T * (i + 1)) std::this_thread::yield();
+        if (err == hipSuccess) {
+            const size_t len = std::min(STAGE_PIECE, bytes - i * STAGE_PIECE);
+            err = hipMemcpyAsync(static_cast<uint8_t *>(dst) + i * STAGE_PIECE, stage + (i % STAGE_R) * STAGE_PIECE, len,
+                                 hipMemcpyHostToDevice, c->stream);
+            if (err == hipSuccess) err = hipEventRecord(c->ev_stage[i % STAGE_R], c->stream);
+        }
+    }
+    for (std::thread &t : pool) t.join();
+    if (err != hipSuccess) rc = fail(c, BPE_E_HIP, "pinned upload: %s", hipGetErrorString(err));
+    return rc;
+}
+
+// ... and the way back: the copy engine fills pinned buffer i % STAGE_R with piece i (up to STAGE_R pieces ahead) while
+// the host threads copy the pieces before out into the caller's (pageable) buffer.  Returns with the data in dst.
+int download_d2h(bpe_ctx *c, void *dst, const void *src_dev, size_t bytes) {
+    if (!bytes) return BPE_OK;
+    if (!c->pinned_upload || bytes < 2 * STAGE_PIECE || !c->h_stage) {  // (the ring exists once an upload has used it)
+        HIPCHK(c, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return BPE_OK;
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const int T = (int)std::max(1u, std::min((unsigned)STAGE_T_MAX, hw / 2));
+    const size_t pieces = (bytes + STAGE_PIECE - 1) / STAGE_PIECE;
+    std::atomic<long long> go{-1};
+    std::atomic<unsigned long long> done{0};
+    uint8_t *d8 = static_cast<uint8_t *>(dst);
+    const uint8_t *stage = c->h_stage;
+    auto copy_out = [&](size_t i, int w) {
+        const size_t len = std::min(STAGE_PIECE, bytes - i * STAGE_PIECE);
+        const size_t per = (len + (size_t)T - 1) / (size_t)T, lo = std::min(len, per * (size_t)w), hi = std::min(len, lo + per);
+        if (hi > lo) memcpy(d8 + i * STAGE_PIECE + lo, stage + (i % STAGE_R) * STAGE_PIECE + lo, hi - lo);
+        done.fetch_add(1, std::memory_order_release);
+    };
+    auto worker = [&](int w) {
+        for (size_t i = 0; i < pieces; i++) {
+            while (go.load(std::memory_order_acquire) < (long long)i) std::this_thread::yield();
+            copy_out(i, w);
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T);
+    for (int w = 1; w < T; w++) pool.emplace_back(worker, w);
+    hipError_t err = hipSuccess;
+    size_t issued = 0;
+    for (size_t i = 0; i < pieces; i++) {
+        for (; issued < pieces && issued < i + (size_t)STAGE_R && err == hipSuccess; issued++) {  // (pieces before i are out of their buffers)
+            const size_t len = std::min(STAGE_PIECE, bytes - issued * STAGE_PIECE);
+            err = hipMemcpyAsync(c->h_stage + (issued % STAGE_R) * STAGE_PIECE, static_cast<const uint8_t *>(src_dev) + issued * STAGE_PIECE,
+                                 len, hipMemcpyDeviceToHost, c->stream);
+            if (err == hipSuccess) err = hipEventRecord(c->ev_stage[issued % STAGE_R], c->stream);
+        }
+        if (err == hipSuccess) err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);
+        go.store((long long)i, std::memory_order_release);  // (on an error the workers still run through every piece, so that they end)
+        copy_out(i, 0);
+        while (done.load(std::memory_order_acquire) < (unsigned long long)T * (i + 1)) std::this_thread::yield();
+    }
+    for (std::thread &t : pool) t.join();
+    if (err != hipSuccess) return fail(c, BPE_E_HIP, "pinned download: %s", hipGetErrorString(err));
     return BPE_OK;
 }
 

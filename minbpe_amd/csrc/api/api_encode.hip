@@ -12,9 +12,7 @@ int upload_offsets(bpe_ctx *c, const uint64_t *chunk_offsets, uint64_t n_chunks)
         TRY(dev_realloc(c, c->d_offsets, (size_t)n_chunks));
         c->cap_offsets = n_chunks;
     }
-    if (n_chunks)
-        HIPCHK(c, hipMemcpyAsync(c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t),
-                                 hipMemcpyHostToDevice, c->stream));
+    if (n_chunks) TRY(upload_h2d(c, c->d_offsets, chunk_offsets, n_chunks * sizeof(uint64_t)));
     return BPE_OK;
 }
 }  // namespace
@@ -115,7 +113,8 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
         c->cap_bytes = n + 16;
     }
     // (the bytes are copied either way: the kernels read up to 16 bytes past the end of the ctx's padded buffer)
-    HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    if (resident) HIPCHK(c, hipMemcpyAsync(c->d_bytes, bytes, n, hipMemcpyDeviceToDevice, c->stream));
+    else TRY(upload_h2d(c, c->d_bytes, bytes, n));  // (pinned staging ring, several host threads: api_ctx.hip)
     if (!resident) TRY(upload_offsets(c, chunk_offsets, n_chunks));
     const uint64_t *d_offs = resident ? chunk_offsets : c->d_offsets;
     // 3. scratch
@@ -327,10 +326,9 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
         hipLaunchKernelGGL(k_store_u64, dim3(1), dim3(1), 0, c->stream, out_offsets + n_chunks, total);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     } else {
-        if (ids_out && total)
-            HIPCHK(c, hipMemcpy(ids_out, c->d_enc_out, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (ids_out && total) TRY(download_d2h(c, ids_out, c->d_enc_out, total * sizeof(int32_t)));
         if (out_offsets) {
-            HIPCHK(c, hipMemcpy(out_offsets, c->d_enc_off, n_chunks * 8, hipMemcpyDeviceToHost));
+            TRY(download_d2h(c, out_offsets, c->d_enc_off, n_chunks * 8));
             out_offsets[n_chunks] = total;
         }
     }

@@ -17,6 +17,8 @@
 #include <chrono>
 #include <deque>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <vector>
 
 #include "bpe_hip.h"
