@@ -131,7 +131,8 @@ def parity_report(name, wl, data_sha, offs, res):
         bad = first_divergence(got, g["digests"])
         checked = [c for c, _ in got if c in {c2 for c2, _ in g["digests"]}]
         n_ok = max(checked) if checked else 0
-        kind = "weighted oracle on the distinct chunks" if g.get("weighted") else "oracle"
+        kind = ("weighted oracle on the distinct chunks" if g.get("weighted") else
+                "incremental exact trainer, pinned to the plain oracle" if g.get("fast") else "oracle")
         rep.setdefault("goldens", []).append(
             {"entry": f"tests/golden/big_golden.json[{gname}] ({kind}, {g['done']} merges)",
              "merges_checked": n_ok, "equal": bool(checked) and bad is None})
