@@ -76,7 +76,7 @@ void bpe_destroy(bpe_ctx *c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (hipEvent_t ev : c->ev_stage)
         if (ev) (void)hipEventDestroy(ev);
-    for (void *p : {(void *)c->d_step_pub, (void *)c->d_step_bar, (void *)c->d_step_stamps})
+    for (void *p : {(void *)c->d_step_pub, (void *)c->d_step_bar, (void *)c->d_step_stamps, (void *)c->d_forced})
         if (p) (void)hipFree(p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -182,6 +182,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_kcap = (int)value;
     } else if (!strcmp(name, "pool")) {
         c->pool = value != 0;
+    } else if (!strcmp(name, "enc_replay")) {
+        if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "enc_replay must be 0 or 1");
+        c->enc_replay = (int)value;
     } else if (!strcmp(name, "pinned_upload")) {
         if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "pinned_upload must be 0 or 1");
         c->pinned_upload = (int)value;

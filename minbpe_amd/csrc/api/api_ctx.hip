@@ -136,11 +136,18 @@ struct bpe_ctx {
     unsigned long long *d_step_pub = nullptr; // ... its published line (STEP_PUB_WORDS granules)
     uint32_t *d_step_bar = nullptr;           // ... its grid-barrier counter (only ever grows; zeroed when a train() begins)
     uint32_t step_bar_target = 0;             // ... and what it will read once every launch enqueued so far is through its barrier
+    // encode as a replay of training (api_encode.hip): the loop's selections are the merges of d_forced, in order
+    bool forced = false;
+    int32_t *d_forced = nullptr;
+    uint64_t cap_forced = 0;
+    int enc_replay = 1;                       // option "enc_replay": one giant chunk (BasicTokenizer.encode) is encoded by replaying its merge
+                                              // list through the training engine (0: the stream-wide rounds)
     // host -> device uploads of large caller buffers (upload_h2d below): a ring of pinned staging buffers filled by several
     // host threads while the copy engine drains the ones before (option "pinned_upload": 0 = plain hipMemcpyAsync)
     int pinned_upload = 1;
     uint8_t *h_stage = nullptr;
     hipEvent_t ev_stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool stage_busy[4] = {false, false, false, false};  // a copy out of / into the buffer was enqueued: wait for its event before the buffer is touched again
     uint64_t n_fused = 0;                     // chain steps of the last train() that were one launch
     unsigned long long *d_step_stamps = nullptr;  // debug (env BPE_STEP_STAMPS=file): clock stamps of its phases, dumped when train() ends
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
@@ -592,6 +599,26 @@ inline bool aa_through_index(const bpe_ctx *c) { return c->aa_sparse && c->idx_l
 // this rank's candidate)
 int launch_select(bpe_ctx *c, bool rowmax_all, bool sparse_next = false) {
     TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
+    if (c->forced) {  // (encode as a replay of training: the pair is given; a sparse pass's candidate list as in the sharded loop)
+        hipLaunchKernelGGL(GK(c, k_forced_pair), dim3(1), dim3(1), 0, c->stream, c->d_st, c->d_forced, (uint32_t)c->prof_iter,
+                           c->d_mat, c->vcap);
+        LAUNCHCHK(c, "k_forced_pair");
+        if (sparse_next && c->slotted && c->slot2) {
+            CandArgs C;
+            C.idx = c->d_idx;
+            C.dirty = c->d_idx_dirty;
+            C.cand = c->d_cand;
+            C.stride = (uint32_t)c->idx_cap_words;
+            C.T = (uint32_t)c->slot_T;
+            C.enable = 1;
+            C.tie_index = C.tie_window = 0;
+            C.aa = aa_through_index(c) ? 1u : 0u;
+            hipLaunchKernelGGL(GK(c, k_dp_cand), dim3(1), dim3(1024), 0, c->stream, c->d_st, C);
+            LAUNCHCHK(c, "k_dp_cand");
+        }
+        TRY(prof_end(c));
+        return BPE_OK;
+    }
     if (rowmax_all) {
         hipLaunchKernelGGL(k_rowmax_all, dim3(c->vcur), dim3(256), 0, c->stream, c->d_mat, c->vcap,
                            c->vcur, c->d_rowmax);
@@ -1141,7 +1168,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, zhi);
     // one launch for the whole step (k_step.hip) where there is nothing between its parts: a single-GPU job's sparse steps
-    const bool fused = c->fuse_step && c->pool && !dense && !c->dp_comm && use_index && c->idx_live;
+    const bool fused = c->fuse_step && c->pool && !c->forced && !dense && !c->dp_comm && use_index && c->idx_live;
     if (!fused) TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     CandArgs C;
     C.idx = c->d_idx;
@@ -1266,7 +1293,9 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         c->n_sparse++;
         return BPE_OK;
     }
-    if (c->pool)
+    if (c->forced)
+        hipLaunchKernelGGL(GK(c, k_forced_sel), dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_forced, c->d_mat, c->vcap, kcap);
+    else if (c->pool)
         hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                            kcap, c->d_pool, c->d_pool_gather, hint_below, dp ? c->d_dp_ckey : (long long *)nullptr,
@@ -1394,8 +1423,12 @@ int upload_h2d(bpe_ctx *c, void *dst, const void *src, size_t bytes) {
     int rc = BPE_OK;
     hipError_t err = hipSuccess;
     for (size_t i = 0; i < pieces; i++) {
-        // (the buffer's previous piece has left it; on an error the workers are still let through every piece, so that they end)
-        if (i >= (size_t)STAGE_R && err == hipSuccess) err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);
+        // (the buffer's previous piece has left it -- this call's, or the tail of the call before: a copy is only ENQUEUED
+        // when a call returns; on an error the workers are still let through every piece, so that they end)
+        if (c->stage_busy[i % STAGE_R] && err == hipSuccess) {
+            err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);
+            c->stage_busy[i % STAGE_R] = false;
+        }
         go.store((long long)i, std::memory_order_release);
         {   // the calling thread is worker 0
             const size_t len = std::min(STAGE_PIECE, bytes - i * STAGE_PIECE);
@@ -1409,6 +1442,7 @@ int upload_h2d(bpe_ctx *c, void *dst, const void *src, size_t bytes) {
             err = hipMemcpyAsync(static_cast<uint8_t *>(dst) + i * STAGE_PIECE, stage + (i % STAGE_R) * STAGE_PIECE, len,
                                  hipMemcpyHostToDevice, c->stream);
             if (err == hipSuccess) err = hipEventRecord(c->ev_stage[i % STAGE_R], c->stream);
+            if (err == hipSuccess) c->stage_busy[i % STAGE_R] = true;
         }
     }
     for (std::thread &t : pool) t.join();
@@ -1452,11 +1486,16 @@ int download_d2h(bpe_ctx *c, void *dst, const void *src_dev, size_t bytes) {
     for (size_t i = 0; i < pieces; i++) {
         for (; issued < pieces && issued < i + (size_t)STAGE_R && err == hipSuccess; issued++) {  // (pieces before i are out of their buffers)
             const size_t len = std::min(STAGE_PIECE, bytes - issued * STAGE_PIECE);
+            if (c->stage_busy[issued % STAGE_R]) {  // (an upload before this call may still be reading the buffer)
+                err = hipEventSynchronize(c->ev_stage[issued % STAGE_R]);
+                c->stage_busy[issued % STAGE_R] = false;
+                if (err != hipSuccess) break;
+            }
             err = hipMemcpyAsync(c->h_stage + (issued % STAGE_R) * STAGE_PIECE, static_cast<const uint8_t *>(src_dev) + issued * STAGE_PIECE,
                                  len, hipMemcpyDeviceToHost, c->stream);
             if (err == hipSuccess) err = hipEventRecord(c->ev_stage[issued % STAGE_R], c->stream);
         }
-        if (err == hipSuccess) err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);
+        if (err == hipSuccess) err = hipEventSynchronize(c->ev_stage[i % STAGE_R]);  // (piece i has arrived; nothing is pending on its buffer)
         go.store((long long)i, std::memory_order_release);  // (on an error the workers still run through every piece, so that they end)
         copy_out(i, 0);
         while (done.load(std::memory_order_acquire) < (unsigned long long)T * (i + 1)) std::this_thread::yield();

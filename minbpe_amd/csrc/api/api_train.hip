@@ -299,7 +299,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 } else if (known) {
                     in_chain = false;
                     records_ok = false;
-                    if (lean) {
+                    if (lean && !c->forced) {  // (a replay's selections are given: chain steps or the general path)
                         lean_on = true;
                         // (the selection works from the previous table update's records when that was a lean one
                         // too: nothing else has touched the table or the row maxima since)

@@ -1689,6 +1689,89 @@ __global__ void k_dp_after_sum(DevState *st, const uint32_t *__restrict__ tail) 
     if (tail[8] != 0 && st->status == 0) st->status = ST_INTERNAL;
 }
 
+// ---------------------------------------------------------------------------
+// ENCODE AS A REPLAY OF TRAINING (api_encode.hip: one giant chunk, BasicTokenizer.encode, basic.py:57-74).  The reference's
+// encode merges the lowest-ranked pair present until none is left; a pair created by merge r ranks above r, so
+// that is the merges applied in rank order -- which is what the training loop does with its own selections.  Here the
+// selection is GIVEN: merge r is pairs[r] whatever its count (zero sites: nothing happens), and everything else -- slots,
+// the inverted index, sparse sweeps, batches of token-disjoint pairs in one sweep, the table update that keeps the counts
+// a sparse pass is planned by -- is the training engine's.
+// k_forced_sel: a chain step's batch = the longest run of the next merges with a != b and no shared token (<= kcap).
+__global__ void __launch_bounds__(64)
+k_forced_sel(DevState *st, const int32_t *__restrict__ pairs, const uint32_t *__restrict__ mat, uint32_t stride, uint32_t kcap) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t status = st->status, defer = st->defer, iter = st->iter, nm = st->num_merges;
+    if (status || defer) return;
+    if (iter >= nm) {  // the merge list is used up: this step and the ones behind it do nothing
+        if (lane == 0) st->bk = 0;
+        return;
+    }
+    const uint32_t r = iter + lane;
+    const bool in = lane < kcap && r < nm;
+    const uint32_t a = in ? (uint32_t)pairs[2 * r] : 0xFFFFFFFEu, b = in ? (uint32_t)pairs[2 * r + 1] : 0xFFFFFFFDu;
+    uint32_t bad = in ? (a == b) : 1u;
+#pragma unroll
+    for (int j = 0; j < CH_KSWEEP - 1; j++) {
+        const uint32_t aj = (uint32_t)__shfl((int)a, j), bj = (uint32_t)__shfl((int)b, j);
+        if ((uint32_t)j < lane) bad |= (aj == a) | (aj == b) | (bj == a) | (bj == b);
+    }
+    const unsigned long long bb = __ballot(bad != 0);
+    const uint32_t K = bb ? min(kcap, (uint32_t)__ffsll((long long)bb) - 1u) : kcap;
+    const uint32_t c = lane < K ? mat[(size_t)a * stride + b] : 0u;
+    const uint32_t cmax = wave_umax_dpp(c);
+    __shared__ uint32_t s_pa[CH_KMAX];
+    if (lane < CH_KMAX) s_pa[lane] = a;
+    __syncthreads();
+    const uint32_t hm = chain_hash_find(s_pa, K);
+    if (lane == 0) {
+        st_agent(&st->adj, 0u);
+        st->count = c;
+        st->ntied = 1;
+        st->firstpos = NOPOS;
+        st->sel_tie = 0;
+        st->a = (int32_t)a;
+        st->b = (int32_t)b;
+        st->fin_a = (int32_t)a;
+        st->fin_b = (int32_t)b;
+        st->bk = K;
+        st->bz0 = 256u + iter;
+        st->tl_n = st->tl_skip = 0;
+        st->dp_wait = 0;
+        st->sel_mode = CH_LIST;
+        st->found = K ? 1u : 0u;
+        if (K == 0) st->defer = 1;  // a == b heads the run: the general path's merge
+        st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
+        st->bhm = hm;
+        st->bhm_key = ((256u + iter) << 8) | K;
+        st->pool_n = 0;
+    }
+    if (lane < K) {
+        st->ba[lane] = (int32_t)a;
+        st->bb[lane] = (int32_t)b;
+        st_agent(&st->badj[lane], 0u);
+        st->bcnt[lane] = c;
+    }
+}
+// k_forced_pair: the general path's selection (the first merge, every a == b merge): merge `iter` is pairs[iter]
+__global__ void k_forced_pair(DevState *st, const int32_t *__restrict__ pairs, uint32_t iter, const uint32_t *__restrict__ mat,
+                              uint32_t stride) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->adj = 0;
+    st->chain_n = 0;
+    if (st->status) return;
+    const int32_t a = pairs[2 * iter], b = pairs[2 * iter + 1];
+    st->a = a;
+    st->b = b;
+    st->fin_a = a;
+    st->fin_b = b;
+    st->count = mat[(size_t)(uint32_t)a * stride + (uint32_t)b];
+    st->ntied = 1;
+    st->firstpos = NOPOS;
+    st->sel_tie = 0;
+    st->found = 1;
+    st->ncand = 0;
+}
+
 // host: entering chain steps after general iterations (the device counts the merges from here on)
 __global__ void k_set_iter(DevState *st, uint32_t iter, uint32_t num_merges) {
     st->iter = iter;

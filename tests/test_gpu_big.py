@@ -149,3 +149,29 @@ def test_cross_mode_large_chunked(native, engine):
         engine.set_option("mode", 1)
     assert slow["pairs"] == fast["pairs"]
     assert slow["counts"] == fast["counts"] and slow["lens"] == fast["lens"]
+
+
+@pytest.mark.parametrize("pinned", [1, 0])
+def test_large_buffers_survive_the_staged_copies(engine, native, pinned):
+    """Caller buffers of hundreds of MB go to the device (and ids come back) through a ring of pinned staging buffers filled
+    by several host threads (api_ctx.hip: upload_h2d / download_d2h; option pinned_upload): text and chunk offsets are two
+    uploads back to back (the second must not touch a buffer the first one's tail is still being copied out of), the ids
+    of a batch encode one download -- every byte and every offset must arrive, with the option on and off."""
+    import oracle
+    from minbpe_amd import _native
+    data = native.synth_text(180_000_000, 41)
+    offs = _native.split_offsets(data, 4)
+    assert len(offs) * 8 > 128 << 20  # (both buffers take the ring, several times around)
+    engine.set_option("pinned_upload", pinned)
+    try:
+        engine.load_bytes(data, offs)
+        ids = engine.read_ids()
+        assert len(ids) == len(data) and np.array_equal(ids.astype(np.uint8), np.frombuffer(data, dtype=np.uint8))
+        assert np.array_equal(np.asarray(engine.read_chunk_starts(), dtype=np.uint64), np.asarray(offs, dtype=np.uint64))
+        # one merge list, the whole text as a batch of GPT-4-split chunks: 180 MB up, 1.4 GB of offsets up, ~0.5 GB of ids down
+        pairs = oracle.train_fast(data[:2_000_000], 300, _native.split_offsets(data[:2_000_000], 4))[0]
+        got, got_off = engine.encode_batch(np.array(pairs, np.int32), None, data, offs)
+        exp, exp_off = oracle.encode(pairs, data, offs)
+        assert np.array_equal(got, exp) and np.array_equal(np.asarray(got_off, dtype=np.uint64), np.asarray(exp_off, dtype=np.uint64))
+    finally:
+        engine.set_option("pinned_upload", 1)

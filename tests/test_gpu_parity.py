@@ -351,6 +351,37 @@ def test_encode_batch_vs_oracle(engine, native, kind, cache, bits):
     assert np.array_equal(out_off, exp_off)
 
 
+@pytest.mark.parametrize("kind", ["own_text", "other_text", "letters"])
+def test_encode_one_giant_chunk_is_a_replay_of_training(engine, native, kind):
+    """BasicTokenizer.encode (basic.py:57-74): the whole text is ONE chunk of megabytes.  With a merge list of the shape
+    training makes, the library replays the list through the training engine (forced selections: k_forced_sel /
+    k_forced_pair) instead of sweeping the stream once per rank -- equal to oracle.encode, and to the stream-wide rounds
+    (option enc_replay = 0), on the text the merges were trained on, on another text (most late pairs never occur: merges
+    with zero sites) and on a four-letter text (a == a merges at every other step, runs of one letter: F2)."""
+    if kind == "letters":
+        rng = np.random.default_rng(3)
+        text = bytes(97 + rng.integers(0, 4, size=1_300_000).astype(np.uint8))
+        pairs = oracle.train_fast(text[:400_000], 300)[0]
+    else:
+        text = native.synth_text(1_500_000, 81)
+        pairs = oracle.train_fast(text if kind == "own_text" else native.synth_text(700_000, 82), 700)[0]
+    exp_ids, exp_off = oracle.encode(pairs, text, None)
+    tp = np.array(pairs, np.int32)
+    ids, out_off = engine.encode_batch(tp, None, text, None)
+    assert np.array_equal(ids, exp_ids) and list(out_off) == [0, len(exp_ids)]
+    assert engine.train_stats()["steps"] > 0  # (it did go through the training engine's chain steps)
+    engine.set_option("enc_replay", 0)
+    try:
+        ids2, _ = engine.encode_batch(tp, None, text, None)
+    finally:
+        engine.set_option("enc_replay", 1)
+    assert np.array_equal(ids2, exp_ids)
+    if kind == "own_text":  # training applies its merges in order: the stream it leaves IS encode of its own text
+        engine.load_bytes(text)
+        engine.train(len(pairs))
+        assert np.array_equal(engine.read_ids(), exp_ids)
+
+
 @pytest.mark.parametrize("cache,bits", ENC_VARIANTS)
 def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits):
     """The cache's own cases: the same chunk at every byte alignment, chunks that differ in one byte (first,
