@@ -1696,7 +1696,8 @@ __global__ void k_dp_after_sum(DevState *st, const uint32_t *__restrict__ tail) 
 // selection is GIVEN: merge r is pairs[r] whatever its count (zero sites: nothing happens), and everything else -- slots,
 // the inverted index, sparse sweeps, batches of token-disjoint pairs in one sweep, the table update that keeps the counts
 // a sparse pass is planned by -- is the training engine's.
-// k_forced_sel: a chain step's batch = the longest run of the next merges with a != b and no shared token (<= kcap).
+// k_forced_sel: a chain step's batch = the longest run of the next merges with a != b, no shared token, and no token that
+// the run itself creates (<= kcap).
 __global__ void __launch_bounds__(64)
 k_forced_sel(DevState *st, const int32_t *__restrict__ pairs, const uint32_t *__restrict__ mat, uint32_t stride, uint32_t kcap) {
     const uint32_t lane = threadIdx.x;
@@ -1709,7 +1710,8 @@ k_forced_sel(DevState *st, const int32_t *__restrict__ pairs, const uint32_t *__
     const uint32_t r = iter + lane;
     const bool in = lane < kcap && r < nm;
     const uint32_t a = in ? (uint32_t)pairs[2 * r] : 0xFFFFFFFEu, b = in ? (uint32_t)pairs[2 * r + 1] : 0xFFFFFFFDu;
-    uint32_t bad = in ? (a == b) : 1u;
+    // (a pair made of a token that an earlier merge of this very run creates has no site yet: it ends the run too)
+    uint32_t bad = in ? ((a == b) | (a >= 256u + iter) | (b >= 256u + iter)) : 1u;
 #pragma unroll
     for (int j = 0; j < CH_KSWEEP - 1; j++) {
         const uint32_t aj = (uint32_t)__shfl((int)a, j), bj = (uint32_t)__shfl((int)b, j);
@@ -1739,7 +1741,7 @@ k_forced_sel(DevState *st, const int32_t *__restrict__ pairs, const uint32_t *__
         st->dp_wait = 0;
         st->sel_mode = CH_LIST;
         st->found = K ? 1u : 0u;
-        if (K == 0) st->defer = 1;  // a == b heads the run: the general path's merge
+        if (K == 0) st->defer = 1;  // a == b heads the run: the general path's merge (lane 0's tokens are older than its own merge: never the other reason)
         st->brep = cmax > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
         st->bhm = hm;
         st->bhm_key = ((256u + iter) << 8) | K;
