@@ -113,6 +113,8 @@ def _worker(rank, world, port, argv, out_q, tmpdir, golden=None, path="steps"):
     try:
         bench.main()
         out_q.put((rank, "ok", buf.getvalue()))
+    except SystemExit as e:  # (bench.py exits 3 after printing its line when a comparison with the oracle came out False)
+        out_q.put((rank, "ok" if not e.code else f"exit {e.code}", buf.getvalue()))
     except BaseException as e:  # noqa: BLE001 (the parent reports it)
         import traceback
         out_q.put((rank, "failed", f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
@@ -143,12 +145,15 @@ def test_sharded_bench_leg_runs_on_doubles_at_world_2(tmp_path, golden, path):
     for p in procs:
         p.join(timeout=60)
     for rank, status, text in outs:
-        assert status == "ok", f"rank {rank}: {text}"
+        # a job whose merges differ from the oracle's is reported by rank 0's exit code as well as in its line
+        assert status == ("exit 3" if (golden == "wrong" and rank == 0) else "ok"), f"rank {rank}: {status}: {text}"
     assert outs[1][2].strip() == ""  # rank 1 prints nothing
     lines = [ln for ln in outs[0][2].splitlines() if ln.strip()]
     assert len(lines) == 1  # ONE JSON line from rank 0
     line = json.loads(lines[0])
-    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["unit"] == "merges/s"
+    # (N > 1: `value` counts a merge once per shard it is applied to, and the unit says so)
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["unit"] == "shard-merges/s"
+    assert ("parity_failures" in line) == (golden == "wrong")
     assert line["steps"] == 1 and line["warmup"] == 1 and line["higher_is_better"] is True
     # the units ALL ranks processed per second = world x the job's own rate
     assert line["value"] == pytest.approx(world * line["job_merges_per_s"], rel=1e-3)
