@@ -434,7 +434,10 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
             }
             __syncthreads();  // (s_x is rewritten by the next round)
         }
-        __threadfence();
+        // (what was gathered went out as agent-scope stores: it needs no cache maintenance, only to have been
+        // acknowledged before the deciding workgroup is told -- a __threadfence() here made every one of the 63 x 1024
+        // threads write back and invalidate its L2, tens of microseconds per rebuild: tools/atomic_peak.hip)
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) granule_put(req + 2 + PL_ROWS + blk, tag, 1u);
         return;
@@ -634,7 +637,7 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
             if (!stale(x)) row_in(x, rowma[x].x);
         for (uint32_t i = tid; i < nd; i += 1024) row_in(s_exrow[i], s_exm[i]);
         if (tid == 0) __hip_atomic_store(&gather[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        __builtin_amdgcn_s_waitcnt(0);  // (the counter's reset is in memory before the rows are handed out; no fence: see above)
         __syncthreads();
         const uint32_t nrows = min(s_nrows, PL_ROWS);
         if (tid < nrows) granule_put(req + 1 + tid, tag, s_rows[tid]);
