@@ -77,7 +77,7 @@ __device__ __forceinline__ void chain_slot_load(const AbArgs &A, const uint32_t 
     if (lane < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
 }
 // (rv / hv: the slot's loads, issued by the caller -- k_merge_chain issues the NEXT slot's before it works on this one)
-template <bool DENSE>
+template <bool DENSE, bool THROUGH = false>
 __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t, const AbArgs &A,
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
                                                  const uint32_t K, const uint32_t z0, const uint32_t brep,
@@ -281,7 +281,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = make_uint4(h[4], h[5], 0u, 0u);
         } else {
-            stage_put(A.stage + t, t, h);
+            stage_put<THROUGH>(A.stage + t, t, h);
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
         if (total < 3 && t + 1 < Tl) A.st->gap = 1;
@@ -425,7 +425,9 @@ struct MergeLds {
     uint32_t s_pa[CH_KMAX], s_pb[CH_KMAX], s_pb1[CH_KMAX + 1];
     uint32_t s_ph[256], s_hm;
 };
-// (s_pa / s_pb / s_pb1 are filled and a barrier has passed; every thread of the workgroup calls)
+// (s_pa / s_pb / s_pb1 are filled and a barrier has passed; every thread of the workgroup calls; THROUGH: k_step -- the
+// staged headers are committed by other workgroups of the same launch)
+template <bool THROUGH = false>
 __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index,
                                                  MergeLds &L, const uint32_t K, const uint32_t z0, const uint32_t brep,
                                                  const uint32_t blk, const uint32_t nblk, unsigned long long *dbg = nullptr,
@@ -454,11 +456,11 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
         if (K == 1) {
-            merge_ab_wave<true, true, false>(s_out[wave_id()], nullptr, t, A1, a0, b0);
+            merge_ab_wave<true, true, false, THROUGH>(s_out[wave_id()], nullptr, t, A1, a0, b0);
         } else {
             uint4 rv[MJ], hv;
             chain_slot_load(A, t, rv, hv);
-            merge_chain_wave<false>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+            merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
         }
     };
     if (!(use_index & 1u) || gap != 0) {  // short slots about: visit everything
@@ -509,7 +511,7 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
             for (; i < n; i += NWV) {
                 const bool more = i + NWV < n;
                 if (more) chain_slot_load(A, s_list[i + NWV], nrv, nhv);
-                merge_chain_wave<false>(s_out[wave_id()], nullptr, s_list[i], A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+                merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, s_list[i], A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < MJ; j++) rv[j] = nrv[j];
@@ -909,17 +911,18 @@ __device__ __forceinline__ void apply_chain_records(DevState *st, int par, IterR
 }
 // staged headers: smask[w] bit s = slot 32*w + s has a new header in stage[32*w + s]; this thread takes mask words
 // first, first + stp, ...
+template <bool THROUGH = false>
 __device__ __forceinline__ void apply_chain_commit(uint32_t first, uint32_t stp, uint32_t nwords, uint32_t *__restrict__ smask,
                                                    const StageRec *__restrict__ stage, SlotHdr *__restrict__ hdr_cur) {
     for (uint32_t w = first; w < nwords; w += stp) {
-        uint32_t m = ld_agent(&smask[w]);  // (set by device atomics; in k_step by other workgroups of this launch)
+        uint32_t m = THROUGH ? ld_agent(&smask[w]) : smask[w];  // (set by device atomics; in k_step by other workgroups of this launch)
         if (!m) continue;
         smask[w] = 0;
         while (m) {
             const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
             m &= m - 1u;
             uint32_t h[8];
-            stage_get(stage + t, h);
+            stage_get<THROUGH>(stage + t, h);
             uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
             dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
             dst[1] = make_uint4(h[4], h[5], h[6], h[7]);

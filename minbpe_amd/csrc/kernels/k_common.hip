@@ -137,22 +137,37 @@ __device__ __forceinline__ void step_rec_seal(StepRec *r, unsigned long long seq
 }
 
 // a staged slot header (sparse merge passes): written by the wave that rewrote slot t, read by whoever commits it --
-// another workgroup, in k_step in the same launch
+// another workgroup, in k_step (THROUGH) in the same launch: only then written through and read at agent scope.  (Written
+// through in every sweep the four 8-byte stores per changed slot cost the mid-training sweeps 40-70 %: they queue at the
+// memory side with the sites' atomics -- profiles/r6_notes.md.)
+template <bool THROUGH>
 __device__ __forceinline__ void stage_put(StageRec *r, uint32_t t, const uint32_t (&h)[8]) {
     r->t = t;
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(r->h);
+    if (THROUGH) {
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(r->h);
 #pragma unroll
-    for (int i = 0; i < 4; i++) st_agent64(q + i, (unsigned long long)h[2 * i] | ((unsigned long long)h[2 * i + 1] << 32));
+        for (int i = 0; i < 4; i++) st_agent64(q + i, (unsigned long long)h[2 * i] | ((unsigned long long)h[2 * i + 1] << 32));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) r->h[i] = h[i];
+    }
 }
+template <bool THROUGH>
 __device__ __forceinline__ void stage_get(const StageRec *r, uint32_t (&h)[8]) {
-    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(r->h);
-    unsigned long long v[4];
+    if (THROUGH) {
+        const unsigned long long *q = reinterpret_cast<const unsigned long long *>(r->h);
+        unsigned long long v[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = ld_agent64(q + i);
+        for (int i = 0; i < 4; i++) v[i] = ld_agent64(q + i);
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        h[2 * i] = (uint32_t)v[i];
-        h[2 * i + 1] = (uint32_t)(v[i] >> 32);
+        for (int i = 0; i < 4; i++) {
+            h[2 * i] = (uint32_t)v[i];
+            h[2 * i + 1] = (uint32_t)(v[i] >> 32);
+        }
+    } else {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(r->h), hi = *reinterpret_cast<const uint4 *>(r->h + 4);
+        h[0] = lo.x; h[1] = lo.y; h[2] = lo.z; h[3] = lo.w;
+        h[4] = hi.x; h[5] = hi.y; h[6] = hi.z; h[7] = hi.w;
     }
 }
 

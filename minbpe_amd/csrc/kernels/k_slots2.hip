@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int srclane) {
 // VGPRs; the early dense passes, which run before the index exists, use the variant without).
 // LDSD: every id is below LDSD_CAP and the delta goes into the workgroup's LDS tables `sd`
 // (SL[LDSD_CAP] | SR[LDSD_CAP] | adj | removed), flushed by the kernel when its slots are done.
-template <bool SPARSE, bool INDEXED, bool LDSD>
+template <bool SPARSE, bool INDEXED, bool LDSD, bool THROUGH = false>
 __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t,
                                               const AbArgs &A, const uint32_t a, const uint32_t b) {
     const int lane = lane_id();
@@ -305,7 +305,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t] = make_uint4(h[0], h[1], h[2], h[3]);
             reinterpret_cast<uint4 *>(A.hdr_out)[2 * (size_t)t + 1] = make_uint4(h[4], h[5], 0u, 0u);
         } else {
-            stage_put(A.stage + t, t, h);
+            stage_put<THROUGH>(A.stage + t, t, h);
             atomicOr(&A.smask[t >> 5], 1u << (t & 31));
         }
         if (LDSD) atomicAdd(&sd[2 * LDSD_CAP + 1], len - total);

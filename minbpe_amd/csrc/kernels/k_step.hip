@@ -143,7 +143,7 @@ k_step(StepArgs S) {
             if (tid == 0) L.s_pb1[0] = 0xFFFFFFFFu;  // (a masked word has its weight bits clear: never equal)
         }
         __syncthreads();
-        merge_chain_body(S.A, S.idx_dirty, S.use_index, L, K, z0, brep, blockIdx.x, S.gm, blockIdx.x == 0 ? nullptr : dbg);
+        merge_chain_body<true>(S.A, S.idx_dirty, S.use_index, L, K, z0, brep, blockIdx.x, S.gm, blockIdx.x == 0 ? nullptr : dbg);
     }
     // ================= B: every delta word, staged header and flag of this step is in memory ==================================
     stamp(3);
@@ -241,7 +241,7 @@ k_step(StepArgs S) {
     }
     stamp(6);
     if (noop) return;
-    apply_chain_commit(blockIdx.x * (uint32_t)LEAN_MT + tid, gridDim.x * (uint32_t)LEAN_MT, S.nwords, S.smask, S.stage, S.hdr_cur);
+    apply_chain_commit<true>(blockIdx.x * (uint32_t)LEAN_MT + tid, gridDim.x * (uint32_t)LEAN_MT, S.nwords, S.smask, S.stage, S.hdr_cur);
     stamp(7);
 }
 
