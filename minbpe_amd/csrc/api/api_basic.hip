@@ -168,6 +168,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
+    } else if (!strcmp(name, "mc_occ")) {
+        if (value < 1 || value > 2) return fail(c, BPE_E_ARG, "mc_occ must be 1 or 2");
+        c->mc_occ = (int)value;
     } else if (!strcmp(name, "chain_prefetch")) {
         c->chain_prefetch = value != 0;
     } else if (!strcmp(name, "count_is_removed")) {

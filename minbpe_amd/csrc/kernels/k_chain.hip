@@ -82,9 +82,12 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
                                                  const uint32_t *pa, const uint32_t *pb, const uint32_t *pb1,
                                                  const uint32_t K, const uint32_t z0, const uint32_t brep,
                                                  uint4 (&rv)[MJ], const uint4 hv,
-                                                 const uint32_t *ph = nullptr, const uint32_t hm = 0) {
+                                                 const uint32_t *ph = nullptr, const uint32_t hm = 0,
+                                                 const uint32_t tl_in = 0xFFFFFFFFu) {
     const int lane = lane_id();
-    const uint32_t Tl = min(A.T, A.st->tlive);
+    // (tl_in: the caller read st->tlive once -- the kernel stores to *st, so a load here is repeated for every slot, a
+    // dependent round trip at the head of each)
+    const uint32_t Tl = tl_in != 0xFFFFFFFFu ? tl_in : min(A.T, A.st->tlive);
     const uint32_t *src;
     const uint32_t meta = bcast(hv.w, 2);
     const uint32_t len = meta & 0x7FFFFFFFu, buf = meta >> 31;
@@ -294,10 +297,15 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
     // every group of words, and were bound by instruction issue while every site compared its neighbours with
     // every pair).  Positions -2 and -1 (the previous slot's last words) and 1024, 1025 come from the context words.
     const uint32_t vc = A.vcap & 0xFFFFFFu;
-    const uint32_t cm2 = (uint32_t)(chain_match(pa, pb, K, prev2, prev1) + 1);  // (uniform)
+    // (uniform values, K compares each on the vector unit: looked up only when a site reads them -- position -2 by a site
+    // on the slot's first word, positions 1024 / 1025 by sites on its last two words)
+    uint32_t cm2 = 0, ct0 = 0, ct1 = 0;
+    if (bcast(mb[0], 0) & 1u) cm2 = (uint32_t)(chain_match(pa, pb, K, prev2, prev1) + 1);
     const uint32_t cm1 = s ? ip : 0u;
-    const uint32_t ct0 = (uint32_t)(chain_match(pa, pb, K, tail[0], tail[1]) + 1);
-    const uint32_t ct1 = (uint32_t)(chain_match(pa, pb, K, tail[1], tail[2]) + 1);
+    if (bcast(mb[MJ - 1], 63) & 0xCu) {
+        ct0 = (uint32_t)(chain_match(pa, pb, K, tail[0], tail[1]) + 1);
+        ct1 = (uint32_t)(chain_match(pa, pb, K, tail[1], tail[2]) + 1);
+    }
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         if (!__any(mb[j] != 0)) continue;  // (uniform) no site in this stripe
@@ -322,12 +330,19 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
         const uint32_t hi = lane_next(jc[j] & 0xFFu, hi_fill);
         const uint32_t win = lo | (jc[j] << 8) | (hi << 24);
         if (mb[j] == 0) continue;
+        // A lane's four words hold at most TWO sites (token-disjoint pairs: no two sites overlap or touch), and a sparse
+        // pass has one or two sites in a whole slot: the lanes take their FIRST site together, then their second, instead
+        // of one round per word position with a lane or two active in each (the site's words by select, not by index).
+        uint32_t todo = mb[j];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!((mb[j] >> k) & 1u)) continue;
-            const int q = j * 256 + lane * 4 + k;
-            const uint32_t p = ((win >> (4 * (k + 2))) & 15u) - 1u;
-            const int li = (int)((win >> (4 * k)) & 15u) - 1, ri = (int)((win >> (4 * (k + 4))) & 15u) - 1;
+        for (int si = 0; si < 2; si++) {
+            if (todo == 0) continue;
+            const uint32_t k = (uint32_t)__ffs((int)todo) - 1u;
+            todo &= todo - 1u;
+            const int q = j * 256 + lane * 4 + (int)k;
+            const uint32_t wk = win >> (4u * k);
+            const uint32_t p = ((wk >> 8) & 15u) - 1u;
+            const int li = (int)(wk & 15u) - 1, ri = (int)((wk >> 16) & 15u) - 1;
             const uint32_t Z = z0 + p;
             uint32_t *dl, *dr;  // SL, SR of pair p
             if (DENSE) {
@@ -341,9 +356,10 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
                 dl = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (t & (brep - 1u)), vc);
                 dr = dl + vc;
             }
-            const uint32_t wa = W[k + 1];
+            const bool k1 = (k & 1u) != 0, k2 = (k & 2u) != 0;
+            const uint32_t wa = k2 ? (k1 ? W[4] : W[3]) : (k1 ? W[2] : W[1]);
             const uint32_t wt = word_weight(wa);
-            const uint32_t Lw = W[k];
+            const uint32_t Lw = k2 ? (k1 ? W[3] : W[2]) : (k1 ? W[1] : W[0]);
             if (!(wa & FLAG) && Lw != INVALID_WORD) {
                 // the left neighbour ends a site of pair li: when pair p is merged it already reads Z_li
                 // (li < p) or still b_li (li > p); li == p is the same pair twice in a row -- format B's adj,
@@ -358,7 +374,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
                     }
                 }
             }
-            const uint32_t R = W[k + 3];
+            const uint32_t R = k2 ? (k1 ? W[6] : W[5]) : (k1 ? W[4] : W[3]);
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
                 if (ri == (int)p) {
                     if (DENSE) atomicAdd(&dl[2 * LDSD_CAP], wt);
@@ -456,11 +472,11 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
     const uint32_t a0 = s_pa[0], b0 = s_pb[0];
     auto do_slot = [&](uint32_t t) {
         if (K == 1) {
-            merge_ab_wave<true, true, false, THROUGH>(s_out[wave_id()], nullptr, t, A1, a0, b0);
+            merge_ab_wave<true, true, false, THROUGH>(s_out[wave_id()], nullptr, t, A1, a0, b0, Tl);
         } else {
             uint4 rv[MJ], hv;
             chain_slot_load(A, t, rv, hv);
-            merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+            merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, t, A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm, Tl);
         }
     };
     if (!(use_index & 1u) || gap != 0) {  // short slots about: visit everything
@@ -511,7 +527,7 @@ __device__ __forceinline__ void merge_chain_body(const AbArgs &A, const uint32_t
             for (; i < n; i += NWV) {
                 const bool more = i + NWV < n;
                 if (more) chain_slot_load(A, s_list[i + NWV], nrv, nhv);
-                merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, s_list[i], A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm);
+                merge_chain_wave<false, THROUGH>(s_out[wave_id()], nullptr, s_list[i], A, s_pa, s_pb, s_pb1, K, z0, brep, rv, hv, s_ph, hm, Tl);
                 if (more) {
 #pragma unroll
                     for (int j = 0; j < MJ; j++) rv[j] = nrv[j];
@@ -549,7 +565,11 @@ __device__ __forceinline__ void step_words_fetch(const DevState *st, uint32_t *s
     }
     __syncthreads();
 }
-__global__ void __launch_bounds__(LEAN_MT)
+// WPE: waves per SIMD the compiler must leave room for (the second launch bound).  1 = whatever the code needs (120 VGPRs:
+// one workgroup per CU); 8 = 64 VGPRs, two workgroups per CU (256-id slots only: 1024-id slots need 83 KB of LDS) --
+// option "mc_occ"
+template <int WPE>
+__global__ void __launch_bounds__(LEAN_MT, WPE)
 k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
     __shared__ MergeLds L;
     __shared__ uint32_t s_w[64];
@@ -617,11 +637,12 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
     __syncthreads();
     constexpr uint32_t NWV = LEAN_MT / 64;
     const uint32_t nw = gridDim.x * NWV;
+    const uint32_t Tl = min(A.T, st->tlive);
     for (uint32_t t = blockIdx.x * NWV + wave_id(); t < A.T; t += nw)
     {
         uint4 rv[MJ], hv;
         chain_slot_load(A, t, rv, hv);
-        merge_chain_wave<true>(s_out[wave_id()], s_sd, t, A, s_pa, s_pb, s_pb1, K, z0, (uint32_t)CH_RSTRIDE, rv, hv);
+        merge_chain_wave<true>(s_out[wave_id()], s_sd, t, A, s_pa, s_pb, s_pb1, K, z0, (uint32_t)CH_RSTRIDE, rv, hv, nullptr, 0, Tl);
     }
     __syncthreads();
     // flush: the tables of pair p into one of its CH_RSTRIDE replica blocks
@@ -656,8 +677,9 @@ k_merge_chain_dense1(AbArgs A) {
     A.newid = st->bz0;
     ldsd_clear(s_delta);
     const uint32_t nw = gridDim.x * (MT / 64);
+    const uint32_t Tl = min(A.T, st->tlive);
     for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
-        merge_ab_wave<false, false, true>(s_out[wave_id()], s_delta, t, A, a, b);
+        merge_ab_wave<false, false, true>(s_out[wave_id()], s_delta, t, A, a, b, Tl);
     ldsd_flush(s_delta, A);
 }
 

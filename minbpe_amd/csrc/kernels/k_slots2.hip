@@ -134,9 +134,11 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, int srclane) {
 // (SL[LDSD_CAP] | SR[LDSD_CAP] | adj | removed), flushed by the kernel when its slots are done.
 template <bool SPARSE, bool INDEXED, bool LDSD, bool THROUGH = false>
 __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32_t *__restrict__ sd, const uint32_t t,
-                                              const AbArgs &A, const uint32_t a, const uint32_t b) {
+                                              const AbArgs &A, const uint32_t a, const uint32_t b,
+                                              const uint32_t tl_in = 0xFFFFFFFFu) {
     const int lane = lane_id();
-    const uint32_t Tl = min(A.T, A.st->tlive);  // no slot from here on holds anything
+    // no slot from Tl on holds anything (tl_in: the caller read st->tlive once for all its slots)
+    const uint32_t Tl = tl_in != 0xFFFFFFFFu ? tl_in : min(A.T, A.st->tlive);
     // ---- (1) every load that does not depend on another one -------------------------------
     // the slot itself, speculatively from buffer 0 (a slot lives in buffer 1 only between an
     // a == b pass that rewrote it and the next re-packing), all TILE2 words whatever its length;
@@ -353,13 +355,20 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
         W[7] = lane_next(x[j][1], dn1);
         W[8] = lane_next(x[j][2], dn2);
         if (mb[j] == 0) continue;
+        // (a lane's four words hold at most two sites: the lanes take their first site together, then their second --
+        // merge_chain_wave, k_chain.hip)
+        uint32_t todo = mb[j];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!((mb[j] >> k) & 1u)) continue;
-            const int q = j * 256 + lane * 4 + k;
-            const uint32_t wa = W[k + 2];
+        for (int si = 0; si < 2; si++) {
+            if (todo == 0) continue;
+            const uint32_t k = (uint32_t)__ffs((int)todo) - 1u;
+            todo &= todo - 1u;
+            const int q = j * 256 + lane * 4 + (int)k;
+            const bool k1 = (k & 1u) != 0, k2 = (k & 2u) != 0;
+            auto wsel = [&](int o) -> uint32_t { return k2 ? (k1 ? W[o + 3] : W[o + 2]) : (k1 ? W[o + 1] : W[o]); };
+            const uint32_t wa = wsel(2);
             const uint32_t wt = word_weight(wa);
-            const uint32_t Lw = W[k + 1], LL = W[k];
+            const uint32_t Lw = wsel(1), LL = wsel(0);
             if (!(wa & FLAG) && Lw != INVALID_WORD) {
                 const bool ltail = ((LL & IDMASK) == a) & ((Lw & NWMASK) == b);
                 if (!ltail) {
@@ -374,7 +383,7 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
                     }
                 }
             }
-            const uint32_t R = W[k + 4], RR = W[k + 5];
+            const uint32_t R = wsel(4), RR = wsel(5);
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
                 const bool rsite = ((R & IDMASK) == a) & ((RR & NWMASK) == b);
                 if (rsite) adj += wt;
@@ -457,8 +466,9 @@ k_merge_ab_dense_early(AbArgs A) {
     if (a == b) return;
     ldsd_clear(s_delta);
     const uint32_t nw = gridDim.x * (MT / 64);
+    const uint32_t Tl = min(A.T, st->tlive);
     for (uint32_t t = blockIdx.x * (MT / 64) + wave_id(); t < A.T; t += nw)
-        merge_ab_wave<false, INDEXED, true>(s_out[wave_id()], s_delta, t, A, a, b);
+        merge_ab_wave<false, INDEXED, true>(s_out[wave_id()], s_delta, t, A, a, b, Tl);
     ldsd_flush(s_delta, A);
 }
 
