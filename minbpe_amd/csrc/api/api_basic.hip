@@ -168,9 +168,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->chain_dense = value != 0;
     } else if (!strcmp(name, "chain_extend")) {
         c->chain_extend = value != 0;
-    } else if (!strcmp(name, "mc_occ")) {
-        if (value < 1 || value > 2) return fail(c, BPE_E_ARG, "mc_occ must be 1 or 2");
-        c->mc_occ = (int)value;
     } else if (!strcmp(name, "chain_prefetch")) {
         c->chain_prefetch = value != 0;
     } else if (!strcmp(name, "count_is_removed")) {
@@ -213,6 +210,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "lean_scan")) {
         if (value < 1 || value > 1024) return fail(c, BPE_E_ARG, "lean_scan must be 1..1024");
         c->lean_scan = (int)value;
+    } else if (!strcmp(name, "repack_acc")) {
+        if (value < 0 || value > 10000) return fail(c, BPE_E_ARG, "repack_acc must be 0..10000");
+        c->repack_acc = (int)value;
     } else if (!strcmp(name, "depth")) {
         if (value < 0 || value > 64) return fail(c, BPE_E_ARG, "depth must be 0..64");
         c->depth = (int)value;

@@ -61,6 +61,9 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
+    int repack_acc = 150;  // option "repack_acc": 0 = re-pack the dense phase's slots when their fill drops below 31/32; N = when the
+                         // empty fractions of the sweeps since the last re-pack add up to N/100 of a sweep (what a re-pack costs)
+    double repack_waste = 0.0;
     // slotted stream (training loop, a != b merges)
     int use_slots = 2;  // 0 contiguous | 1 slotted, first form (k_slots.hip) | 2 second form (k_slots2.hip)
     int fused_rows = 0;                  // 1: row maxima inside the k_apply_delta launch
@@ -125,7 +128,6 @@ struct bpe_ctx {
                                               // slots too (tests)
     int count_is_removed = 1;                 // option "count_is_removed": chain steps of an unweighted stream take the ids a merge removes from the pair's
                                               // count instead of counting them (0: count, the cross-check)
-    int mc_occ = 1;                           // option "mc_occ": workgroups per CU of a sparse chain step's merge pass (256-id slots): 2 = the 64-VGPR build of the kernel
     int chain_prefetch = 1;                   // option "chain_prefetch": 256-id slots -- a wave's next candidate slot is loaded while it works on this one
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
     int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
@@ -1348,12 +1350,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         hipLaunchKernelGGL(GK(c, k_merge_chain_dense1), dim3(g1), dim3(MT), 0, c->stream, A);
     } else {
         const unsigned g = std::max(1u, std::min(use_index ? nwords : (T + 15) / 16, (unsigned)c->lean_grid));
-        if (c->mc_occ > 1 && c->ts == TILE2_MIN && use_index) {
-            const unsigned g2 = std::max(1u, std::min(nwords, (unsigned)c->mc_occ * (unsigned)c->lean_grid));
-            hipLaunchKernelGGL(bpe::bpe_g1::k_merge_chain<8>, dim3(g2), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
-                               1u | (c->chain_prefetch ? 2u : 0u), c->d_dbits);
-        } else
-        hipLaunchKernelGGL(GK(c, k_merge_chain<1>), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
+        hipLaunchKernelGGL(GK(c, k_merge_chain), dim3(g), dim3(LEAN_MT), 0, c->stream, A, c->d_idx_dirty,
                            (use_index ? 1u : 0u) | (c->chain_prefetch ? 2u : 0u), c->d_dbits);
     }
     LAUNCHCHK(c, "k_merge_chain");

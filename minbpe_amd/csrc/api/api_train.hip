@@ -221,6 +221,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
         return BPE_OK;
     };
 
+    c->repack_waste = 0.0;
     auto t_loop = now();
     while (!stop) {
         // ---- enqueue one more unit (if any merge is left to enqueue), then look at the oldest one ---------
@@ -235,8 +236,16 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
             // (with the inverted index live most passes skip most slots, and a re-packing also costs
             // an index build: re-pack at 7/8 there)
             const uint64_t den = c->idx_live ? 8 : REPACK_DEN;
-            const bool repack = c->slotted && c->slot_T > 64 &&
-                                c->n * den < c->slot_T * (uint64_t)(c->slot2 ? c->ts : TILE) * (den - 1);
+            bool repack = c->slotted && c->slot_T > 64 &&
+                          c->n * den < c->slot_T * (uint64_t)(c->slot2 ? c->ts : TILE) * (den - 1);
+            // (option repack_acc, dense phase: a sweep costs per SLOT, a re-pack about one sweep -- re-pack when the empty
+            // fractions of the sweeps since the last one add up to what it costs, not at a fixed fill: early merges
+            // remove 2 % of the stream each and 31/32 re-packs every other sweep)
+            if (c->repack_acc && c->slotted && c->slot2 && !c->idx_live && c->slot_T > 64) {
+                const double cap = (double)c->slot_T * (double)c->ts;
+                c->repack_waste += std::max(0.0, 1.0 - (double)c->n / cap);
+                repack = c->repack_waste * 100.0 >= (double)c->repack_acc;
+            }
             bool sparse = false;
             // lean iterations (k_lean.hip) / chain steps (k_chain.hip): every sparse pass whose pair is rare enough,
             // and every pass of a stream too small for the index (a few thousand slots: visiting them all costs nothing)
@@ -258,6 +267,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                     full_rowmax = true;
                 }
                 if (repack) {
+                    c->repack_waste = 0.0;
                     if (c->slot2) {
                         TRY(slots2_leave(c));
                         TRY(slots2_enter(c));

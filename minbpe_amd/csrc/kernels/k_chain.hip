@@ -132,10 +132,17 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const int q0 = j * 256 + lane * 4;
-        x[j][0] = at(q0 + 0, rv[j].x);
-        x[j][1] = at(q0 + 1, rv[j].y);
-        x[j][2] = at(q0 + 2, rv[j].z);
-        x[j][3] = at(q0 + 3, rv[j].w);
+        if ((j + 1) * 256 <= (int)len) {  // (uniform) a stripe of own words: nothing to select
+            x[j][0] = rv[j].x;
+            x[j][1] = rv[j].y;
+            x[j][2] = rv[j].z;
+            x[j][3] = rv[j].w;
+        } else {
+            x[j][0] = at(q0 + 0, rv[j].x);
+            x[j][1] = at(q0 + 1, rv[j].y);
+            x[j][2] = at(q0 + 2, rv[j].z);
+            x[j][3] = at(q0 + 3, rv[j].w);
+        }
     }
     uint32_t tail[3];
 #pragma unroll
@@ -565,11 +572,7 @@ __device__ __forceinline__ void step_words_fetch(const DevState *st, uint32_t *s
     }
     __syncthreads();
 }
-// WPE: waves per SIMD the compiler must leave room for (the second launch bound).  1 = whatever the code needs (120 VGPRs:
-// one workgroup per CU); 8 = 64 VGPRs, two workgroups per CU (256-id slots only: 1024-id slots need 83 KB of LDS) --
-// option "mc_occ"
-template <int WPE>
-__global__ void __launch_bounds__(LEAN_MT, WPE)
+__global__ void __launch_bounds__(LEAN_MT)
 k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_index, uint32_t *__restrict__ dbits) {
     __shared__ MergeLds L;
     __shared__ uint32_t s_w[64];

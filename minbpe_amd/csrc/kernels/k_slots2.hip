@@ -196,10 +196,17 @@ __device__ __forceinline__ void merge_ab_wave(uint32_t *__restrict__ out, uint32
 #pragma unroll
     for (int j = 0; j < MJ; j++) {
         const int q0 = j * 256 + lane * 4;
-        x[j][0] = at(q0 + 0, rv[j].x);
-        x[j][1] = at(q0 + 1, rv[j].y);
-        x[j][2] = at(q0 + 2, rv[j].z);
-        x[j][3] = at(q0 + 3, rv[j].w);
+        if ((j + 1) * 256 <= (int)len) {  // (uniform) a stripe of own words: nothing to select
+            x[j][0] = rv[j].x;
+            x[j][1] = rv[j].y;
+            x[j][2] = rv[j].z;
+            x[j][3] = rv[j].w;
+        } else {
+            x[j][0] = at(q0 + 0, rv[j].x);
+            x[j][1] = at(q0 + 1, rv[j].y);
+            x[j][2] = at(q0 + 2, rv[j].z);
+            x[j][3] = at(q0 + 3, rv[j].w);
+        }
     }
     uint32_t tail[3];  // positions TILE2 .. TILE2+2: beyond any slot's own words
 #pragma unroll

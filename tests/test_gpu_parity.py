@@ -412,6 +412,27 @@ def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits)
     assert np.array_equal(out_off, exp_off)
 
 
+@pytest.mark.parametrize("acc", [0, 5, 150, 10000])
+@pytest.mark.parametrize("kind", ["basic", "regex"])
+def test_repack_policy_vs_oracle(engine, native, kind, acc):
+    """Option repack_acc (when the dense phase re-packs its slots: at a fixed fill of 31/32, after nearly every sweep,
+    the default, never) changes the slot layout a pass works on, never the merges: the default engine on a 3 MB text,
+    dense sweeps first, then the index."""
+    text = native.synth_text(3_000_000, 19)
+    data, offs = (text, None) if kind == "basic" else split_chunks(text.decode())
+    nm = 500
+    exp = oracle.train(data, nm, offs)
+    reset_variant(engine)
+    engine.set_option("repack_acc", acc)
+    try:
+        engine.load_bytes(data, offs)
+        res = engine.train(nm)
+        assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
+        assert engine.train_stats()["dense"] > 0
+    finally:
+        engine.set_option("repack_acc", 150)
+
+
 CHAIN_OPTIONS = [
     (("pool", 0),),                                  # round 4's selection: the list of the pairs tied at the maximum
     (("pool", 0), ("chain_levels", 1)),              # ... walking into tied levels
