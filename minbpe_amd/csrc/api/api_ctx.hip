@@ -1149,7 +1149,7 @@ int launch_lean(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool use_ind
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (newid + 1 + 255) / 256;
     // (+ workgroups that commit the staged headers: a mask word or two per thread)
-    const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
+    const uint32_t ncommit = std::max(8u, std::min(128u, (nwords + 255) / 256));  // (a mask word per thread, at most)
     hipLaunchKernelGGL(GK(c, k_apply_lean), dim3(na + ncommit), dim3(256), 0, c->stream, c->d_mat, c->vcap, c->d_delta, dl,
                        c->d_rowmax, c->d_st, newid, c->d_dbits, c->par, rec, iter, na, c->d_hdr2[c->mq], c->d_stage,
                        c->d_removed, c->d_smask, nwords, c->d_lean_sum);
@@ -1357,7 +1357,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     TRY(prof_end(c));
     TRY(prof_begin(c, BPE_PROF_TABLE, 0));
     const uint32_t na = (zhi + 1 + 255) / 256;
-    const uint32_t ncommit = std::max(8u, std::min(64u, (nwords + 255) / 256));
+    const uint32_t ncommit = std::max(8u, std::min(128u, (nwords + 255) / 256));  // (a mask word per thread, at most)
     const uint32_t fS = std::min<uint32_t>(c->vcap, ((zhi + 1 + 63) / 64) * 64);  // vector stride of the SUM payload
     uint32_t *ftail = dp ? c->d_dp_cfold + (size_t)2 * kcap * fS : nullptr;
     if (dp) {

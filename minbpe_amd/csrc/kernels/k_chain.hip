@@ -943,14 +943,24 @@ __device__ __forceinline__ void apply_chain_commit(uint32_t first, uint32_t stp,
         uint32_t m = THROUGH ? ld_agent(&smask[w]) : smask[w];  // (set by device atomics; in k_step by other workgroups of this launch)
         if (!m) continue;
         smask[w] = 0;
+        // four headers in flight at a time: a mid-training sweep changes half the slots of a word, and with one staged
+        // header loaded, waited for and stored per turn the commit was 17 dependent round trips -- 50 of a step's 60 us of
+        // table update (SQ counters per phase, profiles/r6_notes.md)
         while (m) {
-            const uint32_t t = w * 32 + (uint32_t)__ffs((int)m) - 1u;
-            m &= m - 1u;
-            uint32_t h[8];
-            stage_get<THROUGH>(stage + t, h);
-            uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + t);
-            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
-            dst[1] = make_uint4(h[4], h[5], h[6], h[7]);
+            uint32_t tt[4], h[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                tt[i] = m ? w * 32 + (uint32_t)__ffs((int)m) - 1u : 0xFFFFFFFFu;
+                m &= m - 1u;  // (0 stays 0)
+                if (tt[i] != 0xFFFFFFFFu) stage_get<THROUGH>(stage + tt[i], h[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (tt[i] == 0xFFFFFFFFu) continue;
+                uint4 *dst = reinterpret_cast<uint4 *>(hdr_cur + tt[i]);
+                dst[0] = make_uint4(h[i][0], h[i][1], h[i][2], h[i][3]);
+                dst[1] = make_uint4(h[i][4], h[i][5], h[i][6], h[i][7]);
+            }
         }
     }
 }

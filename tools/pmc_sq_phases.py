@@ -4,7 +4,7 @@ the dispatch sequence is cut into steps at every selection kernel (as tools/rocp
 one kernel are summed per range of steps.  SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave
 (MI355X_MICROARCH.md); the ratios are what matters: wait = parked at s_waitcnt / barrier, wait_inst = issue stall,
 active = issuing.
-usage: tools/pmc_sq_phases.py run.db kernel_substring [edge edge ...]"""
+usage: tools/pmc_sq_phases.py run.db kernel_substring[,kernel_substring...] [edge edge ...]"""
 import json
 import sqlite3
 import sys
@@ -33,7 +33,7 @@ for did in sorted(disp):
     d = disp[did]
     if d["name"].startswith(SEL):
         it += 1
-    if flt not in d["name"] or it < 0:
+    if not any(f in d["name"] for f in flt.split(",")) or it < 0:
         continue
     b = next(f"{lo}-{hi if hi < (1 << 30) else 'end'}" for lo, hi in zip(edges[:-1], edges[1:]) if lo <= it < hi)
     a = acc[b + " " + d["name"]]
