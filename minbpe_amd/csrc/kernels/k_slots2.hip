@@ -518,13 +518,28 @@ k_merge_ab_sparse(AbArgs A) {
 // every pair charged to its left element) on the 32-byte headers and one-wave slots: the tile
 // helpers of k_merge.hip with a single wave (its span IS the slot).
 
-__device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A, const uint32_t a) {
+__device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A, const uint32_t a, const uint32_t Tl) {
     __shared__ int s_wave[MT / 64];
     __shared__ uint32_t s_wsum[MT / 64];
     __shared__ uint32_t s_ctx[8];   // halo0..2, prev2, prev1, carry
     __shared__ uint32_t s_hdr[8];   // my header (copied, then rewritten by the tile)
     const uint32_t b = a;
-    const SlotHdr hme = A.hdr_in[t];
+    // the headers of slots t - 1, t, t + 1 as six 16-byte pieces on lanes 0..5, ONE round trip (merge_ab_wave's scheme: the
+    // pass used to read its own header, then the state's tlive, then walk to both neighbours with thread 0 -- four
+    // dependent round trips per slot before the slot's words were asked for)
+    uint4 hv6 = (lane_id() & 1) ? make_uint4(INVALID_WORD, INVALID_WORD, 0u, 0u) : make_uint4(INVALID_WORD, INVALID_WORD, INVALID_WORD, 0u);
+    {
+        const long long hi = 2ll * (long long)t - 2 + lane_id();
+        if (lane_id() < 6 && hi >= 0 && hi < 2ll * (long long)A.T) hv6 = reinterpret_cast<const uint4 *>(A.hdr_in)[hi];
+    }
+    SlotHdr hme;
+    hme.w0 = bcast(hv6.x, 2);
+    hme.w1 = bcast(hv6.y, 2);
+    hme.w2 = bcast(hv6.z, 2);
+    hme.meta = bcast(hv6.w, 2);
+    hme.l0 = bcast(hv6.x, 3);
+    hme.l1 = bcast(hv6.y, 3);
+    hme.pad0 = hme.pad1 = 0;
     const uint32_t mi = hme.meta;
     const int len = (int)(mi & 0x7FFFFFFFu);
     uint4 *out4 = reinterpret_cast<uint4 *>(A.hdr_out + t);
@@ -540,8 +555,20 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
     }
     const uint32_t cur = mi >> 31;
     const uint32_t *src = (cur ? A.b1 : A.b0) + (size_t)t * TILE2;
+    const uint32_t nlen = bcast(hv6.w, 4) & 0x7FFFFFFFu, plen = bcast(hv6.w, 0) & 0x7FFFFFFFu;
+    const uint32_t nh0 = bcast(hv6.x, 4), nh1 = bcast(hv6.y, 4), nh2 = bcast(hv6.z, 4), pp2 = bcast(hv6.x, 1), pp1 = bcast(hv6.y, 1);
     if (threadIdx.x == 0) {
-        slot_context_walk(A.hdr_in, t, min(A.T, A.st->tlive), s_ctx);
+        if ((t + 1 < Tl && nlen < 3) || (t > 0 && plen < 2)) {  // (rare) short or empty neighbours: walk the headers
+            slot_context_walk(A.hdr_in, t, Tl, s_ctx);
+        } else {
+            s_ctx[0] = nh0;
+            s_ctx[1] = nh1;
+            s_ctx[2] = nh2;
+            s_ctx[3] = pp2;
+            s_ctx[4] = pp1;
+            s_ctx[5] = t - 1;
+            s_ctx[6] = t + 1;
+        }
         s_hdr[0] = hme.w0;
         s_hdr[1] = hme.w1;
         s_hdr[2] = hme.w2;
@@ -678,7 +705,7 @@ __device__ __forceinline__ void merge_aa_tile(const uint32_t t, const AaArgs &A,
                 r->h[6] = r->h[7] = 0;
             }
             atomicAdd(&A.removed[(t & 255u) * REMOVED_STRIDE], (uint32_t)len - kept);
-            if (kept < 3 && t + 1 < min(A.T, A.st->tlive)) A.st->gap = 1;
+            if (kept < 3 && t + 1 < Tl) A.st->gap = 1;
             if (A.dirty) {
                 // its pairs changed, and so did the boundary pairs it shares with both neighbours:
                 // none of that is in the index until the next build
@@ -699,16 +726,17 @@ k_merge_aa(AaArgs A) {
     if (st->status || !st->found) return;  // (a missing decision is reported by the a != b kernel)
     const uint32_t a = (uint32_t)st->a;
     if (a != (uint32_t)st->b) return;
+    const uint32_t Tl = min(A.T, st->tlive);  // (read once: the pass stores to *st, a load inside the loop is repeated per slot)
     if (A.cand) {  // (ascending, like the slots themselves: a wait for a predecessor's carry ends)
         const uint32_t n = st->ncand;
         for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-            merge_aa_tile(A.cand[i], A, a);
+            merge_aa_tile(A.cand[i], A, a, Tl);
             __syncthreads();
         }
         return;
     }
     for (uint32_t t = blockIdx.x; t < A.T; t += gridDim.x) {
-        merge_aa_tile(t, A, a);
+        merge_aa_tile(t, A, a, Tl);
         __syncthreads();
     }
 }
