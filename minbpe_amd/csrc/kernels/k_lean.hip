@@ -101,7 +101,7 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
     if (!use_index || st->gap != 0) {
         const uint32_t nw = gridDim.x * NWV;
         for (uint32_t t = blockIdx.x * NWV + wave_id(); t < Tl; t += nw)
-            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b);
+            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, t, A, a, b, Tl);
         return;
     }
     const uint32_t nwords = (Tl + 31) / 32;
@@ -133,7 +133,7 @@ k_merge_ab_lean(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_i
         }
         __syncthreads();
         for (uint32_t i = wave_id(); i < n; i += NWV)
-            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, s_list[i], A, a, b);
+            merge_ab_wave<true, INDEXED, false>(s_out[wave_id()], nullptr, s_list[i], A, a, b, Tl);
         __syncthreads();  // (the list is rewritten by the next round)
     }
 }

@@ -506,8 +506,9 @@ k_merge_ab_sparse(AbArgs A) {
         if (blockIdx.x * (MT / 64) >= n) return;  // (uniform) none of my waves has a slot
         ldsd_clear(s_delta);
     }
+    const uint32_t Tl = min(A.T, st->tlive);
     for (uint32_t i = blockIdx.x * (MT / 64) + wave_id(); i < n; i += nw)
-        merge_ab_wave<true, true, LDSD>(s_out[wave_id()], s_delta, A.cand[i], A, a, b);
+        merge_ab_wave<true, true, LDSD>(s_out[wave_id()], s_delta, A.cand[i], A, a, b, Tl);
     if (LDSD) ldsd_flush(s_delta, A);
 }
 
