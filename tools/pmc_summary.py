@@ -136,7 +136,7 @@ def main():
                 hbm = tab[dk]["frac_of_hbm_peak"] or 0.0
                 out["dominant_kernel"]["limited_by"] = (
                     "hbm bytes" if hbm >= max(0.4, ach / peak if peak else 0) else
-                    "memory-side atomics per merge site and dependent round trips per slot (latency), not HBM bytes")
+                    "instruction issue and per-slot latency, in balance (SQ counters of the same kernel, profiles/r6_sq_after_pass*.json: VALU pipes ~73 % busy at four waves per SIMD, waves parked ~58 % of their cycles), plus eight memory-side atomics per merge site -- not HBM bytes")
     with open(outp, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps({k: out[k] for k in ("workload", "source_hash", "launches", "trains", "merges", "hbm_bytes_per_launch")}))
