@@ -166,8 +166,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->fuse_load = value != 0;
     } else if (!strcmp(name, "chain_dense")) {
         c->chain_dense = value != 0;
-    } else if (!strcmp(name, "chain_extend")) {
-        c->chain_extend = value != 0;
     } else if (!strcmp(name, "chain_prefetch")) {
         c->chain_prefetch = value != 0;
     } else if (!strcmp(name, "count_is_removed")) {
@@ -180,8 +178,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "chain_kcap")) {
         if (value < 1 || value > CH_KSWEEP) return fail(c, BPE_E_ARG, "chain_kcap must be 1..%d", CH_KSWEEP);
         c->chain_kcap = (int)value;
-    } else if (!strcmp(name, "pool")) {
-        c->pool = value != 0;
     } else if (!strcmp(name, "enc_replay")) {
         if (value < 0 || value > 1) return fail(c, BPE_E_ARG, "enc_replay must be 0 or 1");
         c->enc_replay = (int)value;
@@ -194,10 +190,6 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
     } else if (!strcmp(name, "pool_hint")) {
         if (value < 0 || value > 128) return fail(c, BPE_E_ARG, "pool_hint must be 0..128");
         c->pool_hint = (int)value;
-    } else if (!strcmp(name, "chain_levels")) {
-        c->chain_levels = value != 0;
-    } else if (!strcmp(name, "chain_list")) {
-        c->chain_list = value != 0;
     } else if (!strcmp(name, "chain_scan")) {
         if (value < 1 || value > 255) return fail(c, BPE_E_ARG, "chain_scan must be 1..255");
         c->chain_scan = value;

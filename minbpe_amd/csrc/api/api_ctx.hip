@@ -115,12 +115,7 @@ struct bpe_ctx {
     int lean_chain = 1;                       // option "lean_chain": 1 = tied pairs are merged off the list one selection made (k_sel_lean), 0 = every iteration selects
     int chain_dense = 1;                      // option "chain_dense": chain steps from the second merge on -- dense passes, LDS delta tables, up to CH_KDENSE
                                               // pairs per sweep -- while every id is below LDSD_CAP and the index does not exist yet
-    int chain_extend = 1;                     // option "chain_extend": a chain step's batch may reach below the maximum count (k_chain_sel)
-    int chain_list = 1;                       // option "chain_list": 0 = no LIST steps, every step is a full selection that walks the levels (with chain_levels;
-                                              // UNTESTED ON A GPU)
-    int chain_levels = 0;                     // option "chain_levels": ... and into a level that holds several pairs (taken in order of first occurrence;
-                                              // that level becomes the list).  UNTESTED ON A GPU (written without one): off until it is
-    unsigned long long *d_chain_req = nullptr;  // ... the request / answer words of its second-maximum scans
+    unsigned long long *d_chain_req = nullptr;  // the request / answer words between the deciding and the scanning workgroups of a chain step's selection (k_pool.hip)
     int ts = TILE2_MAX;                       // ids per slot of the second slotted form as the stream stands: 1024 (kernels of namespace bpe_g4)
                                               // or 256 (bpe_g1) -- see GK below
     int small_slots = 1;                      // option "small_slots": re-pack into 256-id slots when the inverted index is first built (a large
@@ -130,8 +125,6 @@ struct bpe_ctx {
                                               // count instead of counting them (0: count, the cross-check)
     int chain_prefetch = 1;                   // option "chain_prefetch": 256-id slots -- a wave's next candidate slot is loaded while it works on this one
     int chain_kcap = CH_KSWEEP;               // option "chain_kcap": most pairs of a sparse chain step's batch (1..CH_KSWEEP)
-    int pool = 1;                             // option "pool": a chain step's selection is k_pool_sel (k_pool.hip: every pair at or above a threshold, kept
-                                              // across steps) instead of k_chain_sel (one count level at a time); in a sharded job in two halves around the MIN all-reduce: k_pool_sel, k_pool_sel_dp
     int fuse_step = 0;                        // option "fuse_step": 1 = a sparse chain step of a single-GPU job is ONE launch (k_step.hip:
                                               // selection -> published batch -> merge pass -> grid barrier -> table update) instead of three.
                                               // Measured SLOWER than the three launches (this part overlaps a dependent launch's
@@ -1171,7 +1164,7 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     const uint32_t T = (uint32_t)c->slot_T;
     const uint32_t dl = delta_layout(c, zhi);
     // one launch for the whole step (k_step.hip) where there is nothing between its parts: a single-GPU job's sparse steps
-    const bool fused = c->fuse_step && c->pool && !c->forced && !dense && !c->dp_comm && use_index && c->idx_live;
+    const bool fused = c->fuse_step && !c->forced && !dense && !c->dp_comm && use_index && c->idx_live;
     if (!fused) TRY(prof_begin(c, BPE_PROF_ARGMAX, 0));
     CandArgs C;
     C.idx = c->d_idx;
@@ -1199,9 +1192,9 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
         HIPCHK(c, hipMemsetAsync(c->d_pool_gather, 0, (2 + 2 * PL_GATHER) * sizeof(uint32_t), c->stream));
     }
     // sharded training (dp_train_loop, api_rccl.hip): the step's two collectives sit between its launches -- a tie's
-    // first occurrences (MIN) before the batch is formed, the batch's delta (SUM) before the table update.  A batch
-    // goes on below the maximum only when the maximum is attained by ONE pair (k_chain_sel then decides everything
-    // from replicated state, as on one GPU); after a tie the list is made by k_chain_sel_dp, which stays at the maximum
+    // first occurrences (MIN) before the batch is formed, the batch's delta (SUM) before the table update: k_pool_sel
+    // leaves the local first occurrences of the entries it must order, k_pool_sel_dp finishes the selection from the
+    // reduced words (the pool itself is replicated state, maintained alike on every rank)
     const DpComm *dp = c->dp_comm;
     uint32_t kcap = (uint32_t)(dense ? CH_KDENSE : std::min(CH_KSWEEP, c->chain_kcap));
     if (dp) kcap = std::min(kcap, (uint32_t)c->dp_kcap);
@@ -1298,25 +1291,17 @@ int launch_chain_step(bpe_ctx *c, uint32_t step, uint32_t zhi, bool use_index, b
     }
     if (c->forced)
         hipLaunchKernelGGL(GK(c, k_forced_sel), dim3(1), dim3(64), 0, c->stream, c->d_st, c->d_forced, c->d_mat, c->vcap, kcap);
-    else if (c->pool)
+    else
         hipLaunchKernelGGL(GK(c, k_pool_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
                            c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
                            kcap, c->d_pool, c->d_pool_gather, hint_below, dp ? c->d_dp_ckey : (long long *)nullptr,
                            (unsigned long long)(dp ? dp->rank : 0), c->d_pool + PL_CAP);
-    else
-    hipLaunchKernelGGL(GK(c, k_chain_sel), dim3(1 + nscan), dim3(1024), 0, c->stream, c->d_rowmax, c->d_mat,
-                       c->vcap, c->d_st, stream_ref_h(c), C, c->d_dbits, c->d_lean_res, ++c->lean_tag, c->d_chain_req,
-                       (uint32_t)((c->chain_extend && (int)nscan >= CH_KMAX - 1) ? (1 | (c->chain_levels ? 2 : 0) | (c->chain_list ? 0 : 4)) : 0),  // (workgroups 1 .. CH_KMAX - 1 answer its row scans)
-                       kcap, dp ? c->d_dp_ckey : (long long *)nullptr, (unsigned long long)(dp ? dp->rank : 0));
-    LAUNCHCHK(c, "k_chain_sel");
+    LAUNCHCHK(c, "k_pool_sel");
     if (dp) {
         TRY(dp_allreduce(c, c->d_dp_ckey, DP_KEY_WORDS, BPE_DT_INT64, BPE_OP_MIN));
-        if (c->pool)
-            hipLaunchKernelGGL(GK(c, k_pool_sel_dp), dim3(1), dim3(PL_CAP), 0, c->stream, c->d_st, c->d_dp_ckey, kcap, c->d_pool,
-                               c->d_pool + PL_CAP, hint_below);
-        else
-            hipLaunchKernelGGL(GK(c, k_chain_sel_dp), dim3(1), dim3(128), 0, c->stream, c->d_st, c->d_dp_ckey, kcap);
-        LAUNCHCHK(c, "k_chain_sel_dp");
+        hipLaunchKernelGGL(GK(c, k_pool_sel_dp), dim3(1), dim3(PL_CAP), 0, c->stream, c->d_st, c->d_dp_ckey, kcap, c->d_pool,
+                           c->d_pool + PL_CAP, hint_below);
+        LAUNCHCHK(c, "k_pool_sel_dp");
     }
     TRY(prof_end(c));
     AbArgs A;

@@ -76,7 +76,7 @@ __host__ __device__ inline size_t delta_rep_off(uint32_t r, uint32_t stride) {
 constexpr int CH_KMAX = 16;                    // (array sizes)
 constexpr int CH_KSWEEP = 15;                  // most pairs one sweep merges: a word's pair number + 1 is a nibble (merge_chain_wave)
 constexpr int CH_RSTRIDE = 16;                 // replica blocks set aside per pair of a batch: all of them while its pairs have
-constexpr uint32_t CH_REP_COUNT = 4096;        // more sites than this (hot tokens queue ~11 ns per same-address atomic) ...
+constexpr uint32_t CH_REP_COUNT = 16384;       // more sites than this (hot tokens queue ~11 ns per same-address atomic) ...
 constexpr int CH_REP = 4;                      // ... this many otherwise (the table update folds every replica it is told to)
 constexpr int CH_RMV = 16;                     // removal counters per pair of a batch (of the 256)
 constexpr int DP_KCAP_MAX = CH_KSWEEP;         // sharded chain steps: most pairs of a batch (option dp_kcap; the SUM payload grows with it: 2 K S words)
@@ -85,7 +85,7 @@ static_assert(CH_KMAX * CH_RSTRIDE <= DELTA_REPL, "a batch's delta vectors must 
 static_assert(CH_KMAX * CH_RMV <= 256, "removal counters of a batch");
 static_assert(CH_KSWEEP < 16 && CH_KSWEEP <= CH_KMAX, "pair number + 1 must fit a nibble");
 constexpr uint32_t CH_FULL = 0, CH_LIST = 1;   // DevState::sel_mode
-constexpr int DP_KEY_WORDS = TIE_CAP + 2;      // sharded chain steps: int64 words of the MIN all-reduce (k_chain_sel)
+constexpr int DP_KEY_WORDS = TIE_CAP + 2;      // sharded chain steps: int64 words of the MIN all-reduce (k_pool_sel)
 
 // encode: one chunk per lane, token lists in lane-private LDS columns
 constexpr int ENC_THREADS = 256;
@@ -173,11 +173,11 @@ struct DevState {
     uint32_t bk, bz0;             // this step's batch: pairs, the new id of the first one
     int32_t ba[CH_KMAX], bb[CH_KMAX];
     uint32_t badj[CH_KMAX];       // delta format B, per pair of the batch: sites whose right neighbour starts a site of the SAME pair
-    uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum: k_chain_sel)
+    uint32_t bcnt[CH_KMAX];       // the pairs' counts (a batch may reach below the maximum)
     uint32_t brep;                // delta replicas per pair of this batch (CH_REP or CH_RSTRIDE)
     uint32_t bhm, bhm_key;        // the multiplier of the batch's first-token look-up table (merge_chain_wave), found once by the selection
                                   // instead of by every workgroup of the merge pass; valid iff bhm_key == bz0 << 8 | bk
-    uint32_t dp_wait;             // sharded chain steps: k_chain_sel left a tie for k_chain_sel_dp to order (after the MIN all-reduce)
+    uint32_t dp_wait;             // sharded chain steps: the selection waits for the MIN all-reduce (k_pool_sel_dp finishes it)
     // the pool (k_pool.hip): every pair that counts pool_theta or more, pool_n entries in the ctx's pool buffer
     uint32_t pool_n, pool_theta;
     uint32_t pool_hint;           // the next selection launch may have to rebuild the pool: its row-scanning workgroups stay.

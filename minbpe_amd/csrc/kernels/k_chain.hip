@@ -24,10 +24,11 @@
 //      pair i > j still reads b_i; same on the right; i == j is format B's adj).
 //
 // A step is three launches, like a lean iteration:
-//   k_chain_sel    LIST mode (one workgroup): four-way replacement of the listed pairs the last batch touched,
-//                  then the next batch.  FULL mode: the maximum from k_apply_chain's per-wave records (or the
-//                  whole row-maxima array after a general iteration) while workgroups 1.. re-scan every
-//                  flagged row; all tied pairs (<= TIE_CAP) located through the index and sorted -> the list.
+//   k_pool_sel     (k_pool.hip) the list generalised to every pair at or above a threshold, kept exact across steps: the
+//                  next batch off the pool; a rebuild re-scans the flagged rows with workgroups 1...  (Rounds 4-5 kept
+//                  the list itself -- k_chain_sel, LIST / FULL modes, one count level at a time; retired in round 6: the
+//                  rule is pinned by tests/test_list_model.py and tests/test_level_model.py, the pool by
+//                  tests/test_pool_model.py.)
 //   k_merge_chain  every workgroup lists its candidate slots (the filter rows of ALL the batch's pairs) and
 //                  its waves rewrite them (merge_chain_wave).
 //   k_apply_chain  table update for every pair of the batch, one token per thread; rows a_j, b_j, Z_j and the
@@ -905,7 +906,7 @@ __device__ __forceinline__ void apply_chain_records(DevState *st, int par, IterR
             const unsigned long long n = st->n[par];
             unsigned long long nn = n;
             const uint32_t iter = st->iter;
-            const uint32_t mode_used = st->sel_mode;  // (what this step's k_chain_sel ran as)
+            const uint32_t mode_used = st->sel_mode;  // (CH_FULL / CH_LIST: left from the list selection; the pool does not use it)
             uint32_t k_done = 0;
             if (!noop) {
                 for (uint32_t p = 0; p < K; p++) {
@@ -998,662 +999,8 @@ k_apply_chain(uint32_t *__restrict__ mat, uint32_t stride, uint32_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------
-// The batch: the longest prefix of the list (n entries in LDS) whose pairs have a != b and share no token.
-// Thread 0 of the deciding workgroup.  An empty batch with a non-empty list means a == b at its head: the
-// general path's merge.
-__device__ __forceinline__ void chain_form_batch(DevState *st, const int32_t *s_list, uint32_t n, uint32_t M,
-                                                 uint32_t iter, uint32_t nm, uint32_t kcap) {
-    const uint32_t kmax = min(kcap, nm - iter);
-    int32_t ta[CH_KMAX], tb[CH_KMAX];
-    uint32_t k = 0;
-    for (uint32_t e = 0; e < n && k < kmax; e++) {
-        const int32_t a = s_list[2 * e], b = s_list[2 * e + 1];
-        bool clash = a == b;
-        for (uint32_t i = 0; i < k; i++) clash |= (a == ta[i]) | (a == tb[i]) | (b == ta[i]) | (b == tb[i]);
-        if (clash) break;
-        ta[k] = a;
-        tb[k] = b;
-        k++;
-    }
-    st->adj = 0;
-    st->count = M;
-    st->ntied = n;
-    st->firstpos = NOPOS;
-    st->sel_tie = 0;
-    st->a = s_list[0];
-    st->b = s_list[1];
-    st->fin_a = s_list[0];
-    st->fin_b = s_list[1];
-    st->bk = k;
-    st->bz0 = 256u + iter;
-    st->tl_skip = k;
-    if (k == 0) {
-        st->found = 0;
-        st->defer = 1;  // a == b: the host re-runs this merge through the general path
-        return;
-    }
-    st->found = 1;
-    for (uint32_t i = 0; i < k; i++) {
-        st->ba[i] = ta[i];
-        st->bb[i] = tb[i];
-        st->badj[i] = 0;
-        st->bcnt[i] = M;
-    }
-    st->brep = M > CH_REP_COUNT ? (uint32_t)CH_RSTRIDE : (uint32_t)CH_REP;
-}
-
-// Largest entry of a table row except column excl, by a 1024-thread workgroup (thread 0 gets it).
-__device__ __forceinline__ uint32_t row_scan_excl(const uint32_t *__restrict__ row, uint32_t ncols, uint32_t excl,
-                                                  uint32_t *s_r16) {
-    uint32_t m = 0;
-    const uint32_t n4 = (ncols + 3) & ~3u;
-    constexpr int U = 8;
-    for (uint32_t base = 0; base < n4; base += U * 4096) {
-        uint4 q[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
-            q[u] = (y < n4) ? *reinterpret_cast<const uint4 *>(row + y) : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t y = base + ((uint32_t)u * 1024u + threadIdx.x) * 4u;
-            const uint32_t v[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (y + k != excl && y + k < ncols) m = max(m, v[k]);
-        }
-    }
-    m = wave_umax_dpp(m);
-    __syncthreads();
-    if (lane_id() == 0) s_r16[wave_id()] = m;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int w = 1; w < 16; w++) m = max(m, s_r16[w]);
-    return m;
-}
-
-// K2 of a chain step.
-// LIST mode: one workgroup, table look-ups only (see the head of this file).
-// FULL mode: workgroup 0 reads the whole row-maxima array (32 rows per thread, in registers) while workgroups 1..
-// re-scan the flagged rows and hand their maxima over; the pairs at the maximum M, located through the index and
-// sorted, are the list; the batch is its longest token-disjoint prefix.  If that prefix is the WHOLE list the batch
-// goes on BELOW the maximum: the argument for ties holds for any prefix of the ranking by (count, first
-// occurrence) -- a created pair inherits at most the count and the place of a pair that ranks after the prefix.
-// The device has only every row's maximum, so it takes, level by level, the largest row maximum below the last
-// one if exactly one row attains it with one column (a != b, no shared token) -- and then makes sure that no
-// entry HIDDEN behind the maximum of a row it took from ranks among the taken pairs: workgroups 1..k-1 scan those
-// rows for their second largest entry, and the batch is cut before the first pair whose count does not exceed
-// them all (tests/test_list_model.py restates exactly this against the reference semantics).
-// req: the request / answer words of that exchange ([0] = tag | n, [1 + j] = tag | row << 16 | column,
-// [16 + j] = tag | second maximum), all self-validating (the launch tag never repeats).
-__global__ void __launch_bounds__(1024)
-k_chain_sel(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_t stride, DevState *st, SlotRefH ref,
-            CandArgs C, uint32_t *__restrict__ dbits, unsigned long long *__restrict__ res, uint32_t tag,
-            unsigned long long *__restrict__ req, uint32_t extend, uint32_t kcap, long long *__restrict__ dpkey,
-            unsigned long long dprank) {
-    __shared__ unsigned long long s_red[32];
-    __shared__ uint32_t s_words[DBITS_WORDS], s_pref[DBITS_WORDS + 1];
-    __shared__ int32_t s_tied[2 * TIE_CAP];
-    __shared__ int32_t s_list[2 * TIE_CAP];
-    __shared__ uint32_t s_exrow[CH_EX_CAP], s_exm[CH_EX_CAP], s_exarg[CH_EX_CAP];
-    __shared__ uint32_t s_bits[2048];
-    __shared__ uint32_t s_r16[16], s_c16[16];
-    __shared__ uint32_t s_fail, s_nt, s_k, s_m2, s_hit, s_hitarg, s_stop;
-    __shared__ uint32_t s_nt2, s_nrows2, s_rows2[16];  // the tied level's pairs are gathered by the loop that finds the level
-    __shared__ uint32_t s_lv, s_lvn, s_lvfirst, s_lvc, s_more;  // a TIED level below the maximum: its count (0: none; s_lvc: of the one that is the list), its pairs,
-                                                                // where they start in the batch; s_more: it was taken whole, the walk goes on
-    __shared__ unsigned long long s_pos[TIE_CAP];
-    __shared__ uint32_t s_order[TIE_CAP], s_keep[TIE_CAP];
-    __shared__ int32_t s_ba[CH_KMAX], s_bb[CH_KMAX];
-    __shared__ uint32_t s_bc[CH_KMAX], s_sec[CH_KMAX];
-    const uint32_t status = st->status, defer = st->defer, gap = st->gap;
-    // (extend bit 2, option chain_list = 0: every step selects afresh and walks the levels -- no LIST steps; the step
-    // record still says what k_apply_chain would have chosen)
-    const uint32_t iter = st->iter, nm = st->num_merges, mode = (extend & 4u) ? CH_FULL : st->sel_mode;
-    const uint32_t vcur = 256u + iter;
-    const uint32_t tid = threadIdx.x;
-    // Sharded training (dpkey != nullptr, k_dp.hip): the table, the row maxima and the flag words are replicas of
-    // GLOBAL state, so every rank finds the same maximum and the same tied pairs -- but a pair's first occurrence is
-    // a rank-local fact.  The deciding workgroup leaves the MIN all-reduce payload: [0] = -status, [1] = -1 if this
-    // rank cannot order its share of a tie (short slots about), [2 + i] = rank << 40 | first local position of tied
-    // pair i (pairs in canonical order), INT64_MAX = no occurrence here.  k_chain_sel_dp makes the list from the
-    // reduced words.  Every word is written by the thread of the same number, first with its neutral value.
-    if (dpkey && blockIdx.x == 0 && tid < (uint32_t)DP_KEY_WORDS)
-        dpkey[tid] = tid == 0 ? -(long long)status : (tid == 1 ? 0ll : 0x7FFFFFFFFFFFFFFFll);
-    if (status || defer) return;
-    if (iter >= nm) {  // training is over: this step and the ones behind it do nothing
-        if (blockIdx.x == 0 && tid == 0) st->bk = 0;
-        return;
-    }
-    // ================= LIST mode: one workgroup, table look-ups only =================================
-    if (mode == CH_LIST) {
-        // (Re-scanning the flagged rows here, off the critical path, so that the next FULL selection finds only one
-        // step's worth of them, was tried: +3 us on every LIST step for the 31 extra workgroups, -3 us on a FULL
-        // one -- whose time goes to locating the tied pairs, not to the rows -- and flags must then not be cleared
-        // by a step that merges nothing.  Dropped.)
-        if (blockIdx.x != 0) return;
-        const uint32_t n_old = st->tl_n, skip = st->tl_skip, M = st->tl_M;
-        const uint32_t Kp = st->bk, zp = st->bz0;  // the batch the last step merged: the first `skip` entries
-        const uint32_t n_in = n_old - skip;
-        // every listed pair the batch touched: up to four places its occurrences can have gone to
-        int32_t nx = 0, ny = 0;
-        uint32_t keep = 0;
-        if (tid < n_in) {
-            const int32_t x = st->chain[2 * (skip + tid)], y = st->chain[2 * (skip + tid) + 1];
-            int32_t zx = -1, zy = -1;
-            for (uint32_t p = 0; p < Kp; p++) {
-                if (st->bb[p] == x) zx = (int32_t)(zp + p);
-                if (st->ba[p] == y) zy = (int32_t)(zp + p);
-            }
-            nx = x;
-            ny = y;
-            if (zx < 0 && zy < 0) {
-                keep = 1;  // shares no token that matters: untouched
-            } else {
-                const uint32_t c00 = mat[(size_t)x * stride + y];
-                const uint32_t c10 = zx >= 0 ? mat[(size_t)zx * stride + y] : 0u;
-                const uint32_t c01 = zy >= 0 ? mat[(size_t)x * stride + zy] : 0u;
-                const uint32_t c11 = (zx >= 0 && zy >= 0) ? mat[(size_t)zx * stride + zy] : 0u;
-                if (c00 == M) keep = 1;
-                else if (c10 == M) { keep = 1; nx = zx; }
-                else if (c01 == M) { keep = 1; ny = zy; }
-                else if (c11 == M) { keep = 1; nx = zx; ny = zy; }
-            }
-            s_keep[tid] = keep;
-        }
-        __syncthreads();
-        if (tid < n_in && keep) {
-            uint32_t r = 0;
-            for (uint32_t q = 0; q < tid; q++) r += s_keep[q];
-            s_list[2 * r] = nx;
-            s_list[2 * r + 1] = ny;
-        }
-        if (tid == 0) {
-            uint32_t n = 0;
-            for (uint32_t q = 0; q < n_in; q++) n += s_keep[q];
-            s_nt = n;
-        }
-        __syncthreads();
-        const uint32_t n = s_nt;
-        if (tid < 2 * n) st->chain[tid] = s_list[tid];
-        if (tid == 0) {
-            st->tl_n = n;
-            st->tl_skip = 0;
-            if (n == 0) st->bk = 0;  // the maximum dropped: this step merges nothing, the next one selects
-            else chain_form_batch(st, s_list, n, M, iter, nm, kcap);
-        }
-        return;
-    }
-    // ================= FULL mode ======================================================================
-    const DirtyView D{s_words, s_pref};
-    if (blockIdx.x != 0) {
-        const uint32_t nd = dirty_view_build(dbits, D);
-        if (nd) lean_scan_rows(mat, stride, rowmax, vcur, NOROW, NOROW, NOROW, D, 3 + nd, blockIdx.x - 1, gridDim.x - 1, res, tag,
-                               true, s_red, 3);
-        // workgroups 1 .. CH_KMAX - 1 stay for the deciding workgroup's question: the second largest entry of a row
-        if (!extend || blockIdx.x >= CH_KMAX) return;
-        uint32_t n = 0, rc = 0;
-        if (tid == 0) {
-            if (!granule_get(req, tag, n)) n = 0;  // (never asked: the deciding workgroup reports its own failures)
-            if (blockIdx.x <= n && !granule_get(req + blockIdx.x, tag, rc)) n = 0;
-            s_k = n;
-            s_m2 = rc;
-        }
-        __syncthreads();
-        if (blockIdx.x > s_k) return;
-        const uint32_t x = s_m2 >> 16, y = s_m2 & 0xFFFFu;
-        const uint32_t sec = row_scan_excl(mat + (size_t)x * stride, vcur, y, s_r16);
-        if (tid == 0) granule_put(req + 16 + blockIdx.x, tag, sec);
-        return;
-    }
-    // ---- the deciding workgroup ---------------------------------------------------------------
-    // (whatever happens below, the waiting workgroups get an answer: n = 0 unless rows are to be scanned)
-    auto dismiss = [&]() {
-        if (extend && tid == 0) granule_put(req, tag, 0u);
-    };
-    uint32_t rm[SEL_RPT];
-    select_load(rowmax, vcur, rm);
-    for (uint32_t i = tid; i < 2048; i += 1024) s_bits[i] = 0;
-    if (tid == 0) {
-        s_fail = 0;
-        s_nt = 0;
-        s_stop = 0;
-        s_lv = 0;
-        s_lvn = 0;
-        s_lvfirst = 0;
-        s_lvc = 0;
-        s_more = 0;
-    }
-    const uint32_t nd = dirty_view_build(dbits, D);
-    if (tid == 0) st->sel_ran = 1;  // (this launch re-scans every flagged row)
-    if (nd > CH_EX_CAP) {  // (the other workgroups re-scan them all the same; the general path selects)
-        if (tid == 0) {
-            st->found = 0;
-            st->bk = 0;
-            st->defer = 2;
-        }
-        dismiss();
-        return;
-    }
-    for (uint32_t i = tid; i < nd; i += 1024) {
-        const uint32_t x = dirty_view_row(D, i);
-        uint32_t m = 0, arg = 0;
-        const bool ok = granule_get(res + 2 * (size_t)i, tag, m) && granule_get(res + 2 * (size_t)i + 1, tag, arg);
-        if (!ok) s_fail = 1;
-        s_exrow[i] = x;
-        s_exm[i] = m;
-        s_exarg[i] = arg;
-    }
-    __syncthreads();
-    if (s_fail) {  // a row never arrived: never decide on a stale maximum
-        if (tid == 0) atomicExch(&st->status, ST_LOOKBACK);
-        dismiss();
-        return;
-    }
-    uint32_t M = 0, nt = 0;
-    // s_words (the flag words) is the bitmap of rows whose entry in the row-maxima array is stale
-    select_core(rowmax, mat, stride, vcur, s_tied, s_bits, M, nt, rm, SelExtra{s_words, nd, s_exrow, s_exm, s_exarg});
-    if (M == 0) {  // stats is empty: max() raises ValueError in the reference (F6)
-        if (tid == 0) {
-            st->status = ST_EMPTY;
-            st->count = 0;
-            st->found = 0;
-            st->bk = 0;
-            st->sel_tie = 0;
-        }
-        dismiss();
-        return;
-    }
-    // ---- the list: every tied pair, in order of first occurrence ---------------------------------------
-    if (dpkey && nt > 1 && nt <= TIE_CAP) {
-        // sharded: the tied pairs in canonical order (select_core lists them as its atomics fall), their local first
-        // occurrences into the payload; the list is made by k_chain_sel_dp after the all-reduce
-        uint32_t kx = 0;
-        if (tid < nt) {
-            kx = ((uint32_t)s_tied[2 * tid] << 16) | (uint32_t)s_tied[2 * tid + 1];
-            s_order[tid] = kx;
-        }
-        __syncthreads();
-        if (tid < nt) {
-            uint32_t r = 0;
-            for (uint32_t q = 0; q < nt; q++) r += s_order[q] < kx;
-            s_list[2 * r] = (int32_t)(kx >> 16);
-            s_list[2 * r + 1] = (int32_t)(kx & 0xFFFFu);
-        }
-        __syncthreads();
-        if (tid < 2 * nt) s_tied[tid] = s_list[tid];
-        __syncthreads();
-        const bool objection = gap != 0;
-        if (!objection) (void)tie_by_index(ref, C, s_tied, nt, s_pos);
-        __syncthreads();
-        if (tid == 1 && objection) dpkey[1] = -1ll;
-        if (tid >= 2 && tid - 2 < nt && !objection && s_pos[tid - 2] != NOPOS)
-            dpkey[tid] = (long long)((dprank << 40) | s_pos[tid - 2]);
-        if (tid < 2 * nt) st->chain[tid] = s_tied[tid];
-        if (tid == 0) {
-            st->tl_n = nt;
-            st->tl_M = M;
-            st->tl_skip = 0;
-            st->count = M;
-            st->ntied = nt;
-            st->found = 0;
-            st->bk = 0;
-            st->dp_wait = 1;
-        }
-        dismiss();
-        return;
-    }
-    bool ok = nt <= TIE_CAP && (nt == 1 || gap == 0);
-    if (ok && nt > 1) {
-        (void)tie_by_index(ref, C, s_tied, nt, s_pos);
-        __syncthreads();
-        if (tid < nt && s_pos[tid] == NOPOS) s_fail = 1;  // (a tied pair the index does not lead to: not ours to order)
-        __syncthreads();
-        ok = s_fail == 0;
-        if (ok && tid < nt) {
-            const unsigned long long me = s_pos[tid];
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < nt; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
-            s_order[rank] = tid;
-        }
-    } else if (tid == 0) {
-        s_order[0] = 0;
-    }
-    __syncthreads();
-    if (!ok) {  // too many tied pairs, or short slots about: the general path decides
-        if (tid == 0) {
-            st->count = M;
-            st->ntied = nt;
-            st->found = 0;
-            st->bk = 0;
-            st->defer = 2;
-        }
-        dismiss();
-        return;
-    }
-    if (tid < nt) {
-        s_list[2 * tid] = s_tied[2 * s_order[tid]];
-        s_list[2 * tid + 1] = s_tied[2 * s_order[tid] + 1];
-    }
-    __syncthreads();
-    if (tid < 2 * nt) st->chain[tid] = s_list[tid];
-    if (tid == 0) {
-        st->tl_n = nt;
-        st->tl_M = M;
-        chain_form_batch(st, s_list, nt, M, iter, nm, kcap);
-        const uint32_t k = st->bk;
-        s_k = k;
-        for (uint32_t i = 0; i < k; i++) {
-            s_ba[i] = st->ba[i];
-            s_bb[i] = st->bb[i];
-            s_bc[i] = M;
-        }
-    }
-    __syncthreads();
-    const uint32_t k1 = s_k;
-    const uint32_t kmax = min(kcap, nm - iter);
-    if (!extend || k1 == 0 || k1 != nt || k1 >= kmax) {  // the list goes on (or a == b heads it): nothing below M yet
-        dismiss();
-        return;
-    }
-    // ---- below the maximum: one row maximum per level, while it is unambiguous ---------------------------
-    const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
-    // one pass: single-pair levels from `cur` down, then a tied level; returns that level's count if it was taken whole (the
-    // walk goes on below it: straight-line calls, not a loop -- a back edge here cost 250 bytes of scratch per lane), else 0
-    auto walk = [&](uint32_t cur) -> uint32_t {
-    if (tid == 0) {
-        s_lv = 0;
-        s_more = 0;
-        s_stop = 0;
-    }
-    // (my share of the row maxima again: fetched anew -- loads that hit L2 -- so that these registers are free while
-    // tied pairs are located; held across tie_by_index they were spilled to scratch memory inside its loops.  The
-    // thread number goes through an empty asm so that the twenty addresses are made here, each time, and not hoisted
-    // out of the loop into forty registers that live across it)
-    uint32_t tl = tid;
-    asm volatile("" : "+v"(tl));
-#pragma unroll
-    for (int i = 0; i < SEL_RPT; i++) {
-        const uint32_t x = tl + 1024u * (uint32_t)i;
-        rm[i] = (x < vcur && !((s_words[x >> 5] >> (x & 31)) & 1u)) ? rowma[x].x : 0u;
-    }
-    __syncthreads();
-    for (uint32_t round = s_k; round < kmax; round++) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int i = 0; i < SEL_RPT; i++) m = (rm[i] < cur) ? max(m, rm[i]) : m;
-        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
-            const uint32_t v = ((s_words[x >> 5] >> (x & 31)) & 1u) ? 0u : rowma[x].x;
-            m = (v < cur) ? max(m, v) : m;
-        }
-        for (uint32_t i = tid; i < nd; i += 1024) m = (s_exm[i] < cur) ? max(m, s_exm[i]) : m;
-        m = wave_umax_dpp(m);
-        if (lane_id() == 0) s_r16[wave_id()] = m;
-        if (tid == 0) s_hit = 0;
-        __syncthreads();
-        uint32_t m2 = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) m2 = max(m2, s_r16[w]);
-        if (m2 == 0) break;  // (uniform)
-        // the rows that attain it: exactly one, or the level is not ours to order
-        uint32_t c = 0;
-#pragma unroll
-        for (int i = 0; i < SEL_RPT; i++) {
-            if (rm[i] == m2) {
-                c++;
-                s_m2 = tid + 1024u * (uint32_t)i;  // (read only if the count turns out to be one)
-                s_hitarg = 0xFFFFFFFEu;            // (row-maxima array: the column is fetched below)
-            }
-        }
-        for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
-            if (!((s_words[x >> 5] >> (x & 31)) & 1u) && rowma[x].x == m2) {
-                c++;
-                s_m2 = x;
-                s_hitarg = 0xFFFFFFFEu;
-            }
-        }
-        for (uint32_t i = tid; i < nd; i += 1024) {
-            if (s_exm[i] == m2) {
-                c++;
-                s_m2 = s_exrow[i];
-                s_hitarg = s_exarg[i];
-            }
-        }
-        if (c) atomicAdd(&s_hit, c);
-        __syncthreads();
-        const bool levels = (extend & 2u) && !dpkey && gap == 0;
-        bool tied_level = s_hit != 1;  // (uniform) several rows attain it: a TIED level (taken below, in order of first occurrence)
-        if (!tied_level && levels) {   // ... or one row with several columns
-            uint32_t y = s_hitarg;
-            if (y == 0xFFFFFFFEu) y = rowma[s_m2].y;
-            tied_level = y == ROWARG_MULTI;
-        }
-        if (tied_level) {
-            if (!levels) break;
-            // gather the level's pairs while the row maxima are at hand: a row with one column at m2 gives its pair, a
-            // row with several (ROWARG_MULTI) is scanned afterwards
-            if (tid == 0) {
-                s_nt2 = 0;
-                s_nrows2 = 0;
-            }
-            __syncthreads();
-            auto row_at = [&](uint32_t x, uint32_t y) {
-                if (y != ROWARG_MULTI) {
-                    const uint32_t s = atomicAdd(&s_nt2, 1u);
-                    if (s < TIE_CAP) {
-                        s_tied[2 * s] = (int32_t)x;
-                        s_tied[2 * s + 1] = (int32_t)y;
-                    }
-                } else {
-                    const uint32_t s = atomicAdd(&s_nrows2, 1u);
-                    if (s < 16u) s_rows2[s] = x;
-                }
-            };
-#pragma unroll
-            for (int i = 0; i < SEL_RPT; i++)
-                if (rm[i] == m2) row_at(tl + 1024u * (uint32_t)i, rowma[tl + 1024u * (uint32_t)i].y);
-            for (uint32_t x = tid + 1024u * SEL_RPT; x < vcur; x += 1024) {
-                if ((s_words[x >> 5] >> (x & 31)) & 1u) continue;
-                const uint2 v = rowma[x];
-                if (v.x == m2) row_at(x, v.y);
-            }
-            for (uint32_t i = tid; i < nd; i += 1024)
-                if (s_exm[i] == m2) row_at(s_exrow[i], s_exarg[i]);
-            __syncthreads();
-            const uint32_t nrows2 = s_nrows2;
-            if (nrows2 <= 16u && s_nt2 <= TIE_CAP) {
-                for (uint32_t r = 0; r < nrows2; r++) {
-                    const uint32_t x = s_rows2[r];
-                    const uint32_t *row = mat + (size_t)x * stride;
-                    for (uint32_t y = tid; y < vcur; y += 1024) {
-                        if (row[y] == m2) {
-                            const uint32_t s = atomicAdd(&s_nt2, 1u);
-                            if (s < TIE_CAP) {
-                                s_tied[2 * s] = (int32_t)x;
-                                s_tied[2 * s + 1] = (int32_t)y;
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) s_lv = (nrows2 <= 16u && s_nt2 >= 1u && s_nt2 <= TIE_CAP) ? m2 : 0u;
-            break;
-        }
-        if (tid == 0) {
-            const uint32_t x = s_m2;
-            uint32_t y = s_hitarg;
-            if (y == 0xFFFFFFFEu) y = rowma[x].y;
-            bool clash = (y == ROWARG_MULTI) || (x == y);
-            for (uint32_t i = 0; i < round && !clash; i++)
-                clash = ((int32_t)x == s_ba[i]) | ((int32_t)x == s_bb[i]) | ((int32_t)y == s_ba[i]) | ((int32_t)y == s_bb[i]);
-            if (clash) {
-                s_stop = 1;
-            } else {
-                s_ba[round] = (int32_t)x;
-                s_bb[round] = (int32_t)y;
-                s_bc[round] = m2;
-                s_k = round + 1;
-            }
-        }
-        __syncthreads();
-        if (s_stop) break;
-        cur = m2;
-    }
-    __syncthreads();
-    // ---- a tied level below the maximum (tests/test_level_model.py): every level above it is in the batch, so nothing
-    // outside the batch counts more than its pairs do; they are taken in order of first occurrence until one shares a
-    // token with the batch (a pair a merge of the batch creates reaches this level only by taking over, in place, one
-    // of its pairs that shares a token with the batch -- where the walk stops anyway).  The level's pairs become THE
-    // LIST: the next steps take the rest of it off the list like the pairs tied at a maximum.
-    if (!s_lv) return 0u;  // (uniform)
-    {
-        const uint32_t lv = s_lv;
-        const uint32_t nt2 = s_nt2;  // (1 .. TIE_CAP pairs in s_tied, as the gather's atomics fell)
-        bool ok2 = true;
-        if (ok2 && nt2 > 1) {
-            (void)tie_by_index(ref, C, s_tied, nt2, s_pos);
-            __syncthreads();
-            if (tid < nt2 && s_pos[tid] == NOPOS) s_fail = 1;  // (a pair the index does not lead to: not ours to order)
-            __syncthreads();
-            ok2 = s_fail == 0;
-            if (ok2 && tid < nt2) {
-                const unsigned long long me = s_pos[tid];
-                uint32_t rank = 0;
-                for (uint32_t q = 0; q < nt2; q++) rank += (s_pos[q] < me) | (s_pos[q] == me && q < tid);
-                s_order[rank] = tid;
-            }
-        } else if (tid == 0) {
-            s_order[0] = 0;
-        }
-        __syncthreads();
-        if (ok2) {
-            if (tid < nt2) {
-                s_list[2 * tid] = s_tied[2 * s_order[tid]];
-                s_list[2 * tid + 1] = s_tied[2 * s_order[tid] + 1];
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t k = s_k;
-                s_lvfirst = k;
-                s_lvn = nt2;
-                s_lvc = lv;
-                uint32_t e = 0;
-                for (; e < nt2 && k < kmax; e++) {
-                    const int32_t x = s_list[2 * e], y = s_list[2 * e + 1];
-                    bool clash = x == y;
-                    for (uint32_t i = 0; i < k && !clash; i++) clash = (x == s_ba[i]) | (x == s_bb[i]) | (y == s_ba[i]) | (y == s_bb[i]);
-                    if (clash) break;
-                    s_ba[k] = x;
-                    s_bb[k] = y;
-                    s_bc[k] = lv;
-                    k++;
-                }
-                s_k = k;
-                s_more = (e == nt2 && k < kmax) ? 1u : 0u;  // the whole level is in the batch: the levels below it are next
-            }
-        } else if (tid == 0) {
-            s_fail = 0;  // (the level stays out of the batch; nothing else failed)
-        }
-        __syncthreads();
-        return s_more ? lv : 0u;  // (uniform)
-    }
-    };
-    {
-        uint32_t c = walk(M);
-        if (c) c = walk(c);
-        if (c) c = walk(c);
-        if (c) (void)walk(c);
-    }
-    __syncthreads();
-    const uint32_t k2 = s_k;
-    if (k2 == k1) {
-        dismiss();
-        return;
-    }
-    // ---- entries hidden behind the maxima of the rows taken from: second maxima, by workgroups 1 .. k2 - 1 ------
-    if (tid < k2 - 1) granule_put(req + 1 + tid, tag, ((uint32_t)s_ba[tid] << 16) | (uint32_t)s_bb[tid]);
-    if (tid == 0) granule_put(req, tag, k2 - 1);
-    if (tid < k2 - 1) {
-        uint32_t sec = 0;
-        if (!granule_get(req + 17 + tid, tag, sec)) s_fail = 1;
-        s_sec[tid] = sec;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t m = k1;
-        if (!s_fail) {
-            uint32_t S = 0;
-            for (uint32_t t = 0; t + 1 < k1; t++) S = max(S, s_sec[t]);
-            for (uint32_t t = k1; t < k2; t++) {
-                S = max(S, s_sec[t - 1]);
-                if (S < s_bc[t]) m = t + 1; else break;
-            }
-        }
-        for (uint32_t i = k1; i < m; i++) {
-            st->ba[i] = s_ba[i];
-            st->bb[i] = s_bb[i];
-            st->badj[i] = 0;
-            st->bcnt[i] = s_bc[i];
-        }
-        st->bk = m;
-        // (the list holds the k1 pairs at M only: the batch takes them all, so the next step selects again) -- unless the
-        // batch went into a tied level: then that level's pairs are the list and the batch took the first of them
-        if (s_lvn && m > s_lvfirst) {  // (the LAST tied level entered: s_list still holds its pairs)
-            const uint32_t n = s_lvn;
-            for (uint32_t i = 0; i < 2 * n; i++) st->chain[i] = s_list[i];
-            st->tl_n = n;
-            st->tl_M = s_lvc;
-            st->tl_skip = m - s_lvfirst;  // (more than n when the batch went on below the level: the list is used up)
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Sharded chain steps (api_dp.hip: dp_train_loop).  Per step: k_chain_sel (dpkey) -> MIN all-reduce ->
-// k_chain_sel_dp -> k_merge_chain -> k_dp_fold_chain -> SUM all-reduce -> k_apply_chain (folded payload, status word).
-// k_chain_sel_dp: the list of a FULL selection that found a tie, from the reduced first occurrences (lowest
-// (rank, local position) = earliest in the global stream, F3 / F5); one workgroup.
-__global__ void __launch_bounds__(128)
-k_chain_sel_dp(DevState *st, const long long *__restrict__ key, uint32_t kcap) {
-    __shared__ int32_t s_list[2 * TIE_CAP];
-    __shared__ uint32_t s_bad;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_bad = 0;
-    const uint32_t status = st->status;
-    if (key[0] < 0 && status == 0) {  // some rank failed: every rank stops at this merge
-        if (tid == 0) st->status = ST_INTERNAL;
-        return;
-    }
-    if (status || st->defer || !st->dp_wait) return;
-    const uint32_t nt = st->tl_n, M = st->tl_M;
-    __syncthreads();
-    const long long me = tid < nt ? key[2 + tid] : 0ll;
-    if (tid < nt && me == 0x7FFFFFFFFFFFFFFFll) s_bad = 1;  // a tied pair that no rank holds: not ours to order
-    __syncthreads();
-    if (key[1] < 0 || s_bad) {  // (some rank has short slots about: the general path decides, on every rank)
-        if (tid == 0) {
-            st->found = 0;
-            st->bk = 0;
-            st->defer = 2;
-            st->dp_wait = 0;
-        }
-        return;
-    }
-    if (tid < nt) {
-        uint32_t r = 0;
-        for (uint32_t q = 0; q < nt; q++) r += key[2 + q] < me;  // (distinct: two pairs never share a first occurrence)
-        s_list[2 * r] = st->chain[2 * tid];
-        s_list[2 * r + 1] = st->chain[2 * tid + 1];
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < 2 * nt; i += 128) st->chain[i] = s_list[i];  // (up to 192 words, 128 threads)
-    if (tid == 0) {
-        st->dp_wait = 0;
-        chain_form_batch(st, s_list, nt, M, st->iter, st->num_merges, kcap);
-    }
-}
+// Sharded chain steps (api_dp.hip: dp_train_loop).  Per step: k_pool_sel (dpkey; k_pool.hip) -> MIN all-reduce ->
+// k_pool_sel_dp -> k_merge_chain -> k_dp_fold_chain -> SUM all-reduce -> k_apply_chain (folded payload, status word).
 // k_dp_fold_chain: this rank's delta of the step's batch, folded over its replica blocks into the SUM payload:
 // pair p's SL at folded[2p S ..), its SR at folded[(2p + 1) S ..), S = the payload's vector stride (>= every id in
 // use + 1); tail = folded + 2 kcap S: [p] = format B's adj of pair p (p < 16), [16] = 1 if this rank's status is raised (the

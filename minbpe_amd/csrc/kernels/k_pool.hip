@@ -1,10 +1,10 @@
 // k_pool.hip -- K2 of a chain step, third form: THE POOL.
 //
-// k_chain_sel (k_chain.hip) keeps the pairs tied at the maximum as a list and needs a FULL selection -- every flagged
-// row re-scanned, the row maxima read, the tied pairs located through the index -- once per count level, ~25 us against
-// ~5 us for a step that takes its pairs off the list; and only a FULL selection can walk below its level.  Late in
-// training a level holds three or four pairs, so most steps are FULL ones and most batches are cut short by the end of
-// their level, not by a shared token.
+// Rounds 4-5's selection (k_chain_sel, retired in round 6) kept the pairs tied at the maximum as a list and needed a FULL
+// selection -- every flagged row re-scanned, the row maxima read, the tied pairs located through the index -- once per count
+// level, ~25 us against ~5 us for a step that took its pairs off the list; and only a FULL selection could walk below its
+// level.  Late in training a level holds three or four pairs, so most steps were FULL ones and most batches were cut short by
+// the end of their level, not by a shared token.
 //
 // The pool is the list generalised to EVERY pair that counts at least a threshold theta (tests/test_pool_model.py: the
 // CPU model of exactly this, against the reference semantics of base.py:13-41, basic.py:31-42, regex.py:49-63):

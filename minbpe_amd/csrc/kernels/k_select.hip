@@ -92,7 +92,7 @@ __device__ __forceinline__ uint64_t view_tile(const SlotRefH &) { return TILE2; 
 // several columns (ROWARG_MULTI) is scanned.
 // select_core leaves the result in LDS / registers (every thread gets M and the number of tied
 // pairs, TIE_CAP + 1 = too many to list; the pairs are in s_tied); select_body also writes it to st.
-constexpr int SEL_RPT = 20;  // 20 x 1024 row maxima in registers; rows beyond (vocab > 20480) are read twice (L2 hits).  32 left k_chain_sel
+constexpr int SEL_RPT = 20;  // 20 x 1024 row maxima in registers; rows beyond (vocab > 20480) are read twice (L2 hits).  32 left the selection kernels
                                // (128 VGPRs at 1024 threads) ten of them in scratch memory, reloaded one by one inside select_core
 // A lean iteration re-scans a few rows in the same launch that selects (k_rowsel_lean, k_lean.hip):
 // those rows are EXCLUDED from the row-maxima array (a bitmap in LDS) and come in as extra
@@ -125,7 +125,7 @@ __device__ __forceinline__ void select_core(const uint32_t *__restrict__ rowmax,
     const uint2 *__restrict__ rowma = reinterpret_cast<const uint2 *>(rowmax);
     constexpr int RPT = SEL_RPT;
     auto excluded = [&](uint32_t x) -> bool { return E.excl && ((E.excl[x >> 5] >> (x & 31)) & 1u); };
-    // `below` (k_chain_sel's second look, at a level under the maximum): row maxima of `below` or more do not count --
+    // `below` (a second look, at a level under the maximum): row maxima of `below` or more do not count --
     // their pairs are already taken
     auto capped = [&](uint32_t v) -> uint32_t { return v < below ? v : 0u; };
     uint32_t m = 0;

@@ -434,14 +434,11 @@ def test_repack_policy_vs_oracle(engine, native, kind, acc):
 
 
 CHAIN_OPTIONS = [
-    (("pool", 0),),                                  # round 4's selection: the list of the pairs tied at the maximum
-    (("pool", 0), ("chain_levels", 1)),              # ... walking into tied levels
-    (("pool", 0), ("chain_levels", 1), ("chain_list", 0)),
     (("chain_kcap", 1),), (("chain_kcap", 4),), (("chain_kcap", 8),),   # batches of one, four, eight (default 15)
     (("count_is_removed", 0),),                      # the ids a merge removes are counted, not taken from the pair's count
     (("chain_prefetch", 0),),                        # no register prefetch of the next candidate slot
     (("small_slots", 0),), (("small_slots", 2),),    # 1024-id slots throughout / 256-id slots from the first index build
-    (("small_slots", 2), ("pool", 0)), (("small_slots", 2), ("chain_kcap", 2), ("pool_hint", 64)),
+    (("small_slots", 2), ("chain_kcap", 2), ("pool_hint", 64)),
     (("chain_scan", 1),), (("chain_scan", 127),),    # one / 127 scanning workgroups in a pool rebuild
     # a step as ONE launch (k_step: selection -> published batch -> merge pass -> grid barrier -> table update) instead of three
     (("fuse_step", 1),), (("fuse_step", 1), ("chain_kcap", 4)), (("fuse_step", 1), ("count_is_removed", 0)),
@@ -454,7 +451,7 @@ CHAIN_OPTIONS = [
 @pytest.mark.parametrize("opts", CHAIN_OPTIONS)
 @pytest.mark.parametrize("kind", ["regex", "ties"])
 def test_chain_step_options_cross_check(engine, native, kind, opts):
-    """Every option of the chain steps -- the pool against the list it replaced, batch caps, the removal counters, the
+    """Every option of the chain steps -- batch caps, the removal counters, the
     slot prefetch, both slot geometries, the number of scanning workgroups -- gives the oracle's merges: on a GPT-4-split
     text with every merge a chain step through the index (sparse = 2, lean = 2), and on a three-letter corpus where nearly
     every level is a tie, a == b pairs head the pool again and again and the table runs empty."""
@@ -468,7 +465,7 @@ def test_chain_step_options_cross_check(engine, native, kind, opts):
         offs = np.cumsum([0] + [len(c) for c in chunks[:-1]]).astype(np.uint64)
         nm = 400
     exp = oracle.train(data, nm, offs, raise_on_empty=False)
-    defaults = {"pool": 1, "chain_levels": 0, "chain_list": 1, "chain_kcap": 15, "count_is_removed": 1, "chain_prefetch": 1,
+    defaults = {"chain_kcap": 15, "count_is_removed": 1, "chain_prefetch": 1,
                 "small_slots": 1, "pool_hint": 0, "chain_scan": 63, "fuse_step": 0, "lean_grid": 256}
     set_variant(engine, 1, 0, 2, 2, 7)
     try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of engine option sets on one of bench.py's workloads, ONE upload for all of them:
-    python tools/ab_opts.py regex1g "" "chain_levels=1" "chain_levels=1 chain_list=0"
+    python tools/ab_opts.py regex1g "" "chain_kcap=8" "chain_kcap=8 chain_prefetch=0"
 Per set: wall time of a plain train() (best of REPS), the step statistics, the kernel-class breakdown (profile 2),
 per-phase device time (want_iter_ms) and the parity verdict against the committed golden digests of the workload
 (bench.parity_report).  Options are reset to OPT_RESET's values between sets ("name=value ...": the defaults of the
