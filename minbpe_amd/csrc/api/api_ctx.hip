@@ -61,7 +61,7 @@ struct bpe_ctx {
     uint32_t *d_dirty_list = nullptr;  // rows whose rowmax must be recomputed
     uint32_t *d_dirty_n = nullptr;
     int depth = 8;  // iterations the host may run ahead of the device
-    int repack_acc = 150;  // option "repack_acc": 0 = re-pack the dense phase's slots when their fill drops below 31/32; N = when the
+    int repack_acc = 200;  // option "repack_acc": 0 = re-pack the dense phase's slots when their fill drops below 31/32; N = when the
                          // empty fractions of the sweeps since the last re-pack add up to N/100 of a sweep (what a re-pack costs)
     double repack_waste = 0.0;
     // slotted stream (training loop, a != b merges)
@@ -149,7 +149,7 @@ struct bpe_ctx {
     int pool_hint = 0;                        // option "pool_hint": a rebuild is announced when fewer untouched entries than this are left (0: the step's cap)
     PoolEnt *d_pool = nullptr;                // ... its entries (PL_CAP) and the pairs a rebuild gathers (counter, pad, PL_GATHER x {pair, count})
     uint32_t *d_pool_gather = nullptr;
-    int chain_scan = 63;                      // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
+    int chain_scan = 127;                     // option "chain_scan": workgroups that re-scan flagged rows in a chain step's FULL selection (a level of
                                               // n merges leaves ~3 n rows to re-scan, one 128 KB row per workgroup at a time)
     int chain = 1;                            // option "chain": 1 = chain steps (k_chain.hip: the tied pairs kept as a list, batches of
                                               // token-disjoint pairs merged in one pass) instead of lean iterations, wherever those would run with the index live

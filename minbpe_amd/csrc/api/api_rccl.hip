@@ -229,7 +229,7 @@ int dp_train_loop(bpe_ctx *c, int32_t num_merges, const DpComm &comm, int32_t *p
             // id below LDSD_CAP: the delta through LDS tables), ties left to the general path
             const int hi_dense = std::min(num_merges, done + (int)q.size() * CH_KDENSE + CH_KDENSE);
             const bool want_dense = !want_chain && c->chain && c->chain_dense && c->lean && c->lds_delta && i > 0 &&
-                                    i >= general_until && c->last_count != ~0ull && 256 + hi_dense + 1 <= LDSD_CAP;
+                                    i >= general_until && c->last_count != ~0ull && 256 + hi_dense + 1 <= (int)CH_DCAP;
             const bool known = n_chain_inflight == 0;
             if (want_dense && (known || in_chain)) {
                 c->vcur = 256u + (uint32_t)std::min(i, num_merges - 1);

@@ -282,7 +282,7 @@ int bpe_train(bpe_ctx *c, int32_t num_merges, int32_t *pairs_out, uint64_t *coun
                 const int hi_dense = std::min(num_merges, done + (int)q.size() * CH_KDENSE + CH_KDENSE);
                 const bool chain_dense = !lean && delta && c->chain && c->chain_dense && c->lean && c->lds_delta && c->slotted &&
                                          c->slot2 && !c->idx_live && !sparse && !full_rowmax && i >= general_until &&
-                                         256 + hi_dense + 1 <= LDSD_CAP;
+                                         256 + hi_dense + 1 <= (int)CH_DCAP;
                 const bool chain = chain_dense ||
                                    (lean && c->chain && c->lean_select && c->idx_live && c->tie_index && !full_rowmax);
                 Unit u{U_GENERAL, i, 0u, 0, 0, 0, -1};

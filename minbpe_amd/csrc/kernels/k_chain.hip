@@ -62,10 +62,14 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
 // One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip) for K >= 2 token-disjoint pairs at
 // once.  DENSE == false: the sparse form (staged headers, global delta replicas, index live).  DENSE == true: the
 // early passes, where every slot is visited and a pair has millions of sites: headers go to the other header array,
-// the delta into the workgroup's LDS tables sd (per pair p, at sd + p * CH_SD: SL[LDSD_CAP] | SR[LDSD_CAP] | adj |
-// ids removed; every id is below LDSD_CAP), flushed by the kernel when its slots are done.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
+// the delta into the workgroup's LDS tables sd (per pair p, at sd + p * CH_SD: SL[CH_DCAP] | SR[CH_DCAP] | adj |
+// ids removed; every id is below CH_DCAP), flushed by the kernel when its slots are done.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
 // pb1[0] a word that matches nothing, z0: pair p becomes z0 + p.
-constexpr uint32_t CH_SD = 2 * LDSD_CAP + 2;  // words of one pair's LDS delta tables
+// (the tables of a DENSE chain step cover ids below CH_DCAP, not LDSD_CAP: the dense phase ends when the index comes up --
+// merge ~300 of a 1 GB stream -- and a table of 1024 ids lets eight pairs' tables fit beside the sixteen waves' staging,
+// where 1920 ids allowed four; a stream whose dense phase outlasts id 1024 goes on with the general path's single merges)
+constexpr uint32_t CH_DCAP = 1024;
+constexpr uint32_t CH_SD = 2 * CH_DCAP + 2;  // words of one pair's LDS delta tables
 // the loads of a slot that depend on nothing but its number: its words (speculatively from buffer 0, where a slot lives
 // unless an a == b pass moved it) and the headers of slots t - 1, t, t + 1 as six 16-byte pieces on lanes 0..5
 __device__ __forceinline__ void chain_slot_load(const AbArgs &A, const uint32_t t, uint4 (&rv)[MJ], uint4 &hv) {
@@ -355,8 +359,8 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
             uint32_t *dl, *dr;  // SL, SR of pair p
             if (DENSE) {
                 dl = sd + p * CH_SD;
-                dr = dl + LDSD_CAP;
-                atomicAdd(&dl[2 * LDSD_CAP + 1], 1u);
+                dr = dl + CH_DCAP;
+                atomicAdd(&dl[2 * CH_DCAP + 1], 1u);
             } else {
                 // ids removed, per pair: every site is counted by the slot that owns its first word (one atomic per
                 // site, CH_RMV counters per pair)
@@ -385,7 +389,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
             const uint32_t R = k2 ? (k1 ? W[6] : W[5]) : (k1 ? W[4] : W[3]);
             if (!(R & FLAG)) {  // (INVALID_WORD has the flag bit set: end of stream)
                 if (ri == (int)p) {
-                    if (DENSE) atomicAdd(&dl[2 * LDSD_CAP], wt);
+                    if (DENSE) atomicAdd(&dl[2 * CH_DCAP], wt);
                     else atomicAdd(&A.st->badj[p], wt);
                 } else {
                     atomicAdd(&dr[(ri >= 0 && (uint32_t)ri < p) ? z0 + (uint32_t)ri : (R & IDMASK)], wt);
@@ -606,7 +610,7 @@ k_merge_chain(AbArgs A, const uint32_t *__restrict__ idx_dirty, uint32_t use_ind
 // A batch of K pairs costs ONE sweep over the stream instead of K.  One 1024-thread workgroup per CU, wave w of the
 // grid takes slots w, w + waves, ...; every slot's header is written to the other header array (the host flips the
 // arrays after every dense step -- a step that merges nothing copies the headers across, so that the flip stands).
-constexpr int CH_KDENSE = 4;  // most pairs of a dense step's batch: their LDS tables must fit next to the staging
+constexpr int CH_KDENSE = 6;  // most pairs of a dense step's batch: their LDS tables must fit next to the staging (8 pairs measured no faster than 6; the first-token look-up table of the sparse pass measured no faster than K compares here)
 static_assert((LEAN_MT / 64) * TILE2 * 4 + CH_KDENSE * (int)CH_SD * 4 + 256 <= 160 * 1024, "dense chain pass: LDS");
 __global__ void __launch_bounds__(LEAN_MT)
 k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
@@ -651,18 +655,18 @@ k_merge_chain_dense(AbArgs A, uint32_t *__restrict__ dbits) {
     __syncthreads();
     // flush: the tables of pair p into one of its CH_RSTRIDE replica blocks
     const uint32_t vc = A.vcap & 0xFFFFFFu;
-    const uint32_t lim = min(vc, (uint32_t)LDSD_CAP);
+    const uint32_t lim = min(vc, (uint32_t)CH_DCAP);
     for (uint32_t p = 0; p < K; p++) {
         const uint32_t *sd = s_sd + p * CH_SD;
         // (as many replica blocks per pair as the table update will fold: st->brep)
         uint32_t *g = A.delta + delta_rep_off(p * (uint32_t)CH_RSTRIDE + (blockIdx.x & (brep - 1u)), vc);
         for (uint32_t i = threadIdx.x; i < lim; i += LEAN_MT) {
-            const uint32_t l = sd[i], r = sd[LDSD_CAP + i];
+            const uint32_t l = sd[i], r = sd[CH_DCAP + i];
             if (l) atomicAdd(&g[i], l);
             if (r) atomicAdd(&g[vc + i], r);
         }
         if (threadIdx.x == 0) {
-            const uint32_t adj = sd[2 * LDSD_CAP], rem = sd[2 * LDSD_CAP + 1];
+            const uint32_t adj = sd[2 * CH_DCAP], rem = sd[2 * CH_DCAP + 1];
             if (adj) atomicAdd(&st->badj[p], adj);
             if (rem && A.removed) atomicAdd(&A.removed[(p * (uint32_t)CH_RMV + (blockIdx.x & (uint32_t)(CH_RMV - 1))) * REMOVED_STRIDE], rem);
         }

@@ -412,7 +412,7 @@ def test_encode_batch_repeated_and_unaligned_chunks(engine, native, cache, bits)
     assert np.array_equal(out_off, exp_off)
 
 
-@pytest.mark.parametrize("acc", [0, 5, 150, 10000])
+@pytest.mark.parametrize("acc", [0, 5, 200, 10000])
 @pytest.mark.parametrize("kind", ["basic", "regex"])
 def test_repack_policy_vs_oracle(engine, native, kind, acc):
     """Option repack_acc (when the dense phase re-packs its slots: at a fixed fill of 31/32, after nearly every sweep,
@@ -430,7 +430,7 @@ def test_repack_policy_vs_oracle(engine, native, kind, acc):
         assert res["pairs"] == exp[0] and res["counts"] == exp[1] and res["lens"] == exp[2]
         assert engine.train_stats()["dense"] > 0
     finally:
-        engine.set_option("repack_acc", 150)
+        engine.set_option("repack_acc", 200)
 
 
 CHAIN_OPTIONS = [
@@ -439,7 +439,7 @@ CHAIN_OPTIONS = [
     (("chain_prefetch", 0),),                        # no register prefetch of the next candidate slot
     (("small_slots", 0),), (("small_slots", 2),),    # 1024-id slots throughout / 256-id slots from the first index build
     (("small_slots", 2), ("chain_kcap", 2), ("pool_hint", 64)),
-    (("chain_scan", 1),), (("chain_scan", 127),),    # one / 127 scanning workgroups in a pool rebuild
+    (("chain_scan", 1),), (("chain_scan", 63),), (("chain_scan", 255),),    # one / 63 / 255 scanning workgroups in a pool rebuild (default 127)
     # a step as ONE launch (k_step: selection -> published batch -> merge pass -> grid barrier -> table update) instead of three
     (("fuse_step", 1),), (("fuse_step", 1), ("chain_kcap", 4)), (("fuse_step", 1), ("count_is_removed", 0)),
     (("fuse_step", 1), ("small_slots", 2)), (("fuse_step", 1), ("small_slots", 0)),
@@ -466,7 +466,7 @@ def test_chain_step_options_cross_check(engine, native, kind, opts):
         nm = 400
     exp = oracle.train(data, nm, offs, raise_on_empty=False)
     defaults = {"chain_kcap": 15, "count_is_removed": 1, "chain_prefetch": 1,
-                "small_slots": 1, "pool_hint": 0, "chain_scan": 63, "fuse_step": 0, "lean_grid": 256}
+                "small_slots": 1, "pool_hint": 0, "chain_scan": 127, "fuse_step": 0, "lean_grid": 256}
     set_variant(engine, 1, 0, 2, 2, 7)
     try:
         for k, v in opts:
