@@ -598,8 +598,9 @@ def run_encode_workload(eng, steps, warmup, barrier, pairs=None, tables=("cfg3",
 def run_encode_long_workload(eng, pairs=None, n_docs=100_000):
     """The encode paths the 1 M-document batch does not reach (its synthetic prose holds no chunk above 32 bytes):
     (1) `long_chunks`: n_docs documents of the same text with URLs, identifiers, whitespace runs and letter noise spliced
-    in -- at least 1 % of the GPT-4-split chunks are 33 .. 4096 bytes (one wave per chunk with the chunk in LDS, k_enc_long)
-    and a few are longer (stream-wide rounds) -- the whole batch against oracle.encode;
+    in -- at least 1 % of the GPT-4-split chunks are 33 .. 4096 bytes (one or four waves per chunk with the chunk in LDS,
+    k_enc_long) and a few are longer (up to 9001 bytes: the sixteen-wave instantiation, up to 9216; beyond that the
+    stream-wide rounds) -- the whole batch against oracle.encode;
     (2) `basic_100mb`: BasicTokenizer.encode (basic.py:57-74: ONE chunk) of the 100 MB of configs[1] with its own 3840
     merges.  oracle.encode is O(N x rounds) on one chunk (hours at this size): the answer is checked in full against the
     stream TRAINING leaves resident for the same text (training applies the merges in order, which is encode of its own

@@ -185,8 +185,8 @@ struct bpe_ctx {
     uint32_t *d_enc_tmp = nullptr, *d_enc_len = nullptr;
     int32_t *d_enc_out = nullptr;
     unsigned long long *d_enc_off = nullptr, *d_enc_bsum = nullptr, *d_enc_long = nullptr;
-    unsigned long long *d_enc_huge = nullptr;  // chunks of more than ENC_LONG_MAX bytes: the stream-wide rounds' (k_enc_long hands them on)
-    int enc_long = 1;                          // option "enc_long": chunks of ENC_LMAX + 1 .. ENC_LONG_MAX bytes are encoded on the device, one wave
+    unsigned long long *d_enc_huge = nullptr;  // chunks of more than ENC_LONG_TOP bytes: the stream-wide rounds' (k_enc_long hands them on)
+    int enc_long = 1;                          // option "enc_long": chunks of ENC_LMAX + 1 .. ENC_LONG_TOP bytes are encoded on the device, one wave
                                                // per chunk (k_enc_long); 0 = all of them through the stream-wide rounds (round 4's path, a cross-check)
     unsigned long long *d_ht_keys = nullptr;
     uint32_t *d_ht_vals = nullptr;

@@ -242,7 +242,7 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
                            c->d_enc_long, d_nlong);
     LAUNCHCHK(c, "k_encode_short");
     // 5. chunks of more than ENC_LMAX bytes: one wave per chunk with the chunk in LDS (k_enc_long), straight off the list
-    // pass 1 made -- its length stays on the device; what is longer than ENC_LONG_MAX goes on to d_enc_huge
+    // pass 1 made -- its length stays on the device; what is longer than ENC_LONG_TOP goes on to d_enc_huge
     if (c->enc_long) {
         const unsigned glong = (unsigned)std::min<uint64_t>(n / (ENC_LMAX + 1) + 1, (uint64_t)c->num_cus * 16);
         hipLaunchKernelGGL((k_enc_long<ENC_LONG_MID, 64>), dim3(glong), dim3(64), 0, c->stream, c->d_bytes, d_offs, n_chunks, n,
@@ -251,6 +251,10 @@ int encode_batch_impl(bpe_ctx *c, const int32_t *merges, const int32_t *merge_id
         hipLaunchKernelGGL((k_enc_long<ENC_LONG_MAX, 256>), dim3(std::min(glong, (unsigned)c->num_cus * 2)), dim3(256), 0, c->stream,
                            c->d_bytes, d_offs, n_chunks, n, c->d_enc_long, d_nlong, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
                            c->d_enc_tmp, c->d_enc_len, c->d_enc_huge, d_nhuge, (uint32_t)ENC_LONG_MID);
+        // (a whole CU's LDS per chunk: one workgroup per CU)
+        hipLaunchKernelGGL((k_enc_long<ENC_LONG_TOP, 1024>), dim3(std::min(glong, (unsigned)c->num_cus)), dim3(1024), 0, c->stream,
+                           c->d_bytes, d_offs, n_chunks, n, c->d_enc_long, d_nlong, c->d_ht_keys, c->d_ht_vals, mask, d_mids,
+                           c->d_enc_tmp, c->d_enc_len, c->d_enc_huge, d_nhuge, (uint32_t)ENC_LONG_MAX);
         LAUNCHCHK(c, "k_enc_long");
     }
     TRY(prof_end(c));

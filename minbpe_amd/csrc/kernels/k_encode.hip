@@ -696,8 +696,8 @@ k_long_scatter(const uint32_t *__restrict__ ids, const unsigned long long *__res
 }
 
 // ---------------------------------------------------------------------------
-// Long chunks on the device (lengths ENC_LMAX + 1 .. ENC_LONG_MAX bytes: URLs, code, whitespace runs): one workgroup
-// per chunk -- ONE WAVE up to ENC_LONG_MID bytes, four waves beyond --, the chunk's tokens and the ranks of its adjacent
+// Long chunks on the device (lengths ENC_LMAX + 1 .. ENC_LONG_TOP bytes: URLs, code, whitespace runs): one workgroup
+// per chunk -- ONE WAVE up to ENC_LONG_MID bytes, four up to ENC_LONG_MAX, sixteen beyond --, the chunk's tokens and the ranks of its adjacent
 // pairs in LDS.  A round is what one iteration of the reference's loop does (regex.py:92-109 == basic.py:57-74): the
 // lowest rank present (a minimum over the rank array), every occurrence of that pair merged left to right (an a == a
 // run is walked by the thread that owns its start: the greedy pairing of base.py:25-41), the survivors compacted into
@@ -706,7 +706,9 @@ k_long_scatter(const uint32_t *__restrict__ ids, const unsigned long long *__res
 // launch works through the list pass 1 left (its length is read on the device); CAP = the most bytes this
 // instantiation takes, chunks of `lo` bytes or fewer belong to a smaller one, longer ones go on to `huge_list` (the
 // stream-wide rounds of api_encode.hip: a BasicTokenizer text is one such chunk).
-constexpr uint32_t ENC_LONG_MID = 512, ENC_LONG_MAX = 4096;
+// (three instantiations: one wave up to ENC_LONG_MID bytes, four up to ENC_LONG_MAX, sixteen up to ENC_LONG_TOP -- 9 KiB: what
+// two token and two rank buffers of a chunk leave of a CU's 160 KB of LDS)
+constexpr uint32_t ENC_LONG_MID = 512, ENC_LONG_MAX = 4096, ENC_LONG_TOP = 9216;
 template <uint32_t CAP, uint32_t NT>
 __global__ void __launch_bounds__(NT)
 k_enc_long(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, uint64_t n_chunks, uint64_t n,
@@ -715,7 +717,9 @@ k_enc_long(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, 
            const int32_t *__restrict__ merge_ids, uint32_t *__restrict__ tmp, uint32_t *__restrict__ outlen,
            unsigned long long *__restrict__ huge_list, unsigned long long *__restrict__ n_huge, uint32_t lo) {
     constexpr uint32_t NW = NT / 64, NB = CAP / 64;  // waves; groups of 64 positions (one ballot each)
-    static_assert(NB <= 64 && CAP % NT == 0, "one wave scans the ballots' counts");
+    constexpr uint32_t NG = (NB + 63) / 64;  // groups whose counts one lane of wave 0 scans
+    static_assert(CAP % NT == 0 && CAP % 64 == 0, "whole groups of 64 positions");
+    static_assert((2 * 2 * 4 + 1) * CAP + 4 * NB + 4 * NW + 64 <= 160 * 1024, "the chunk's buffers in LDS");
     __shared__ uint32_t s_tok[2][CAP], s_rk[2][CAP];
     __shared__ uint8_t s_fl[CAP];
     __shared__ uint32_t s_cnt[NB], s_red[NW], s_len;
@@ -737,7 +741,7 @@ k_enc_long(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, 
         const uint64_t e0 = (c + 1 < n_chunks) ? off[c + 1] : n;
         const uint64_t Lb = e0 - s0;
         if (Lb <= lo || Lb > CAP) {  // (uniform) not this instantiation's
-            if (CAP == ENC_LONG_MAX && Lb > CAP && tid == 0) huge_list[atomicAdd(n_huge, 1ull)] = c;
+            if (CAP == ENC_LONG_TOP && Lb > CAP && tid == 0) huge_list[atomicAdd(n_huge, 1ull)] = c;
             continue;
         }
         uint32_t L = (uint32_t)Lb, cur = 0;
@@ -784,10 +788,22 @@ k_enc_long(const uint8_t *__restrict__ bytes, const uint64_t *__restrict__ off, 
                 if (lane == 0) s_cnt[g] = (uint32_t)__popcll(bal);
             }
             sync();
-            if (wave == 0) {
-                const uint32_t v = lane < ngroups ? s_cnt[lane] : 0u;
+            if (wave == 0) {  // (lane l scans groups NG l .. NG l + NG - 1)
+                uint32_t loc[NG], v = 0;
+#pragma unroll
+                for (uint32_t g = 0; g < NG; g++) {
+                    const uint32_t i = lane * NG + g;
+                    loc[g] = i < ngroups ? s_cnt[i] : 0u;
+                    v += loc[g];
+                }
                 const uint32_t inc = wave_iscan_add(v);
-                if (lane < ngroups) s_cnt[lane] = inc - v;
+                uint32_t run = inc - v;
+#pragma unroll
+                for (uint32_t g = 0; g < NG; g++) {
+                    const uint32_t i = lane * NG + g;
+                    if (i < ngroups) s_cnt[i] = run;
+                    run += loc[g];
+                }
                 if (lane == 63) s_len = inc;
             }
             sync();

@@ -516,6 +516,9 @@ def _long_chunk_text(native, seed):
                                             int(rng.integers(500, 6000)))))
         if i % 37 == 9:
             parts.append(" " * int(rng.integers(34, 900)) + "\n")
+        if i % 997 == 13:  # 4097 .. 9216 bytes (sixteen waves per chunk), and beyond (the stream-wide rounds)
+            parts.append("".join(rng.choice(list("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"),
+                                            int(rng.integers(6000, 11000)))))
     return " ".join(parts)
 
 
@@ -523,13 +526,14 @@ def _long_chunk_text(native, seed):
 @pytest.mark.parametrize("cache", [1, 0])
 def test_encode_batch_long_chunks_on_the_device(engine, native, cache, enc_long):
     """Chunks of more than 32 bytes (regex.py:92-109 on URLs, identifiers, whitespace runs): one wave per chunk with
-    the chunk in LDS (k_enc_long, lengths up to 512 and up to 4096 bytes), the stream-wide rounds beyond that -- and
+    the chunk in LDS (k_enc_long, lengths up to 512, 4096 and 9216 bytes), the stream-wide rounds beyond that -- and
     option enc_long = 0, every long chunk through the rounds -- all equal to oracle.encode."""
     pairs = _train_pairs(native, 300_000, 900, 61, "regex")
     text = _long_chunk_text(native, 62)
     data, offs = split_chunks(text)
     lens = np.diff(np.append(offs, len(data)))
-    assert (lens > 32).sum() > 300 and (lens > 512).sum() > 20 and (lens > 4096).sum() >= 3
+    assert (lens > 32).sum() > 300 and (lens > 512).sum() > 20 and (lens > 4096).sum() >= 3 and (lens > 9216).sum() >= 1
+    assert ((lens > 4096) & (lens <= 9216)).sum() >= 3
     exp_ids, exp_off = oracle.encode(pairs, data, offs)
     engine.set_option("enc_cache", cache)
     engine.set_option("enc_long", enc_long)
