@@ -59,7 +59,7 @@ WORKLOADS = {
 }
 
 
-HOST_ONLY_SOURCES = ("synth.cpp", "split.cpp", "dedup.cpp", "unicode_tables.h")
+HOST_ONLY_SOURCES = ("synth.cpp", "split.cpp", "dedup.cpp", "unicode_tables.h", "utf8.cpp")
 
 
 def source_hash():

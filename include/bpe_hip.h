@@ -258,6 +258,14 @@ int bpe_train_stats(bpe_ctx *ctx, uint64_t *out4);
  * "fuse_step").  Writes min(n, 11) values. */
 int bpe_train_stats_ex(bpe_ctx *ctx, uint64_t *out, int n);
 
+/* ---- text.encode("utf-8") by all host threads (host, no GPU needed) ------------------ */
+/* The first statement of every train() / encode() of the reference (basic.py:25, regex.py:44): an array of code
+ * points of `kind` = 1, 2 or 4 bytes each (what a CPython str holds) as UTF-8, counted and written by segments in
+ * parallel.  out may be NULL to only count (*n_bytes); BPE_E_CAP if cap is too small; BPE_E_ARG on a lone surrogate
+ * or a value above 0x10FFFF (str.encode raises there: the caller leaves such a text to it).  threads <= 0: all cores. */
+int bpe_utf8_encode(int kind, const void *code_points, uint64_t n_chars, uint8_t *out, uint64_t cap,
+                    uint64_t *n_bytes, int threads);
+
 /* ---- native pre-split (host, no GPU needed) ----------------------------- */
 /* regex.findall(pattern, text) for the two GPT split patterns (regex.py:18-19, 41, 114),
  * as chunk START byte offsets into the UTF-8 text.  which: 2 = GPT-2 pattern, 4 = GPT-4

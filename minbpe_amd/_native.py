@@ -100,6 +100,7 @@ _SIGS = {
     "bpe_encode_uses_16bit": (C.c_int, [_p, C.c_int32]),
     "bpe_train_stats": (C.c_int, [_p, _p]),
     "bpe_train_stats_ex": (C.c_int, [_p, _p, C.c_int]),
+    "bpe_utf8_encode": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_split": (C.c_int, [C.c_int, _p, _u64, _p, _u64, C.POINTER(_u64), C.c_int]),
     "bpe_dedup_chunks": (C.c_int, [_p, _u64, _p, _u64, _p, _p, _p, C.POINTER(_u64), C.POINTER(_u64),
                                   C.POINTER(_u64), C.c_int]),
@@ -129,6 +130,35 @@ def synth_text(n: int, seed: int) -> bytes:
     if rc != BPE_OK:
         raise RuntimeError(f"bpe_synth_text failed: {rc}")
     return buf.tobytes()
+
+
+def utf8_encode(text: str, threads: int = 0):
+    """text.encode("utf-8") (basic.py:25, regex.py:44) -- by all host threads for a long text: CPython encodes with one
+    thread, 0.7 s per GB of a str with characters beyond the BMP, more than the device side of a whole train().  A
+    compact CPython str is a header followed by its code points, 1, 2 or 4 bytes each; the library transcodes them in
+    place (bpe_utf8_encode).  The layout is checked, not assumed: interpreter and version, the object's state bits, its
+    size, and the first and last code points read through the pointer against the str itself -- anything that does not
+    fit (another interpreter, a non-compact or short or ASCII str, a lone surrogate) goes to str.encode.  Returns bytes
+    or a uint8 array (both are buffers: what every consumer here takes)."""
+    n = len(text)
+    if n < (1 << 22) or sys.implementation.name != "cpython" or sys.version_info[:2] != (3, 10) or type(text) is not str:
+        return text.encode("utf-8")
+    state = C.c_uint8.from_address(id(text) + 32).value  # PyASCIIObject.state: interned:2 kind:3 compact:1 ascii:1 ready:1
+    kind, compact, ascii_, ready = (state >> 2) & 7, (state >> 5) & 1, (state >> 6) & 1, (state >> 7) & 1
+    if not (compact and ready) or ascii_ or kind not in (1, 2, 4) or sys.getsizeof(text) != 72 + (n + 1) * kind:
+        return text.encode("utf-8")  # (an ASCII str encodes by memcpy; a cached utf-8 copy changes the size: both rare here)
+    ptr = id(text) + 72  # sizeof(PyCompactUnicodeObject)
+    ctype = {1: C.c_uint8, 2: C.c_uint16, 4: C.c_uint32}[kind]
+    probe = (ctype * 8).from_address(ptr), (ctype * 8).from_address(ptr + (n - 8) * kind)
+    if [ord(c) for c in text[:8]] != list(probe[0]) or [ord(c) for c in text[-8:]] != list(probe[1]):
+        return text.encode("utf-8")
+    nb = _u64(0)
+    if _lib.bpe_utf8_encode(kind, C.c_void_p(ptr), n, None, 0, C.byref(nb), threads) != BPE_OK:
+        return text.encode("utf-8")  # (a lone surrogate: str.encode raises the reference's own exception)
+    out = np.empty(nb.value, np.uint8)
+    if _lib.bpe_utf8_encode(kind, C.c_void_p(ptr), n, _ptr(out), len(out), C.byref(nb), threads) != BPE_OK:
+        return text.encode("utf-8")
+    return out
 
 
 def split_offsets(data: bytes, which: int, threads: int = 0):

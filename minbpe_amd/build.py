@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRC = [os.path.join(HERE, "csrc", f) for f in ("bpe_api.hip", "synth.cpp", "split.cpp", "dedup.cpp")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("bpe_api.hip", "synth.cpp", "split.cpp", "dedup.cpp", "utf8.cpp")]
 DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("bpe_kernels.hip", "bpe_device.h", "unicode_tables.h")] + [
     os.path.join(HERE, "csrc", sub, f) for sub in ("kernels", "api")
     for f in sorted(os.listdir(os.path.join(HERE, "csrc", sub)))] + [

@@ -271,7 +271,8 @@ class BasicTokenizer(Tokenizer):
         super().__init__()
 
     def train(self, text, vocab_size, verbose=False):
-        self._train_on_device(text.encode("utf-8"), None, vocab_size, verbose)
+        # (a long text is encoded by all host threads: _native.utf8_encode -- the same bytes as text.encode("utf-8"))
+        self._train_on_device(_native.utf8_encode(text), None, vocab_size, verbose)
 
     def decode(self, ids):
         return b"".join(self.vocab[i] for i in ids).decode("utf-8", errors="replace")
@@ -294,14 +295,15 @@ class RegexTokenizer(Tokenizer):
     def _split(self, text):
         return [piece.encode("utf-8") for piece in re.findall(self.compiled_pattern, text)]
 
-    def _chunked(self, text):
+    def _chunked(self, text, for_training=False):
         """(utf-8 bytes of the chunks back to back, chunk start offsets) -- what
         re.findall(self.compiled_pattern, text) yields (regex.py:41,114).  The two GPT
         patterns go through the native scanner (bpe_split, checked against `regex` in
         tests/test_split.py); any other pattern through the `regex` module itself."""
         which = _NATIVE_SPLIT.get(self.compiled_pattern.pattern)
         if which is not None:
-            data = text.encode("utf-8")
+            # (train() takes any buffer of bytes: a long text is encoded by all host threads there)
+            data = _native.utf8_encode(text) if for_training else text.encode("utf-8")
             return data, _native.split_offsets(data, which)
         return _concat_chunks(self._split(text))
 
@@ -313,7 +315,7 @@ class RegexTokenizer(Tokenizer):
     DEDUP_AUTO_MERGES = 2000
 
     def train(self, text, vocab_size, verbose=False):
-        data, offs = self._chunked(text)
+        data, offs = self._chunked(text, for_training=True)
         wexp = None
         want = (vocab_size - 256 >= self.DEDUP_AUTO_MERGES) if self.dedup == "auto" else bool(self.dedup)
         if want and len(offs) > 1:

@@ -120,3 +120,26 @@ def test_reference_import_paths():
     ranks[b"abc"] = 257
     assert bpe(ranks, b"abc", max_rank=257) == [b"ab", b"c"]
     assert recover_merges(ranks) == {(97, 98): 256, (256, 99): 257}
+
+
+def test_utf8_encode_by_all_threads_equals_str_encode():
+    """_native.utf8_encode (bpe_utf8_encode: a CPython str's code points transcoded by segments in parallel) gives the
+    bytes of text.encode("utf-8") for strings of every storage kind -- Latin-1, BMP, beyond the BMP --, goes to str.encode
+    for short, ASCII or otherwise unfit strings, and leaves a lone surrogate to str.encode's own exception (what the
+    reference raises, basic.py:25)."""
+    import numpy as np
+    from minbpe_amd import _native
+    rng = np.random.default_rng(5)
+    n = (1 << 22) + 12345
+    pools = {1: [0x41, 0x7A, 0xE9, 0xFF, 0x20], 2: [0x41, 0xE9, 0x20AC, 0x4E2D, 0xFFFD, 0x7FF, 0x800],
+             4: [0x41, 0xE9, 0x20AC, 0x1F600, 0x10FFFF, 0x10000, 0xFFFF]}
+    for kind, pool in pools.items():
+        text = "".join(map(chr, rng.choice(pool, n)))
+        got = _native.utf8_encode(text)
+        assert isinstance(got, np.ndarray), kind  # (the native path ran)
+        assert bytes(got) == text.encode("utf-8"), kind
+        assert bytes(_native.utf8_encode(text, threads=3)) == text.encode("utf-8")
+    assert _native.utf8_encode("abc") == b"abc" and _native.utf8_encode("") == b""
+    assert _native.utf8_encode("a" * n) == b"a" * n  # (ASCII: str.encode is a copy already)
+    with pytest.raises(UnicodeEncodeError):
+        _native.utf8_encode("ab\ud800" * (n // 3))
