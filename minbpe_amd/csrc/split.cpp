@@ -317,10 +317,11 @@ int split_docs_impl(const uint8_t *s, uint64_t n, const uint64_t *doc_off, uint6
     return BPE_OK;
 }
 
-// one thread scans a few hundred MB/s; threads only pay on long texts: one per 8 MB, at most 64
+// one thread scans a few hundred MB/s; threads only pay on long texts: one per 8 MB, at most 112 (measured on a
+// 256-thread host, 1 GB: 0.25 s with 32 threads, 0.18 with 64, 0.11 with 96..128, 0.13 with 192)
 int auto_threads(uint64_t n) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(64u, hw), n >> 23));
+    return (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min(112u, hw), n >> 23));
 }
 
 }  // namespace

@@ -52,7 +52,7 @@ inline void write_seg(const T *p, uint64_t n, uint8_t *o) {
 template <typename T>
 int encode_impl(const T *cps, uint64_t n, uint8_t *out, uint64_t cap, uint64_t *n_bytes, int threads) {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    unsigned T_ = threads > 0 ? (unsigned)threads : (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(64u, hw), n >> 22));
+    unsigned T_ = threads > 0 ? (unsigned)threads : (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min(32u, hw), n >> 22));  // (bound by memory: 0.06 s per GB with 32 threads, 0.10 with 64, 0.18 with 128)
     T_ = std::max(1u, T_);
     std::vector<uint64_t> cut(T_ + 1), bytes(T_, 0);
     std::vector<char> ok(T_, 1);
