@@ -62,7 +62,7 @@ void bpe_destroy(bpe_ctx *c) {
     }
     for (hipEvent_t ev : c->ev_pool) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->d_bytes, c->d_offsets, c->d_ids[0], c->d_ids[1], c->d_mat,  c->d_first,
-                    c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_scratch,
+                    c->d_rowmax, c->d_st,     c->d_tsum,   c->d_tile_off, c->d_tile_sin, c->d_sup, c->d_scratch,
                     c->d_delta,  c->d_dirty_list, c->d_dirty_n, c->d_desc, c->d_gdesc, c->d_enc_tmp, c->d_enc_len, c->d_enc_out,
                     c->d_enc_off, c->d_enc_bsum, c->d_enc_long, c->d_ht_keys, c->d_ht_vals, c->d_merge_ids,
                     c->d_dp_folded, c->d_dp_table, c->d_dp_key, c->d_meta[0], c->d_meta[1], c->d_slot_lens,
@@ -102,6 +102,9 @@ int bpe_set_option(bpe_ctx *c, const char *name, int64_t value) {
         c->profile = (int)value;
     } else if (!strcmp(name, "k1")) {
         c->k1 = (int)value;
+    } else if (!strcmp(name, "scan_sup")) {
+        if (value < 0 || value > (1 << 30)) return fail(c, BPE_E_ARG, "scan_sup: 0 .. 2^30 tiles");
+        c->scan_sup_min = (int)value;
     } else if (!strcmp(name, "merge")) {
         if (value != 0 && value != 1) return fail(c, BPE_E_ARG, "merge must be 0 or 1");
         c->merge_impl = (int)value;

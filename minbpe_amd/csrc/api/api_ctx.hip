@@ -53,6 +53,7 @@ struct bpe_ctx {
     DevState *d_st = nullptr;
     uint64_t *d_tsum = nullptr, *d_tile_off = nullptr;
     uint8_t *d_tile_sin = nullptr;
+    unsigned long long *d_sup = nullptr;  // streams of many tiles: the transducers of the super-tiles and their prefixes (k_tile_sup)
     uint64_t cap_tiles = 0;
     IterRec *h_rec = nullptr;  // pinned, device-visible
     int rec_cap = 0;
@@ -221,6 +222,7 @@ struct bpe_ctx {
     int prof_iter = -1;   // iteration being enqueued by bpe_train (-1: not in its loop)
     int prof_stride = 64;  // option "prof_stride"
     bool prof_active = false;
+    int scan_sup_min = 1024;  // the three-pass merge's tile scan: more tiles than this take k_tile_sup / k_tile_scan_sup / k_tile_expand (option scan_sup: 0 = always, 1 << 30 = never)
     int k1 = 2;       // 0 one atomic per position | 1 LDS hash cache (8-byte slots) | 2 = 1 + dense 16-bit LDS table for byte streams | 3 = 2 with the 4-byte-slot LDS cache for general unweighted streams (measured: no faster, both bound by L2 atomics on cold pairs)
     bool stream_is_bytes = false;  // every id of the current stream is < 256 (fresh from k_widen)
 
@@ -315,6 +317,7 @@ int ensure_ids(bpe_ctx *c, uint64_t n) {
         TRY(dev_realloc(c, c->d_tsum, nt));
         TRY(dev_realloc(c, c->d_tile_off, nt));
         TRY(dev_realloc(c, c->d_tile_sin, nt));
+        TRY(dev_realloc(c, c->d_sup, 2 * 3 * (nt / SUP_TILES + 2)));  // (a TS is three 8-byte words)
         TRY(dev_realloc(c, c->d_meta[0], nt));
         TRY(dev_realloc(c, c->d_meta[1], nt));
         TRY(dev_realloc(c, c->d_hdr[0], nt));
@@ -759,8 +762,19 @@ int launch_merge(bpe_ctx *c, uint32_t newid, int iter, IterRec *rec, bool with_d
                            c->d_ids[c->par], c->d_st, c->par, c->d_tsum);
         LAUNCHCHK(c, "k_merge_count");
     }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tsum, nt, c->d_tile_off,
-                       c->d_tile_sin, c->d_st, c->par, rec, iter, c->d_ids[c->par], c->d_dirty_n);
+    if (nt > (uint64_t)c->scan_sup_min) {  // many tiles: three small launches instead of one workgroup's serial walk
+        static_assert(sizeof(TS) == 24, "a TS is three 8-byte words");
+        const uint64_t nsup = (nt + SUP_TILES - 1) / SUP_TILES;
+        TS *ssum = reinterpret_cast<TS *>(c->d_sup), *spre = ssum + (nt / SUP_TILES + 2);
+        hipLaunchKernelGGL(k_tile_sup, dim3((unsigned)nsup), dim3(SUP_TILES), 0, c->stream, c->d_tsum, nt, c->d_st, c->par, ssum);
+        hipLaunchKernelGGL(k_tile_scan_sup, dim3(1), dim3(1024), 0, c->stream, ssum, nsup, spre, c->d_st, c->par, rec, iter,
+                           c->d_ids[c->par], c->d_dirty_n);
+        hipLaunchKernelGGL(k_tile_expand, dim3((unsigned)nsup), dim3(SUP_TILES), 0, c->stream, c->d_tsum, nt, c->d_st, c->par,
+                           spre, c->d_tile_off, c->d_tile_sin);
+    } else {
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, c->d_tsum, nt, c->d_tile_off,
+                           c->d_tile_sin, c->d_st, c->par, rec, iter, c->d_ids[c->par], c->d_dirty_n);
+    }
     LAUNCHCHK(c, "k_tile_scan");
     if (nt) {
         if (with_delta)

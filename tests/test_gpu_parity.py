@@ -74,10 +74,12 @@ def test_get_stats_argmax_merge_vs_oracle(engine, k, n):
                 assert engine.read_chunk_starts().tolist() == exp
 
 
-@pytest.mark.parametrize("mimpl", [0, 1])
-def test_long_runs_cross_tile_boundaries(engine, mimpl):
-    # a == b merges with runs spanning many 4096-id tiles, odd/even lengths
+@pytest.mark.parametrize("mimpl,scan_sup", [(0, 1024), (0, 0), (1, 1024)])
+def test_long_runs_cross_tile_boundaries(engine, mimpl, scan_sup):
+    # a == b merges with runs spanning many 4096-id tiles, odd/even lengths; scan_sup = 0: the tile scan of long
+    # streams (k_tile_sup / k_tile_scan_sup / k_tile_expand) on every stream, 1024 (the default): beyond 1024 tiles
     engine.set_option("merge", mimpl)
+    engine.set_option("scan_sup", scan_sup)
     for n in (4095, 4096, 4097, 12289, 100001, 64 * 4096 + 3, 300 * 4096):
         ids = np.full(n, 7, np.int32)
         engine.load_ids(ids)
@@ -96,6 +98,7 @@ def test_long_runs_cross_tile_boundaries(engine, mimpl):
         engine.merge(pair, 300)
         assert np.array_equal(engine.read_ids(), oracle.merge(ids, pair, 300))
     engine.set_option("merge", 0)
+    engine.set_option("scan_sup", 1024)
 
 
 # ---------------------------------------------------------------------------
@@ -1264,3 +1267,32 @@ def test_gpt4_tokenizer_on_a_toy_rank_table(native):
     assert g.decode(want) == probe and g.decode_batch(want) == probe.encode("utf-8")
     ids = g.encode("<|endoftext|>" + probe[:200], allowed_special="all")
     assert ids[0] == 100257 and ids[1:] == g.encode_ordinary(probe[:200])
+
+
+@pytest.mark.parametrize("k1", [1, 3])
+def test_recount_histogram_variants_vs_oracle(native, k1):
+    """the literal path (mode=0: get_stats of EVERY iteration, base.py:13-22) with each general histogram kernel --
+    k_pair_count_lds (1), k_pair_count_h32 (3): merges and counts =
+    the oracle's, on a GPT-4-split text (chunk flags at every few ids), on one stream without chunks (span ends fall
+    anywhere) and on a two-letter text whose counts pass 2^14 in every workgroup's table (the drain)"""
+    eng = native.Engine(0)
+    eng.set_option("mode", 0)
+    eng.set_option("k1", k1)
+    text = native.synth_text(3_000_000, 17).decode()
+    data, offs = split_chunks(text)
+    exp_pairs, exp_counts, _ = oracle.train(data, 48, offs)
+    eng.load_bytes(data, offs)
+    got = eng.train(48)
+    assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
+    raw = native.synth_text(5_000_003, 18)
+    exp_pairs, exp_counts, _ = oracle.train(raw, 24, None)
+    eng.load_bytes(raw)
+    got = eng.train(24)
+    assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
+    rng = np.random.default_rng(19)
+    ab = rng.integers(97, 99, size=40_000_000, dtype=np.uint8).tobytes()
+    exp_pairs, exp_counts, _ = oracle.train(ab, 6, None)
+    eng.load_bytes(ab)
+    got = eng.train(6)
+    assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
+    eng.close()
