@@ -202,7 +202,10 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
             for (uint32_t j = 0; j < (uint32_t)CH_KSWEEP - 1u; j++) {
                 if (j < tid) {
                     const uint32_t xj = a_xy[j] >> 16, yj = a_xy[j] & 0xFFFFu;
-                    bad |= (xj == x) | (xj == y) | (yj == x) | (yj == y);
+                    // (a SECOND token may be shared: sites of (a, b) and (c, b) never overlap and neither merge moves the
+                    // other's count -- only a pair that could chain onto a site of the batch, x a second token or y a first
+                    // one, stops the walk; first tokens stay distinct: the merge pass looks a pair up by its first token)
+                    bad |= (xj == x) | (xj == y) | (yj == x);
                 }
             }
         }
@@ -462,6 +465,24 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     // ---- maintain: what the last batch made of my entry ------------------------------------------------------------
     uint32_t vx[4] = {0, 0, 0, 0}, vy[4] = {0, 0, 0, 0}, cv[4] = {0, 0, 0, 0}, keepm = 0, ec = 0;
     unsigned long long ekey = 0;
+    // (an entry (x, y) whose x is the second token of SEVERAL batch pairs p has a variant (Z_p, y) -- and (Z_p, Zy) -- for
+    // each of them: counted here, looked up again when they are written; rare, and the four-variant path stays as it was)
+    uint32_t mxm = 0, nmulti = 0;
+    bool multi = false;
+    auto multi_variants = [&](auto &&emit) {
+        const uint32_t zp = s_sw[PW_BZ0];
+        const uint32_t x = vx[0], y = vy[0];
+        const bool hy = vy[2] != y;
+        for (uint32_t m = mxm | 0x80000000u; m; m &= m - 1u) {
+            const uint32_t p = (uint32_t)__ffs((int)m) - 1u;
+            const uint32_t lx = p == 31u ? x : zp + p;
+            for (uint32_t r = 0; r < (hy ? 2u : 1u); r++) {
+                const uint32_t ry = r ? vy[2] : y;
+                const uint32_t c = mat[(size_t)lx * stride + ry];
+                if (c >= theta) emit(lx, ry, c);
+            }
+        }
+    };
     if (tid < n0) {
         const uint32_t Kp = min(s_sw[PW_BK], (uint32_t)CH_KMAX), zp = s_sw[PW_BZ0];
         const PoolEnt e = my_ent;
@@ -470,9 +491,13 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         ekey = e.key;
         int32_t zx = -1, zy = -1;
         for (uint32_t p = 0; p < Kp; p++) {
-            if (s_sw[16 + p] == x) zx = (int32_t)(zp + p);
+            if (s_sw[16 + p] == x) {
+                zx = (int32_t)(zp + p);
+                mxm |= 1u << p;
+            }
             if (s_sw[p] == y) zy = (int32_t)(zp + p);
         }
+        multi = (mxm & (mxm - 1u)) != 0;  // several pairs of the batch end in x (a batch may share second tokens)
         vx[0] = vx[2] = x;
         vx[1] = vx[3] = zx >= 0 ? (uint32_t)zx : x;
         vy[0] = vy[1] = y;
@@ -480,6 +505,8 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         if (zx < 0 && zy < 0) {  // shares no token that matters: untouched
             cv[0] = e.c;
             keepm = 1u;
+        } else if (multi) {
+            multi_variants([&](uint32_t, uint32_t, uint32_t) { nmulti++; });
         } else {
             const bool on[4] = {true, zx >= 0, zy >= 0, zx >= 0 && zy >= 0};
 #pragma unroll
@@ -490,19 +517,31 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     }
     __syncthreads();
     {
-        const uint32_t no = (uint32_t)__popc(keepm);
+        const uint32_t no = multi ? nmulti : (uint32_t)__popc(keepm);
         const uint32_t inc = wave_iscan_add(no);
         if (tid < PL_CAP && lane_id() == 63) s_wtot[wave_id()] = inc;
         __syncthreads();
         if (tid < PL_CAP) {
             uint32_t o = inc - no;
             for (int w = 0; w < wave_id(); w++) o += s_wtot[w];
+            if (multi) {
+                multi_variants([&](uint32_t lx, uint32_t ry, uint32_t c) {
+                    if (o < PL_GATHER) {
+                        a_xy[o] = (lx << 16) | ry;
+                        a_c[o] = c;
+                        a_key[o] = c == ec ? ekey : 0ull;
+                    }
+                    o++;
+                });
+            }
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 if ((keepm >> v) & 1u) {
-                    a_xy[o] = (vx[v] << 16) | vy[v];
-                    a_c[o] = cv[v];
-                    a_key[o] = cv[v] == ec ? ekey : 0ull;  // took over every occurrence: stands where the entry stood
+                    if (o < PL_GATHER) {  // (always, unless entries with several variants came before: n1 > PL_GATHER below)
+                        a_xy[o] = (vx[v] << 16) | vy[v];
+                        a_c[o] = cv[v];
+                        a_key[o] = cv[v] == ec ? ekey : 0ull;  // took over every occurrence: stands where the entry stood
+                    }
                     o++;
                 }
             }
@@ -512,6 +551,7 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
     dstamp(9);
     uint32_t n1 = 0;
     if (n0) for (uint32_t w = 0; w < PL_CAP / 64; w++) n1 += s_wtot[w];
+    if (n1 > PL_GATHER) n1 = 0;  // (more variants than the arrays hold -- shared second tokens only: the pool is gathered afresh)
     bool rebuilt = false;
     // (a hinted launch -- the scanning workgroups stayed -- whose pool could not fill a batch any more gathers a fresh,
     // deeper one instead of merging the last few entries in small batches: the old entries are in it, without their keys)
@@ -724,7 +764,7 @@ pool_sel_body(uint32_t *__restrict__ rowmax, uint32_t *__restrict__ mat, uint32_
         for (uint32_t i = 0; i < (uint32_t)CH_KSWEEP; i++) {
             if (i < nwalk) {
                 const uint32_t xi = b_xy[i] >> 16, yi = b_xy[i] & 0xFFFFu;
-                if (tid != i && tid < s_le[i] && ((xi == x) | (xi == y) | (yi == x) | (yi == y))) s_clash[i] = 1;
+                if (tid != i && tid < s_le[i] && ((xi == x) | (xi == y) | (yi == x))) s_clash[i] = 1;
             }
         }
         if (tid < nwalk && x == y) s_clash[tid] = 1;

@@ -107,3 +107,43 @@ def test_a_created_pair_takes_the_place_of_the_pair_it_consumes():
     # from the state after that merge the walk takes the whole tied level at once
     _, one = reference_next([ids], 1, 100)
     assert batch_by_levels(one, 8)[:3] == [(0, 100), (3, 4), (5, 6)]
+
+
+def batch_by_levels_shared_seconds(chunks, cap):
+    """round 6's rule (k_pool.hip, pool_finish): as batch_by_levels, but only a pair that could CHAIN onto a site of the
+    batch stops the walk -- (x, y) with x a second token or y a first token of a pair taken (and a == b) -- or one whose
+    FIRST token is taken already (the merge pass looks a pair up by its first token).  A second token may be shared: sites
+    of (a, b) and (c, b) never overlap, neither merge changes the other's count, and the pairs a merge lowers or creates
+    are (L, a) / (b, R) and their heirs, which chain onto the batch and stop the walk where they stand."""
+    pairs, counts = stats_in_order(chunks)
+    if not pairs:
+        return []
+    batch, firsts, seconds = [], set(), set()
+    for c in sorted(set(int(x) for x in counts), reverse=True):
+        for (a, b), n in zip(pairs, counts):
+            if int(n) != c:
+                continue
+            if a == b or a in firsts or a in seconds or b in firsts:
+                return batch if batch else [(a, b)]
+            batch.append((a, b))
+            firsts.add(a)
+            seconds.add(b)
+            if len(batch) == cap:
+                return batch
+    return batch
+
+
+@pytest.mark.parametrize("cap", [2, 4, 8, 15])
+def test_batches_that_share_second_tokens_are_the_reference_merges(cap):
+    shared = 0
+    for chunks in streams():
+        next_id = 100
+        for _ in range(40):
+            batch = batch_by_levels_shared_seconds(chunks, cap)
+            if not batch:
+                break
+            want, after = reference_next(chunks, len(batch), next_id)
+            assert want == batch, (cap, batch, want)
+            shared += len({b for _, b in batch}) < len(batch)
+            chunks, next_id = after, next_id + len(batch)
+    assert shared > 30, shared  # the cases this rule is about do occur

@@ -21,6 +21,9 @@ against the oracle's sequence, and at every step boundary evaluates three batch 
            the batch or has a == b.  This IS exact -- a created pair reaches a level only by taking over, in place, a
            pair of that level that shares a token with the batch, where the walk stops anyway: tests/test_level_model.py
            pins it against the reference semantics -- so "free" is the rule to build, "tied" a weaker form of it
+  free_s2, free_rx   (round 6, RULES=free,free_s2,free_rx) "free" with a weaker clash rule: only a pair that could OVERLAP a site
+           of the batch stops the walk -- (x, y) with x a second token or y a first token of the batch (a chain a b d), and
+           a == b; free_s2 still keeps first tokens distinct (the merge pass looks a pair up by its first token)
 
     python tools/level_model.py seq.json [cap ...] > profiles/r4_level_model.json     (seq.json: tools/batch_model.py --make)
 """
@@ -137,6 +140,7 @@ def main():
             return 1
         top = counts[i]
         used = {a, b}
+        firsts, seconds = {a}, {b}
         batch = [pairs[i]]
         j = i + 1
         level = top
@@ -144,12 +148,18 @@ def main():
         while j < M and len(batch) < cap:
             x, y = pairs[j]
             c = t.cnt.get((x, y), 0)
-            if x == y or x in used or y in used or c != counts[j]:  # (c != counts[j]: a pair the batch creates or changes)
+            if rule == "free_s2":    # a second token may be shared: (a, b), (c, b) never overlap and leave each other's counts alone
+                clash = x in firsts or x in seconds or y in firsts
+            elif rule == "free_rx":  # only a chain a b d stops the walk (and a == b): first tokens may be shared too
+                clash = x in seconds or y in firsts
+            else:
+                clash = x in used or y in used
+            if x == y or clash or c != counts[j]:  # (c != counts[j]: a pair the batch creates or changes)
                 break
             if c < level:  # a level below
                 if list_level is not None or in_tied:
                     break
-                if rule in ("free", "free1"):
+                if rule in ("free", "free1", "free_s2", "free_rx"):
                     if rule == "free1" and t.levels.count(c) > 1:
                         in_tied = True  # (one tied level per step: the walk ends with it)
                 else:
@@ -181,10 +191,12 @@ def main():
                 level = c
             batch.append((x, y))
             used |= {x, y}
+            firsts.add(x)
+            seconds.add(y)
             j += 1
         return len(batch)
 
-    rules = ("engine", "tied", "free", "free1", "engine+list", "free+list", "free1+list")
+    rules = tuple(os.environ.get("RULES", "engine,tied,free,free1,engine+list,free+list,free1+list").split(","))
     res = {f"{r}_cap{cap}": {"steps": 0, "next": 0, "by_phase": {}, "list": None, "full": 0} for r in rules for cap in caps}
     edges = [0, 300, 1000, 2000, 4000, 8000, 16000, 24000, M]
     for i in range(M):
