@@ -17,7 +17,10 @@
 //      the list is empty.  (tests/test_list_model.py: CPU model against the reference semantics.)
 //  (2) THE BATCH.  The longest prefix of the list whose pairs have a != b and share no token is what the
 //      reference merges next, in that order, whatever those merges create (a pair that shares a token with
-//      a merged one is not in the prefix, so whatever takes its place comes after the prefix).  Their
+//      a merged one is not in the prefix, so whatever takes its place comes after the prefix).  (Round 6: the
+//      prefix may share SECOND tokens -- (a, b), (c, b): only a pair that could chain onto a site of the batch,
+//      x a second token or y a first one, must stay out; k_pool.hip.  First tokens stay distinct: the pass
+//      below looks a pair up by its first token.)  Their
 //      rewrites commute (no two sites overlap): ONE pass over the candidate slots merges them all, and
 //      charges every site its pair-table delta as the sequential merges would have
 //      (delta format B per pair j: a left neighbour that ends a site of pair i < j already reads Z_i, one of
@@ -59,8 +62,8 @@ __device__ __forceinline__ int chain_match(const uint32_t *pa, const uint32_t *p
     return (w0 == INVALID_WORD) ? -1 : hit;
 }
 
-// One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip) for K >= 2 token-disjoint pairs at
-// once.  DENSE == false: the sparse form (staged headers, global delta replicas, index live).  DENSE == true: the
+// One slot of a chain step's merge pass, by ONE WAVE: merge_ab_wave (k_slots2.hip) for K >= 2 pairs with distinct first
+// tokens, none chaining onto another (second tokens may be shared), at once.  DENSE == false: the sparse form (staged headers, global delta replicas, index live).  DENSE == true: the
 // early passes, where every slot is visited and a pair has millions of sites: headers go to the other header array,
 // the delta into the workgroup's LDS tables sd (per pair p, at sd + p * CH_SD: SL[CH_DCAP] | SR[CH_DCAP] | adj |
 // ids removed; every id is below CH_DCAP), flushed by the kernel when its slots are done.  pa / pb: the pairs (LDS), pb1[p + 1] = pb[p] with
@@ -342,7 +345,7 @@ __device__ __forceinline__ void merge_chain_wave(uint32_t *__restrict__ out, uin
         const uint32_t hi = lane_next(jc[j] & 0xFFu, hi_fill);
         const uint32_t win = lo | (jc[j] << 8) | (hi << 24);
         if (mb[j] == 0) continue;
-        // A lane's four words hold at most TWO sites (token-disjoint pairs: no two sites overlap or touch), and a sparse
+        // A lane's four words hold at most TWO sites (no two sites of a batch overlap), and a sparse
         // pass has one or two sites in a whole slot: the lanes take their FIRST site together, then their second, instead
         // of one round per word position with a lane or two active in each (the site's words by select, not by index).
         uint32_t todo = mb[j];

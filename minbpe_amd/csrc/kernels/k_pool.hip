@@ -13,14 +13,18 @@
 //               order for as long as the entries stay untouched; keys of different epochs are never compared;
 //   a step      maintain (below) -> sort by (count descending, key) -> the levels the walk can reach that hold several
 //               entries and are not CLEAN (all entries of one epoch) are located afresh through the index, all at once
-//               -> the batch = the longest prefix with a != b and no shared token (tests/test_level_model.py: walking
-//               the levels from the top, inside a level in order of first occurrence, is what the reference merges) ->
-//               the rest of the entries is the pool of the next step;
+//               -> the batch = the longest prefix with a != b in which no pair could chain onto a site of another -- (x, y)
+//               with x a second token or y a first token of a pair before it -- and no first token comes twice; a SECOND
+//               token may (round 6: sites of (a, b) and (c, b) never overlap, neither merge moves the other's count, and
+//               what a merge lowers or creates -- (L, a), (b, R) and their heirs -- chains onto the batch and stops the walk
+//               where it stands; tests/test_level_model.py: walking the levels from the top, inside a level in order of first
+//               occurrence, under this rule is what the reference merges) -> the rest of the entries is the pool of the next step;
 //   maintain    after a batch, an entry (x, y) with x the SECOND token of a batch pair (-> Zx) or y the FIRST token of
 //               one (-> Zy) has its occurrences spread over (x, y), (Zx, y), (x, Zy), (Zx, Zy): each of the four that
 //               counts >= theta in the updated table is an entry; the one whose count EQUALS the entry's old count
 //               took over every occurrence and stands where the entry stood (it inherits the key), the others have no
-//               order.  Every other entry is untouched.  No pair from outside the pool can reach theta: a created pair
+//               order.  (Several batch pairs p may end in x: a variant (Z_p, y), (Z_p, Zy) for each.)  Every other entry is
+//               untouched.  No pair from outside the pool can reach theta: a created pair
 //               (L, Z) / (Z, R) / (Zi, Zj) counts at most what (L, a) / (b, R) / (bi, aj) counted before;
 //   rebuild     pool (nearly) empty: the flagged rows are re-scanned (workgroups 1..), the deciding workgroup picks a new
 //               theta from the row maxima -- the deepest of eight candidates M - (M >> s) that at most PL_ROWS rows
@@ -147,7 +151,7 @@ __device__ __forceinline__ void pool_levels_dirty(const unsigned long long *key,
     __syncthreads();
 }
 // The end of a selection, once the keys are what they are going to be (b_*: the pool sorted by count, s_ls / s_le its
-// level bounds): the order inside every level, the batch -- the longest prefix with a != b, no shared token, every level
+// level bounds): the order inside every level, the batch -- the longest prefix with a != b, no pair chaining onto another, no first token twice, every level
 // it enters in a known order --, the step's state, and the rest of the entries as the next step's pool.  Every thread of
 // the deciding workgroup calls (blockDim.x >= PL_CAP).
 __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ pool, const uint32_t *b_xy, const uint32_t *b_c,
@@ -192,7 +196,7 @@ __device__ __forceinline__ void pool_finish(DevState *st, PoolEnt *__restrict__ 
         s_dirty[r] = X.dl[lo];
     }
     __syncthreads();
-    // ---- the batch: the longest prefix with a != b, no shared token, every level entered in a known order -----------------
+    // ---- the batch: the longest prefix with a != b, no chain, no first token twice, every level entered in a known order ----
     if (tid < 64) {  // (nwalk <= CH_KSWEEP < 64: one wave)
         uint32_t bad = 0;
         if (tid < nwalk) {
