@@ -58,7 +58,8 @@ int bpe_set_stream(bpe_ctx *ctx, void *hip_stream);
  *   pass visits the slots the index names and keeps the index current), "enc_cache" (1), "enc_chain" (1),
  *   "sparse_ratio" (1), "tie_index" (1), "rep_min" (4), "rep_max" (8: log2 of delta replicas),
  *   "lds_delta" (1), "depth" (8: iterations the host runs ahead), "prof_stride" (64), "merge", "k1",
- *   "lb_tune". */
+ *   "lb_tune", "scan_sup" (1024: the three-pass merge scans the tile summaries of streams of more tiles
+ *   than this in three small launches instead of one workgroup). */
 int bpe_set_option(bpe_ctx *ctx, const char *name, int64_t value);
 
 /* ---- input ----------------------------------------------------------------- */

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """get_stats kernels of the literal path (mode=0) on the headline input, timed at several depths of training:
-median device time of the pair-count pass per k1 variant, every variant's arg-max checked against k1=1's."""
+median device time of the pair-count pass per k1 variant (1 = k_pair_count_lds, the default of general streams; 3 =
+k_pair_count_h32; profiles/r6_ap_pair_count_phases.patch adds 4 = its phased form and the timing-only 7 / 8 / 9: misses
+dropped / and no flush / loads only), every variant's arg-max checked against the first one's."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +11,7 @@ import bench
 from minbpe_amd import Engine
 name = sys.argv[1] if len(sys.argv) > 1 else "regex1g"
 depths = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "64,512,1024").split(",")]
-variants = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,3,4,5,6,7,8").split(",")]
+variants = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,3").split(",")]
 reps = int(os.environ.get("REPS", 5))
 data, offs, _ = bench.make_input(dict(bench.WORKLOADS[name]))
 eng = Engine(0)
