@@ -141,6 +141,7 @@ def main():
         top = counts[i]
         used = {a, b}
         firsts, seconds = {a}, {b}
+        mode = None
         batch = [pairs[i]]
         j = i + 1
         level = top
@@ -152,6 +153,16 @@ def main():
                 clash = x in firsts or x in seconds or y in firsts
             elif rule == "free_rx":  # only a chain a b d stops the walk (and a == b): first tokens may be shared too
                 clash = x in seconds or y in firsts
+            elif rule == "free_e2":  # a batch shares EITHER second tokens OR first tokens (whichever it meets first)
+                clash = x in seconds or y in firsts
+                if not clash and x in firsts:
+                    clash = mode == "s"
+                    if not clash:
+                        mode = "f"
+                if not clash and y in seconds:
+                    clash = mode == "f"
+                    if not clash:
+                        mode = "s"
             else:
                 clash = x in used or y in used
             if x == y or clash or c != counts[j]:  # (c != counts[j]: a pair the batch creates or changes)
@@ -159,7 +170,7 @@ def main():
             if c < level:  # a level below
                 if list_level is not None or in_tied:
                     break
-                if rule in ("free", "free1", "free_s2", "free_rx"):
+                if rule in ("free", "free1", "free_s2", "free_rx", "free_e2"):
                     if rule == "free1" and t.levels.count(c) > 1:
                         in_tied = True  # (one tied level per step: the walk ends with it)
                 else:
