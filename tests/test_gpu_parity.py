@@ -1296,3 +1296,25 @@ def test_recount_histogram_variants_vs_oracle(native, k1):
     got = eng.train(6)
     assert got["pairs"] == exp_pairs and got["counts"] == exp_counts
     eng.close()
+
+
+def test_load_bytes_refuses_bad_offsets_wherever_they_are(engine):
+    """bpe_load_bytes checks the chunk offsets on the host before anything is uploaded (they must ascend and stay <= n) --
+    with up to 16 threads once there are 2^22 of them: the FIRST bad index is named, as by one thread, whichever segment
+    it falls in and also when several segments hold one; a good list of that size loads."""
+    n_chunks = (1 << 22) + 12345
+    data = np.full(2 * n_chunks, 97, np.uint8).tobytes()
+    good = (np.arange(n_chunks, dtype=np.uint64) * 2)
+    engine.load_bytes(data, good)
+    assert len(engine) == len(data)
+    for where in ([7], [n_chunks // 2 + 3], [n_chunks - 1], [n_chunks // 3, 2 * n_chunks // 3 + 1, n_chunks - 5]):
+        bad = good.copy()
+        for w in where:
+            bad[w] = bad[w - 1] - 1  # (descends at w)
+        with pytest.raises(ValueError, match=rf"chunk_offsets\[{where[0]}\] = .*ascend"):
+            engine.load_bytes(data, bad)
+    bad = good.copy()
+    bad[n_chunks - 2] = len(data) + 1  # beyond the text
+    with pytest.raises(ValueError, match=rf"chunk_offsets\[{n_chunks - 2}\]"):
+        engine.load_bytes(data, bad)
+    engine.load_bytes(data, good)
