@@ -309,15 +309,22 @@ class RegexTokenizer(Tokenizer):
 
     # Train on the DISTINCT chunks, each weighted by how often it occurs (bpe_dedup_chunks):
     # same merges, counts and tie-breaks as over the full chunk list, a fraction
-    # of the stream.  The host pass costs about as much as ~1500 device merges over the full
-    # list (profiles/r1_notes.md), so "auto" turns it on from 2000; True / False force it.
+    # of the stream.  True / False force it.  "auto": round 1's engine made the host pass worth
+    # ~1500 device merges over the full list, so it was on from 2000 merges (DEDUP_AUTO_MERGES:
+    # still the rule of the sharded path, dist.py); since round 6 the device trains 1 GB to
+    # vocab 32000 in 0.58 s against 0.19 s on the distinct chunks, and the host pass costs
+    # 0.45-0.6 s per GB on a 256-thread host (profiles/r6_final_bench.json: the whole call 0.88 s
+    # without it, 1.09 s with it) -- so a single process turns it on only for texts of
+    # DEDUP_AUTO_BYTES or more, where the stream nears the 2^32-byte limit of one GPU
+    #  and the distinct chunks are what still fits.
     dedup = "auto"
     DEDUP_AUTO_MERGES = 2000
+    DEDUP_AUTO_BYTES = 1 << 31
 
     def train(self, text, vocab_size, verbose=False):
         data, offs = self._chunked(text, for_training=True)
         wexp = None
-        want = (vocab_size - 256 >= self.DEDUP_AUTO_MERGES) if self.dedup == "auto" else bool(self.dedup)
+        want = (len(data) >= self.DEDUP_AUTO_BYTES) if self.dedup == "auto" else bool(self.dedup)
         if want and len(offs) > 1:
             data, offs, wexp, _ = _native.dedup_chunks(data, offs)
         self._train_on_device(data, offs, vocab_size, verbose, wexp)
